@@ -1,0 +1,23 @@
+# Build libegnn_amd.so (gfx950 only).  `python -c "import __graft_entry__ as g; g.build()"` runs this.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH  ?= gfx950
+CSRC  := diffusion_model_amd/csrc
+OUT   := diffusion_model_amd/libegnn_amd.so
+SRCS  := $(CSRC)/egnn_forward.hip $(CSRC)/sampler.hip
+HDRS  := $(CSRC)/common.h include/egnn_amd.h
+FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -ffp-contract=off
+
+OBJS := $(SRCS:.hip=.o)
+
+all: $(OUT)
+
+%.o: %.hip $(HDRS)
+	$(HIPCC) $(FLAGS) -c $< -o $@
+
+$(OUT): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@
+
+clean:
+	rm -f $(OBJS) $(OUT)
+
+.PHONY: all clean

@@ -1,0 +1,79 @@
+"""ctypes binding of libegnn_amd.so (C ABI: include/egnn_amd.h).  No fallback: if the library
+is missing or a call fails, an exception is raised."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libegnn_amd.so")
+
+PREC_F32, PREC_BF16 = 0, 1
+NORM_CALL, NORM_GRAPH = 0, 1
+PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "float32": PREC_F32, "bf16": PREC_BF16, "bfloat16": PREC_BF16}
+NORM_SCOPES = {"call": NORM_CALL, "graph": NORM_GRAPH}
+
+_vp, _i, _f, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_uint64
+_fp = C.POINTER(C.c_float)
+
+# name -> (restype, argtypes); kept in one table so tests can check every header symbol is exported
+SIGNATURES = {
+    "egnn_last_error": (C.c_char_p, []),
+    "egnn_version": (_i, []),
+    "egnn_create": (_i, [C.POINTER(_vp), _i]),
+    "egnn_destroy": (_i, [_vp]),
+    "egnn_set_model": (_i, [_vp] + [_i] * 6),
+    "egnn_pack_layer": (_i, [_vp, _vp, _i] + [_vp] * 16),
+    "egnn_set_graph": (_i, [_vp, _i, _i, _i] + [_vp] * 5),
+    "egcl_forward": (_i, [_vp, _vp, _i, _i, _i] + [_vp] * 4),
+    "egnn_forward": (_i, [_vp, _vp, _i, _i] + [_vp] * 4),
+    "egnn_eps": (_i, [_vp, _i, _i, _i, _vp, _i] + [_vp] * 5),
+    "egnn_remove_mean": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
+    "schedule_table_build": (_i, [_i, C.c_double, C.c_double, _fp, _fp, _fp]),
+    "schedule_table_from_alpha": (_i, [_i, _fp, _fp, _fp]),
+    "ddpm_reverse_step": (_i, [_vp, _i, _i, _i, _vp, _i, _f, _f, _f, _vp, _i, _vp, _vp, _vp, _i]),
+    "egnn_sampler_prepare": (_i, [_vp, _i, _i, _f, _vp, _vp, _u64]),
+    "egnn_sampler_init": (_i, [_vp, _vp, _vp, _vp]),
+    "egnn_sampler_run": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "egnn_sampler_final": (_i, [_vp, _vp, _i, _i] + [_vp] * 5),
+    "egnn_sampler_state": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(_i)]),
+    "egnn_profile_enable": (_i, [_vp, _i]),
+    "egnn_profile_read": (_i, [_vp, _fp, C.POINTER(_i), _fp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build the HIP extension first (`make` at the repo root or "
+                "`python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+class EgnnError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().egnn_last_error()
+        raise EgnnError(f"libegnn_amd error {rc}: {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(stream=None):
+    import torch
+    s = torch.cuda.current_stream() if stream is None else stream
+    return C.c_void_p(s.cuda_stream)

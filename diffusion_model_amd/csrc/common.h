@@ -1,0 +1,107 @@
+// Shared declarations of libegnn_amd (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+#include "../../include/egnn_amd.h"
+
+namespace egnn {
+
+constexpr int kThreads = 256;   // 4 wave64 per workgroup, one per SIMD
+constexpr int kWaves = 4;
+constexpr int kMaxCB = 8;       // 32-column blocks per wave in the fused edge GEMMs (N <= 1024)
+
+void set_error(const char* fmt, ...);
+
+#define EGNN_HIP(call)                                                                      \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess) {                                                                 \
+      egnn::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return EGNN_EHIP;                                                                     \
+    }                                                                                       \
+  } while (0)
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// Packed parameters of one EGCL layer (all device memory, owned by the context).
+struct LayerPack {
+  bool packed = false;
+  float* w1catT = nullptr;   // [H][TC]  transposed first-layer weights, columns = {Px|Qx|Pm|Qm}
+  float* b1cat = nullptr;    // [TC]     first-layer bias (P columns only)
+  float* wdx = nullptr;      // [WxP]    d^2 column of mlp_x.0
+  float* wdm = nullptr;      // [WmP]    d^2 column of mlp_m.0
+  float* w2x_f32 = nullptr;  // mlp_x.2 as f32 MFMA B fragments  [NB][KS4][64][4]
+  void* w2x_bf16 = nullptr;  // mlp_x.2 as bf16 MFMA B fragments [NB][KS][64][8]
+  float* b2x = nullptr;      // [WxP]
+  float* w3x = nullptr;      // [WxP]    mlp_x.4 weight
+  float* w2m_f32 = nullptr;  // mlp_m.2 fragments, N = MP, K = WmP
+  void* w2m_bf16 = nullptr;
+  float* b2m = nullptr;      // [MP]
+  float* wa = nullptr;       // [MP]     attention.0 weight
+  float* scal = nullptr;     // [4]      {mlp_x.4 bias, attention.0 bias}
+  float* w1h_f32 = nullptr;  // mlp_h.0 fragments, N = WhP, K = K1P (= pad8(H+MP))
+  float* b1h = nullptr;      // [WhP]
+  float* w2h_f32 = nullptr;  // mlp_h.2 fragments, N = HP, K = WhP
+  float* b2h = nullptr;      // [HP]
+};
+
+struct Sampler {
+  bool ready = false;
+  int T = 0, A = 0, t = 0;
+  float onehot_scale = 1.f;
+  uint64_t seed = 0;
+  const float* d_table = nullptr;  // [(T+1)*4] caller-owned
+  float* pos = nullptr;            // [N][3]
+  float* h = nullptr;              // [N][H]
+  float* h_out = nullptr;          // [N][H]
+  float* x_out = nullptr;          // [N][3]
+  float* cond = nullptr;           // [N][H-A-1] constant conditioning block
+  int* t_dev = nullptr;            // current t on device (graph replay reads it)
+  int* bad = nullptr;              // [B] sticky non-finite flags
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  int graph_prec = -1, graph_norm = -1;
+};
+
+}  // namespace egnn
+
+struct egnn_ctx {
+  int device = 0;
+  // model
+  int L = 0, H = 0, M = 0, Wm = 0, Wx = 0, Wh = 0;
+  int WxP = 0, WmP = 0, MP = 0, WhP = 0, HP = 0, K1P = 0, TC = 0;
+  int cbx = 0, cbm = 0;  // 32-column blocks per wave for the x / m second-layer GEMMs
+  std::vector<egnn::LayerPack> layers;
+  // graph
+  int N = 0, E = 0, B = 0;
+  const int32_t *edge_dst = nullptr, *edge_src = nullptr, *row_ptr = nullptr, *graph_ptr = nullptr,
+                *node_graph = nullptr;
+  // scratch (grown on demand by reserve())
+  size_t cap_nodes = 0, cap_tiles = 0, cap_graphs = 0;
+  float* table = nullptr;    // [N][TC] first-layer partial pre-activations
+  float* agg_m = nullptr;    // [N][MP]
+  float* agg_x = nullptr;    // [N][4]
+  float* part_m = nullptr;   // [tiles][2][MP]
+  float* part_x = nullptr;   // [tiles][2][4]
+  float* node_d2 = nullptr;  // [N]
+  float* gscale = nullptr;   // [B] 1/(G+1)
+  float* h_tmp[2] = {nullptr, nullptr};  // [N][H] ping-pong between layers
+  float* x_tmp[2] = {nullptr, nullptr};  // [N][3]
+  egnn::Sampler smp;
+  // profiling
+  bool prof = false;
+  std::vector<hipEvent_t> ev;  // pairs
+  std::vector<int> ev_kind;    // 0 = edge kernel, 1 = node kernels
+  size_t ev_used = 0;
+};
+
+namespace egnn {
+int reserve(egnn_ctx* c);
+int launch_layer(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_scope, const float* h,
+                 const float* x, float* h_out, float* x_out);
+int edge_rows_per_tile(int prec);
+}  // namespace egnn

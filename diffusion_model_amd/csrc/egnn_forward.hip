@@ -1,0 +1,1013 @@
+// EGNN denoiser forward path for MI355X (gfx950 / CDNA4).
+//
+// One EGCL layer (reference: EquivariantGraphNeuralNetwork.py:55-71) is three launches:
+//
+//   node_pre   per node: first-layer partial pre-activations of BOTH edge MLPs.  The reference
+//              feeds [h_i | h_j | d^2] (2H+1 wide) through Linear(2H+1, W) per EDGE (:56-57,:63-64);
+//              because that layer is linear in its input, W1.[h_i|h_j|d2] + b =
+//              (W1[:, :H] h_i + b) + (W1[:, H:2H] h_j) + W1[:, 2H] d2, so it is evaluated once per
+//              NODE into a table {Px|Qx|Pm|Qm} and the per-edge work is two row reads and one fma.
+//   edge       fused per-edge chain on a tile of R edges (CSR order, sorted by receiving node):
+//              gather (x_i, x_j, table rows) -> d^2 -> SiLU -> second-layer GEMMs on MFMA with the
+//              [R, W] hidden activations living only in LDS/registers -> SiLU -> mlp_x.4 dot /
+//              attention gate -> segment sums per receiving node.  No [E, *] tensor reaches HBM.
+//   node_post  per node: gather the segment sums, mlp_h on MFMA (hidden never leaves the CU),
+//              coordinate update x' = x + sum_x / (G + 1).
+//
+// Precision: EGNN_PREC_F32 uses v_mfma_f32_32x32x2_f32 (exact fp32 fma chains); EGNN_PREC_BF16 uses
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation for the two big per-edge GEMMs.  Geometry (d^2,
+// coordinate differences), SiLU/sigmoid, all segment sums and the node MLP stay fp32 in both.
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace egnn {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __forceinline__ float silu_f(float v) {
+  // v * sigmoid(v); exp(-v) = inf for very negative v gives rcp = 0 and the correct limit -0
+  return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+}
+__device__ __forceinline__ float sigmoid_f(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
+// row of accumulator register `reg` of a 32x32 MFMA tile for this lane (C/D layout, gfx950)
+__device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// ------------------------------------------------------------------------------------------------
+// parameter packing
+// ------------------------------------------------------------------------------------------------
+// B fragments of D = A.B with B[k][n] = W[n][k] (nn.Linear weight [Nout, K], leading dim ldw,
+// column offset koff) for v_mfma_f32_32x32x2_f32: lane l holds B[k = 2*ks + (l>>5)][n = 32*nb + (l&31)].
+// Four consecutive k-steps are stored together so one 16-byte load per lane feeds 4 MFMAs:
+// out[((nb*KS4 + ks4)*64 + lane)*4 + s] = W[32nb + (l&31)][8*ks4 + 2*s + (l>>5)].
+__global__ void pack_frags_f32(const float* __restrict__ W, int Nout, int K, int ldw, int NP, int KP,
+                               float* __restrict__ out) {
+  const int KS4 = KP / 8;
+  const size_t total = (size_t)(NP / 32) * KS4 * 64 * 4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int s = i & 3, lane = (i >> 2) & 63;
+    const size_t f = i >> 8;
+    const int ks4 = f % KS4, nb = f / KS4;
+    const int n = 32 * nb + (lane & 31), k = 8 * ks4 + 2 * s + (lane >> 5);
+    out[i] = (n < Nout && k < K) ? W[(size_t)n * ldw + k] : 0.f;
+  }
+}
+// v_mfma_f32_32x32x16_bf16: lane l holds B[k = 16*ks + 8*(l>>5) + j][n = 32*nb + (l&31)], j = 0..7.
+// out[((nb*KS + ks)*64 + lane)*8 + j]
+__global__ void pack_frags_bf16(const float* __restrict__ W, int Nout, int K, int ldw, int NP, int KP,
+                                __bf16* __restrict__ out) {
+  const int KS = KP / 16;
+  const size_t total = (size_t)(NP / 32) * KS * 64 * 8;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int j = i & 7, lane = (i >> 3) & 63;
+    const size_t f = i >> 9;
+    const int ks = f % KS, nb = f / KS;
+    const int n = 32 * nb + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + j;
+    out[i] = (__bf16)((n < Nout && k < K) ? W[(size_t)n * ldw + k] : 0.f);
+  }
+}
+__global__ void pad_copy(const float* __restrict__ src, int n, int stride, float* __restrict__ dst, int nP) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nP; i += gridDim.x * blockDim.x)
+    dst[i] = i < n ? src[(size_t)i * stride] : 0.f;
+}
+// first layers of mlp_x / mlp_m, split per input block and transposed: w1catT[h][col]
+__global__ void pack_first(const float* __restrict__ x0_w, const float* __restrict__ x0_b,
+                           const float* __restrict__ m0_w, const float* __restrict__ m0_b, int H, int Wx,
+                           int Wm, int WxP, int WmP, float* __restrict__ w1catT, float* __restrict__ b1cat) {
+  const int TC = 2 * WxP + 2 * WmP, ld = 2 * H + 1;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < TC * (H + 1); i += gridDim.x * blockDim.x) {
+    const int col = i % TC, h = i / TC;  // h == H -> bias row
+    int k, W, hoff;
+    const float *w, *b;
+    if (col < WxP) { k = col; W = Wx; hoff = 0; w = x0_w; b = x0_b; }
+    else if (col < 2 * WxP) { k = col - WxP; W = Wx; hoff = H; w = x0_w; b = nullptr; }
+    else if (col < 2 * WxP + WmP) { k = col - 2 * WxP; W = Wm; hoff = 0; w = m0_w; b = m0_b; }
+    else { k = col - 2 * WxP - WmP; W = Wm; hoff = H; w = m0_w; b = nullptr; }
+    if (h < H) w1catT[(size_t)h * TC + col] = k < W ? w[(size_t)k * ld + hoff + h] : 0.f;
+    else b1cat[col] = (k < W && b) ? b[k] : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// node_pre: table[n][col] = b1cat[col] + sum_h h[n][h] * w1catT[h][col]
+// ------------------------------------------------------------------------------------------------
+constexpr int kPreNodes = 16;
+__global__ __launch_bounds__(kThreads) void node_pre_kernel(const float* __restrict__ h, int N, int H,
+                                                            const float* __restrict__ w1catT,
+                                                            const float* __restrict__ b1cat, int TC,
+                                                            float* __restrict__ table) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* hs = reinterpret_cast<float*>(smem_raw);  // [kPreNodes][H]
+  const int n0 = blockIdx.x * kPreNodes;
+  for (int i = threadIdx.x; i < kPreNodes * H; i += kThreads) {
+    const int n = n0 + i / H;
+    hs[i] = n < N ? h[(size_t)n * H + i % H] : 0.f;
+  }
+  __syncthreads();
+  const int col = blockIdx.y * kThreads + threadIdx.x;
+  if (col >= TC) return;
+  float acc[kPreNodes];
+  const float b = b1cat[col];
+#pragma unroll
+  for (int i = 0; i < kPreNodes; ++i) acc[i] = b;
+  for (int k = 0; k < H; ++k) {
+    const float w = w1catT[(size_t)k * TC + col];
+#pragma unroll
+    for (int i = 0; i < kPreNodes; ++i) acc[i] = fmaf(hs[i * H + k], w, acc[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < kPreNodes; ++i)
+    if (n0 + i < N) table[(size_t)(n0 + i) * TC + col] = acc[i];
+}
+
+// node_d2[n] = sum over the edges received by n of |x_n - x_src|^2 (fixed order -> deterministic)
+__global__ void node_d2_kernel(const float* __restrict__ x, const int* __restrict__ row_ptr,
+                               const int* __restrict__ edge_src, int N, float* __restrict__ node_d2) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const float x0 = x[3 * n], x1 = x[3 * n + 1], x2 = x[3 * n + 2];
+  float s = 0.f;
+  for (int e = row_ptr[n]; e < row_ptr[n + 1]; ++e) {
+    const int j = edge_src[e];
+    const float a = x0 - x[3 * j], b = x1 - x[3 * j + 1], c = x2 - x[3 * j + 2];
+    s += a * a + b * b + c * c;
+  }
+  node_d2[n] = s;
+}
+// gscale[g] = 1 / (sqrt(sum_{n in g} node_d2[n]) + 1); one workgroup per graph (or one in 'call' scope)
+__global__ __launch_bounds__(kThreads) void graph_scale_kernel(const float* __restrict__ node_d2,
+                                                               const int* __restrict__ graph_ptr, int N,
+                                                               int per_graph, float* __restrict__ gscale) {
+  __shared__ float red[kThreads];
+  const int lo = per_graph ? graph_ptr[blockIdx.x] : 0;
+  const int hi = per_graph ? graph_ptr[blockIdx.x + 1] : N;
+  float s = 0.f;
+  for (int n = lo + threadIdx.x; n < hi; n += kThreads) s += node_d2[n];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = kThreads / 2; w > 0; w >>= 1) {
+    if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) gscale[blockIdx.x] = 1.0f / (sqrtf(red[0]) + 1.0f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused edge kernel
+// ------------------------------------------------------------------------------------------------
+struct EdgeParams {
+  int N, E;
+  const int* edge_dst;
+  const int* edge_src;
+  const int* row_ptr;
+  const float* x;      // [N][3]
+  const float* table;  // [N][TC]
+  int TC, WxP, WmP, MP, cbx, cbm;
+  const float *wdx, *wdm, *b2x, *w3x, *b2m, *wa, *scal;
+  const void *w2x, *w2m;
+  float *agg_m, *agg_x, *part_m, *part_x;
+};
+
+// layout helper used by both host (size) and device (carve): ints/floats 12*R*4 bytes, then 2 A1
+// buffers, then the message tile.
+__host__ __device__ inline size_t edge_smem_small(int R) { return (size_t)12 * R * 4; }
+__host__ __device__ inline size_t edge_a1_bytes(int R) {
+  const size_t bf = (size_t)8 * (R + 1) * 16, f32 = (size_t)32 * R * 4;
+  return (bf > f32 ? bf : f32);
+}
+__host__ __device__ inline size_t edge_smem_bytes(int R, int MP) {
+  return edge_smem_small(R) + 2 * edge_a1_bytes(R) + (size_t)R * (MP + 1) * 4;
+}
+
+// ---- second-layer GEMM of one edge MLP over a tile of R = 32*RB edges --------------------------
+// acc[rb][cb] (+)= SiLU(P[dst] + Q[src] + wd*d2)[R, KP] . W2^T[KP, wave's 32*CB columns]
+// The hidden activation is produced KC columns at a time into a double-buffered LDS chunk that all
+// four waves read as MFMA A fragments; each wave streams its own B fragments straight from the
+// packed weights (one coalesced 1 KiB load per fragment).
+template <int RB, int CB>
+__device__ __forceinline__ void gemm_bf16(const float* __restrict__ table, int TC, int offP, int offQ,
+                                          const float* __restrict__ wd, int KP,
+                                          const bf16x8* __restrict__ w2, const int* s_dst,
+                                          const int* s_src, const float* s_d2, char* s_a1,
+                                          f32x16 (&acc)[RB][CB]) {
+  constexpr int R = 32 * RB, RPAD = R + 1, KC = 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int NC = KP / KC, KS = KP / 16;
+  const size_t bufBytes = edge_a1_bytes(R);
+  const int kg = tid & 7, rsub = tid >> 3;  // 8 k-groups of 8 columns, 32 rows per pass
+
+  const bf16x8* wb[CB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) wb[cb] = w2 + ((size_t)(wave * CB + cb) * KS) * 64 + lane;
+
+  auto build = [&](int c, char* buf) {
+    const int k0 = c * KC + kg * 8;
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(wd + k0), w1 = *reinterpret_cast<const f32x4*>(wd + k0 + 4);
+#pragma unroll
+    for (int pass = 0; pass < RB; ++pass) {
+      const int row = pass * 32 + rsub;
+      const float* pp = table + (size_t)s_dst[row] * TC + offP + k0;
+      const float* qq = table + (size_t)s_src[row] * TC + offQ + k0;
+      const f32x4 p0 = *reinterpret_cast<const f32x4*>(pp), p1 = *reinterpret_cast<const f32x4*>(pp + 4);
+      const f32x4 q0 = *reinterpret_cast<const f32x4*>(qq), q1 = *reinterpret_cast<const f32x4*>(qq + 4);
+      const float d2 = s_d2[row];
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[j] = (__bf16)silu_f(fmaf(w0[j], d2, p0[j] + q0[j]));
+        o[j + 4] = (__bf16)silu_f(fmaf(w1[j], d2, p1[j] + q1[j]));
+      }
+      *reinterpret_cast<bf16x8*>(buf + ((size_t)kg * RPAD + row) * 16) = o;
+    }
+  };
+
+  build(0, s_a1);
+  __syncthreads();
+  bf16x8 bcur[CB], bnxt[CB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) bcur[cb] = wb[cb][0];
+
+  for (int c = 0; c < NC; ++c) {
+    char* cur = s_a1 + (c & 1) * bufBytes;
+    char* nxt = s_a1 + ((c + 1) & 1) * bufBytes;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int ks = c * 4 + s;
+      const int ksn = ks + 1 < KS ? ks + 1 : ks;  // last prefetch re-reads the final fragment (in bounds)
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) bnxt[cb] = wb[cb][(size_t)ksn * 64];
+      bf16x8 a[RB];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+        a[rb] = *reinterpret_cast<const bf16x8*>(cur + ((size_t)(s * 2 + hh) * RPAD + 32 * rb + r) * 16);
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+          acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rb], bcur[cb], acc[rb][cb], 0, 0, 0);
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) bcur[cb] = bnxt[cb];
+    }
+    if (c + 1 < NC) build(c + 1, nxt);
+    __syncthreads();
+  }
+}
+
+template <int RB, int CB>
+__device__ __forceinline__ void gemm_f32(const float* __restrict__ table, int TC, int offP, int offQ,
+                                         const float* __restrict__ wd, int KP,
+                                         const f32x4* __restrict__ w2, const int* s_dst, const int* s_src,
+                                         const float* s_d2, char* s_a1, f32x16 (&acc)[RB][CB]) {
+  constexpr int R = 32 * RB, KC = 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int NC = KP / KC, KS4 = KP / 8;
+  const size_t bufBytes = edge_a1_bytes(R);
+  const int kg = tid & 3, rsub = tid >> 2;  // 4 k-groups of 8 columns, 64 rows per pass
+
+  const f32x4* wb[CB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) wb[cb] = w2 + ((size_t)(wave * CB + cb) * KS4) * 64 + lane;
+
+  auto build = [&](int c, float* buf) {
+    const int k0 = c * KC + kg * 8;
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(wd + k0), w1 = *reinterpret_cast<const f32x4*>(wd + k0 + 4);
+#pragma unroll
+    for (int pass = 0; pass < (R + 63) / 64; ++pass) {
+      const int row = pass * 64 + rsub;
+      if (row < R) {
+        const float* pp = table + (size_t)s_dst[row] * TC + offP + k0;
+        const float* qq = table + (size_t)s_src[row] * TC + offQ + k0;
+        const f32x4 p0 = *reinterpret_cast<const f32x4*>(pp), p1 = *reinterpret_cast<const f32x4*>(pp + 4);
+        const f32x4 q0 = *reinterpret_cast<const f32x4*>(qq), q1 = *reinterpret_cast<const f32x4*>(qq + 4);
+        const float d2 = s_d2[row];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          buf[(kg * 8 + j) * R + row] = silu_f(fmaf(w0[j], d2, p0[j] + q0[j]));
+          buf[(kg * 8 + 4 + j) * R + row] = silu_f(fmaf(w1[j], d2, p1[j] + q1[j]));
+        }
+      }
+    }
+  };
+
+  build(0, reinterpret_cast<float*>(s_a1));
+  __syncthreads();
+  for (int c = 0; c < NC; ++c) {
+    const float* cur = reinterpret_cast<const float*>(s_a1 + (c & 1) * bufBytes);
+    float* nxt = reinterpret_cast<float*>(s_a1 + ((c + 1) & 1) * bufBytes);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {  // 4 groups of 4 k-steps (k-step = 2 columns)
+      f32x4 b[CB];
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) b[cb] = wb[cb][(size_t)(c * 4 + g) * 64];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float a[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) a[rb] = cur[(8 * g + 2 * s + hh) * R + 32 * rb + r];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb)
+            acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rb], b[cb][s], acc[rb][cb], 0, 0, 0);
+      }
+    }
+    if (c + 1 < NC) build(c + 1, nxt);
+    __syncthreads();
+  }
+}
+
+template <int PREC, int RB, int CB>
+__device__ __forceinline__ void run_gemm(const EdgeParams& p, int offP, int offQ, const float* wd, int KP,
+                                         const void* w2, const int* s_dst, const int* s_src,
+                                         const float* s_d2, char* s_a1, f32x16 (&acc)[RB][CB]) {
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[rb][cb][i] = 0.f;
+  if constexpr (PREC == EGNN_PREC_BF16)
+    gemm_bf16<RB, CB>(p.table, p.TC, offP, offQ, wd, KP, reinterpret_cast<const bf16x8*>(w2), s_dst, s_src,
+                      s_d2, s_a1, acc);
+  else
+    gemm_f32<RB, CB>(p.table, p.TC, offP, offQ, wd, KP, reinterpret_cast<const f32x4*>(w2), s_dst, s_src,
+                     s_d2, s_a1, acc);
+}
+
+// mlp_x: s[row] = b3 + sum_n w3[n] * SiLU(acc[row][n] + b2[n])      (EquivariantGraphNeuralNetwork.py:19-25)
+template <int PREC, int RB, int CB>
+__device__ __forceinline__ void phase_x(const EdgeParams& p, const int* s_dst, const int* s_src,
+                                     const float* s_d2, char* s_a1, float* s_part) {
+  constexpr int R = 32 * RB;
+  f32x16 acc[RB][CB];
+  run_gemm<PREC, RB, CB>(p, 0, p.WxP, p.wdx, p.WxP, p.w2x, s_dst, s_src, s_d2, s_a1, acc);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float part[RB][16];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) part[rb][i] = 0.f;
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) {
+    const int n = 32 * (wave * CB + cb) + (lane & 31);
+    const float b = p.b2x[n], w = p.w3x[n];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) part[rb][i] = fmaf(w, silu_f(acc[rb][cb][i] + b), part[rb][i]);
+  }
+  // sum over the 32 columns held by the lanes of each half-wave
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float v = part[rb][i];
+      v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+      v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
+      if ((lane & 31) == 0) s_part[wave * R + 32 * rb + acc_row(i, lane)] = v;
+    }
+}
+
+// mlp_m: msg[row][n] = SiLU(acc[row][n] + b2[n])                     (:13-18), gate applied later
+template <int PREC, int RB, int CB>
+__device__ __forceinline__ void phase_m(const EdgeParams& p, const int* s_dst, const int* s_src,
+                                     const float* s_d2, char* s_a1, float* s_msg) {
+  f32x16 acc[RB][CB];
+  run_gemm<PREC, RB, CB>(p, 2 * p.WxP, 2 * p.WxP + p.WmP, p.wdm, p.WmP, p.w2m, s_dst, s_src, s_d2, s_a1, acc);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ld = p.MP + 1;
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) {
+    const int n = 32 * (wave * CB + cb) + (lane & 31);
+    const float b = p.b2m[n];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        s_msg[(32 * rb + acc_row(i, lane)) * ld + n] = silu_f(acc[rb][cb][i] + b);
+  }
+}
+
+template <int PREC, int RB>
+__global__ __launch_bounds__(kThreads, 1) void edge_kernel(const EdgeParams p) {
+  constexpr int R = 32 * RB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* s_dst = reinterpret_cast<int*>(smem);
+  int* s_src = s_dst + R;
+  float* s_d2 = reinterpret_cast<float*>(s_src + R);
+  float* s_diff = s_d2 + R;      // [3][R]
+  float* s_sval = s_diff + 3 * R;
+  float* s_gate = s_sval + R;
+  float* s_part = s_gate + R;    // [4][R]
+  char* s_a1 = smem + edge_smem_small(R);
+  float* s_msg = reinterpret_cast<float*>(s_a1 + 2 * edge_a1_bytes(R));
+
+  const int tid = threadIdx.x;
+  const int tile = blockIdx.x;
+  const int e0 = tile * R;
+  const int nvalid = min(R, p.E - e0);
+
+  if (tid < R) {
+    int d = 0, s = 0;
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (tid < nvalid) {
+      d = p.edge_dst[e0 + tid];
+      s = p.edge_src[e0 + tid];
+      dx = p.x[3 * d] - p.x[3 * s];
+      dy = p.x[3 * d + 1] - p.x[3 * s + 1];
+      dz = p.x[3 * d + 2] - p.x[3 * s + 2];
+    }
+    s_dst[tid] = d;
+    s_src[tid] = s;
+    s_diff[tid] = dx; s_diff[R + tid] = dy; s_diff[2 * R + tid] = dz;
+    // reference: torch.norm(coords_i-coords_j,dim=1)**2 (sqrt then square, :56)
+    const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+    s_d2[tid] = nrm * nrm;
+  }
+  __syncthreads();
+
+  // ---- coordinate branch ----
+  switch (p.cbx) {
+    case 1: phase_x<PREC, RB, 1>(p, s_dst, s_src, s_d2, s_a1, s_part); break;
+    case 2: phase_x<PREC, RB, 2>(p, s_dst, s_src, s_d2, s_a1, s_part); break;
+    case 4: phase_x<PREC, RB, 4>(p, s_dst, s_src, s_d2, s_a1, s_part); break;
+    default: phase_x<PREC, RB, 8>(p, s_dst, s_src, s_d2, s_a1, s_part); break;
+  }
+  __syncthreads();
+  if (tid < R) s_sval[tid] = p.scal[0] + ((s_part[tid] + s_part[R + tid]) + (s_part[2 * R + tid] + s_part[3 * R + tid]));
+
+  // ---- message branch ----
+  switch (p.cbm) {
+    case 1: phase_m<PREC, RB, 1>(p, s_dst, s_src, s_d2, s_a1, s_msg); break;
+    case 2: phase_m<PREC, RB, 2>(p, s_dst, s_src, s_d2, s_a1, s_msg); break;
+    case 4: phase_m<PREC, RB, 4>(p, s_dst, s_src, s_d2, s_a1, s_msg); break;
+    default: phase_m<PREC, RB, 8>(p, s_dst, s_src, s_d2, s_a1, s_msg); break;
+  }
+  __syncthreads();
+
+  // attention gate: sigmoid(wa . m + ba)  (:31-34, :59-60); kThreads/R threads per row
+  {
+    constexpr int TPR = (kThreads / R) >= 4 ? 4 : ((kThreads / R) >= 2 ? 2 : 1);
+    const int row = tid / TPR, sub = tid % TPR;
+    const int ld = p.MP + 1;
+    float s = 0.f;
+    if (row < R)
+      for (int c = sub; c < p.MP; c += TPR) s = fmaf(p.wa[c], s_msg[row * ld + c], s);
+    if (TPR >= 2) s += __shfl_xor(s, 1);
+    if (TPR >= 4) s += __shfl_xor(s, 2);
+    if (row < R && sub == 0) s_gate[row] = sigmoid_f(s + p.scal[1]);
+  }
+  __syncthreads();
+
+  // ---- segment sums over the receiving node (aggr='sum' into edge_index[0], :10-11) ----
+  // A node's edges are contiguous (CSR).  A segment that holds all edges of its node is stored
+  // directly; otherwise it goes to the tile's partial slot (1 = holds the node's first edge,
+  // 0 = continues a node started in an earlier tile) and node_post adds the partials in tile order.
+  auto flush = [&](int n, int rs, int re, float v, float* agg, float* part, int ld, int c) {
+    const bool first = (e0 + rs) == p.row_ptr[n];
+    const bool last = (e0 + re + 1) == p.row_ptr[n + 1];
+    if (first && last) agg[(size_t)n * ld + c] = v;
+    else part[((size_t)tile * 2 + (first ? 1 : 0)) * ld + c] = v;
+  };
+  {
+    const int ld = p.MP + 1;
+    for (int c = tid; c < p.MP; c += kThreads) {
+      float sum = 0.f;
+      int rs = 0;
+      for (int rr = 0; rr < nvalid; ++rr) {
+        sum = fmaf(s_msg[rr * ld + c], s_gate[rr], sum);
+        if (rr == nvalid - 1 || s_dst[rr + 1] != s_dst[rr]) {
+          flush(s_dst[rr], rs, rr, sum, p.agg_m, p.part_m, p.MP, c);
+          sum = 0.f;
+          rs = rr + 1;
+        }
+      }
+    }
+    if (tid < 3) {  // coordinate messages (x_i - x_j) * s_ij; the 1/(G+1) factor is applied in node_post
+      float sum = 0.f;
+      int rs = 0;
+      for (int rr = 0; rr < nvalid; ++rr) {
+        sum = fmaf(s_diff[tid * R + rr], s_sval[rr], sum);
+        if (rr == nvalid - 1 || s_dst[rr + 1] != s_dst[rr]) {
+          flush(s_dst[rr], rs, rr, sum, p.agg_x, p.part_x, 4, tid);
+          sum = 0.f;
+          rs = rr + 1;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// node_post: h' = mlp_h([h | sum_m]) (:69), x' = x + sum_x / (G + 1) (:64, :70)
+// ------------------------------------------------------------------------------------------------
+struct PostParams {
+  int N, H, MP, K1P, WhP, HP, R;
+  const float *h, *x;
+  const int *row_ptr, *node_graph;
+  const float *agg_m, *agg_x, *part_m, *part_x, *gscale;
+  int per_graph;
+  const f32x4 *w1h, *w2h;
+  const float *b1h, *b2h;
+  float *h_out, *x_out;
+};
+constexpr int kPostNodes = 32;
+constexpr int kPostHC = 512;   // hidden columns kept in LDS at a time
+constexpr int kPostMaxOB = 8;  // output column blocks (H <= 256)
+__host__ __device__ inline size_t post_smem_bytes(int K1P, int WhP) {
+  const int hc = WhP < kPostHC ? WhP : kPostHC;
+  size_t hs = (size_t)hc * 33 * 4, red = (size_t)4 * 16 * 64 * 4;
+  return (size_t)K1P * 33 * 4 + (hs > red ? hs : red);
+}
+
+__global__ __launch_bounds__(kThreads, 1) void node_post_kernel(const PostParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* Xs = reinterpret_cast<float*>(smem);  // [K1P][33]
+  float* Hs = Xs + (size_t)p.K1P * 33;         // [HC][33], reused for the cross-wave reduction
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const int n0 = blockIdx.x * kPostNodes;
+
+  // gather [h | sum_m] for 32 nodes
+  for (int i = tid; i < kPostNodes * p.K1P; i += kThreads) {
+    const int node = i / p.K1P, k = i % p.K1P, n = n0 + node;
+    float v = 0.f;
+    if (n < p.N) {
+      if (k < p.H) v = p.h[(size_t)n * p.H + k];
+      else if (k - p.H < p.MP) {
+        const int c = k - p.H, rp0 = p.row_ptr[n], rp1 = p.row_ptr[n + 1];
+        if (rp1 > rp0) {
+          const int t0 = rp0 / p.R, t1 = (rp1 - 1) / p.R;
+          if (t0 == t1) v = p.agg_m[(size_t)n * p.MP + c];
+          else {
+            v = p.part_m[((size_t)t0 * 2 + 1) * p.MP + c];
+            for (int t = t0 + 1; t <= t1; ++t) v += p.part_m[((size_t)t * 2) * p.MP + c];
+          }
+        }
+      }
+    }
+    Xs[k * 33 + node] = v;
+  }
+  // coordinate update
+  if (tid < kPostNodes * 3) {
+    const int node = tid / 3, d = tid % 3, n = n0 + node;
+    if (n < p.N) {
+      const int rp0 = p.row_ptr[n], rp1 = p.row_ptr[n + 1];
+      float v = 0.f;
+      if (rp1 > rp0) {
+        const int t0 = rp0 / p.R, t1 = (rp1 - 1) / p.R;
+        if (t0 == t1) v = p.agg_x[(size_t)n * 4 + d];
+        else {
+          v = p.part_x[((size_t)t0 * 2 + 1) * 4 + d];
+          for (int t = t0 + 1; t <= t1; ++t) v += p.part_x[((size_t)t * 2) * 4 + d];
+        }
+      }
+      const float g = p.gscale[p.per_graph ? p.node_graph[n] : 0];
+      p.x_out[3 * n + d] = p.x[3 * n + d] + v * g;
+    }
+  }
+  __syncthreads();
+
+  const int OB = p.HP / 32;
+  const int KS4a = p.K1P / 8, KS4b = p.WhP / 8;
+  f32x16 oacc[kPostMaxOB];
+#pragma unroll
+  for (int ob = 0; ob < kPostMaxOB; ++ob)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) oacc[ob][i] = 0.f;
+
+  for (int ch0 = 0; ch0 < p.WhP; ch0 += kPostHC) {
+    const int hc = min(kPostHC, p.WhP - ch0);  // multiple of 128
+    const int nbw = hc / 128;                  // column blocks per wave (1..4)
+    // phase A: hidden chunk = SiLU(X . W1h^T + b1h)
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+    for (int ks4 = 0; ks4 < KS4a; ++ks4) {
+      f32x4 b[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < nbw) b[j] = p.w1h[((size_t)(ch0 / 32 + wave * nbw + j) * KS4a + ks4) * 64 + lane];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float a = Xs[(8 * ks4 + 2 * s + hh) * 33 + r];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j < nbw) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[j][s], acc[j], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < nbw) {
+        const int cl = 32 * (wave * nbw + j) + r;  // column inside the chunk
+        const float b = p.b1h[ch0 + cl];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Hs[cl * 33 + acc_row(i, lane)] = silu_f(acc[j][i] + b);
+      }
+    __syncthreads();
+    // phase B: out += hidden chunk . W2h^T ; K split across the 4 waves
+    const int kw = hc / 4;  // hidden columns per wave (multiple of 32)
+    for (int q = 0; q < kw / 8; ++q) {
+      const int kl = wave * kw + 8 * q;  // local hidden index of this group of 4 k-steps
+      float a[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) a[s] = Hs[(kl + 2 * s + hh) * 33 + r];
+#pragma unroll
+      for (int ob = 0; ob < kPostMaxOB; ++ob)
+        if (ob < OB) {
+          const f32x4 b = p.w2h[((size_t)ob * KS4b + (ch0 + kl) / 8) * 64 + lane];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) oacc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], oacc[ob], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+  // cross-wave reduction + store
+  float* red = Hs;  // [4][16][64]
+#pragma unroll
+  for (int ob = 0; ob < kPostMaxOB; ++ob) {
+    if (ob < OB) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) red[(wave * 16 + i) * 64 + lane] = oacc[ob][i];
+      __syncthreads();
+      for (int e = tid; e < 16 * 64; e += kThreads) {
+        const int i = e >> 6, l = e & 63;
+        const float v = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
+        const int node = acc_row(i, l), col = 32 * ob + (l & 31), n = n0 + node;
+        if (n < p.N && col < p.H) p.h_out[(size_t)n * p.H + col] = v + p.b2h[col];
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+int edge_rows_per_tile(int prec) { (void)prec; return 64; }
+
+template <typename T>
+static int dev_alloc(T** p, size_t count) {
+  if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (count == 0) return EGNN_OK;
+  if (hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)) != hipSuccess) {
+    set_error("hipMalloc of %zu bytes failed", count * sizeof(T));
+    *p = nullptr;
+    return EGNN_ENOMEM;
+  }
+  return EGNN_OK;
+}
+
+int reserve(egnn_ctx* c) {
+  if (c->L == 0 || c->N == 0) { set_error("model and graph must be set first"); return EGNN_ESTATE; }
+  const int R = edge_rows_per_tile(0);
+  const size_t tiles = (size_t)(c->E + R - 1) / R;
+  int rc = EGNN_OK;
+  if ((size_t)c->N > c->cap_nodes) {
+    const size_t n = c->N;
+    if ((rc = dev_alloc(&c->table, n * c->TC))) return rc;
+    if ((rc = dev_alloc(&c->agg_m, n * c->MP))) return rc;
+    if ((rc = dev_alloc(&c->agg_x, n * 4))) return rc;
+    if ((rc = dev_alloc(&c->node_d2, n))) return rc;
+    for (int i = 0; i < 2; ++i) {
+      if ((rc = dev_alloc(&c->h_tmp[i], n * c->H))) return rc;
+      if ((rc = dev_alloc(&c->x_tmp[i], n * 3))) return rc;
+    }
+    c->cap_nodes = n;
+  }
+  if (tiles > c->cap_tiles) {
+    if ((rc = dev_alloc(&c->part_m, (tiles + 1) * 2 * c->MP))) return rc;
+    if ((rc = dev_alloc(&c->part_x, (tiles + 1) * 2 * 4))) return rc;
+    c->cap_tiles = tiles;
+  }
+  if ((size_t)c->B > c->cap_graphs) {
+    if ((rc = dev_alloc(&c->gscale, (size_t)c->B + 1))) return rc;
+    c->cap_graphs = c->B;
+  }
+  return EGNN_OK;
+}
+
+static void prof_begin(egnn_ctx* c, hipStream_t st, int kind) {
+  if (!c->prof) return;
+  if (c->ev_used + 2 > c->ev.size()) {
+    for (int i = 0; i < 2; ++i) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return;
+      c->ev.push_back(e);
+    }
+    c->ev_kind.push_back(kind);
+  } else {
+    c->ev_kind[c->ev_used / 2] = kind;
+  }
+  (void)hipEventRecord(c->ev[c->ev_used], st);
+}
+static void prof_end(egnn_ctx* c, hipStream_t st) {
+  if (!c->prof || c->ev_used + 2 > c->ev.size()) return;
+  (void)hipEventRecord(c->ev[c->ev_used + 1], st);
+  c->ev_used += 2;
+}
+
+template <int PREC, int RB>
+static int launch_edge(const EdgeParams& p, int tiles, size_t smem, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel<PREC, RB>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((edge_kernel<PREC, RB>), dim3(tiles), dim3(kThreads), smem, st, p);
+  EGNN_HIP(hipGetLastError());
+  return EGNN_OK;
+}
+
+int launch_layer(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_scope, const float* h,
+                 const float* x, float* h_out, float* x_out) {
+  const LayerPack& lp = c->layers[layer];
+  if (!lp.packed) { set_error("layer %d has no packed parameters", layer); return EGNN_ESTATE; }
+  const int N = c->N, E = c->E, R = edge_rows_per_tile(prec);
+  const int per_graph = norm_scope == EGNN_NORM_GRAPH;
+
+  prof_begin(c, st, 1);
+  {
+    dim3 grid((N + kPreNodes - 1) / kPreNodes, (c->TC + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL(node_pre_kernel, grid, dim3(kThreads), (size_t)kPreNodes * c->H * sizeof(float), st, h, N,
+                       c->H, lp.w1catT, lp.b1cat, c->TC, c->table);
+    hipLaunchKernelGGL(node_d2_kernel, dim3((N + 255) / 256), dim3(256), 0, st, x, c->row_ptr, c->edge_src, N,
+                       c->node_d2);
+    hipLaunchKernelGGL(graph_scale_kernel, dim3(per_graph ? c->B : 1), dim3(kThreads), 0, st, c->node_d2,
+                       c->graph_ptr, N, per_graph, c->gscale);
+  }
+  prof_end(c, st);
+  EGNN_HIP(hipGetLastError());
+
+  if (E > 0) {
+    EdgeParams p;
+    p.N = N; p.E = E;
+    p.edge_dst = c->edge_dst; p.edge_src = c->edge_src; p.row_ptr = c->row_ptr;
+    p.x = x; p.table = c->table;
+    p.TC = c->TC; p.WxP = c->WxP; p.WmP = c->WmP; p.MP = c->MP; p.cbx = c->cbx; p.cbm = c->cbm;
+    p.wdx = lp.wdx; p.wdm = lp.wdm; p.b2x = lp.b2x; p.w3x = lp.w3x; p.b2m = lp.b2m; p.wa = lp.wa;
+    p.scal = lp.scal;
+    p.w2x = prec == EGNN_PREC_BF16 ? lp.w2x_bf16 : (const void*)lp.w2x_f32;
+    p.w2m = prec == EGNN_PREC_BF16 ? lp.w2m_bf16 : (const void*)lp.w2m_f32;
+    p.agg_m = c->agg_m; p.agg_x = c->agg_x; p.part_m = c->part_m; p.part_x = c->part_x;
+    const int tiles = (E + R - 1) / R;
+    const size_t smem = edge_smem_bytes(R, c->MP);
+    prof_begin(c, st, 0);
+    int rc = prec == EGNN_PREC_BF16 ? launch_edge<EGNN_PREC_BF16, 2>(p, tiles, smem, st)
+                                    : launch_edge<EGNN_PREC_F32, 2>(p, tiles, smem, st);
+    prof_end(c, st);
+    if (rc) return rc;
+  }
+
+  {
+    PostParams q;
+    q.N = N; q.H = c->H; q.MP = c->MP; q.K1P = c->K1P; q.WhP = c->WhP; q.HP = c->HP; q.R = R;
+    q.h = h; q.x = x; q.row_ptr = c->row_ptr; q.node_graph = c->node_graph;
+    q.agg_m = c->agg_m; q.agg_x = c->agg_x; q.part_m = c->part_m; q.part_x = c->part_x;
+    q.gscale = c->gscale; q.per_graph = per_graph;
+    q.w1h = reinterpret_cast<const f32x4*>(lp.w1h_f32); q.w2h = reinterpret_cast<const f32x4*>(lp.w2h_f32);
+    q.b1h = lp.b1h; q.b2h = lp.b2h; q.h_out = h_out; q.x_out = x_out;
+    static bool attr_done = false;
+    if (!attr_done) {
+      EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&node_post_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_done = true;
+    }
+    prof_begin(c, st, 1);
+    hipLaunchKernelGGL(node_post_kernel, dim3((N + kPostNodes - 1) / kPostNodes), dim3(kThreads),
+                       post_smem_bytes(c->K1P, c->WhP), st, q);
+    prof_end(c, st);
+    EGNN_HIP(hipGetLastError());
+  }
+  return EGNN_OK;
+}
+
+}  // namespace egnn
+
+using namespace egnn;
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* egnn_last_error(void) { return g_err; }
+int egnn_version(void) { return 1; }
+
+int egnn_create(egnn_ctx** out, int device) {
+  if (!out) return EGNN_EINVAL;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) {
+    set_error("no HIP device %d (count %d)", device, count);
+    return EGNN_EHIP;
+  }
+  EGNN_HIP(hipSetDevice(device));
+  egnn_ctx* c = new egnn_ctx();
+  c->device = device;
+  *out = c;
+  return EGNN_OK;
+}
+
+static void free_layer(LayerPack& lp) {
+  void* ptrs[] = {lp.w1catT, lp.b1cat, lp.wdx, lp.wdm, lp.w2x_f32, lp.w2x_bf16, lp.b2x, lp.w3x, lp.w2m_f32,
+                  lp.w2m_bf16, lp.b2m, lp.wa, lp.scal, lp.w1h_f32, lp.b1h, lp.w2h_f32, lp.b2h};
+  for (void* q : ptrs)
+    if (q) (void)hipFree(q);
+  lp = LayerPack();
+}
+
+void sampler_free(egnn_ctx* c);
+
+int egnn_destroy(egnn_ctx* c) {
+  if (!c) return EGNN_EINVAL;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  for (auto& lp : c->layers) free_layer(lp);
+  void* ptrs[] = {c->table, c->agg_m, c->agg_x, c->part_m, c->part_x, c->node_d2, c->gscale,
+                  c->h_tmp[0], c->h_tmp[1], c->x_tmp[0], c->x_tmp[1]};
+  for (void* q : ptrs)
+    if (q) (void)hipFree(q);
+  sampler_free(c);
+  for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+  delete c;
+  return EGNN_OK;
+}
+
+static int pow2_ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+int egnn_set_model(egnn_ctx* c, int L, int H, int M, int Wm, int Wx, int Wh) {
+  if (!c || L < 1 || H < 1 || M < 1 || Wm < 1 || Wx < 1 || Wh < 1) { set_error("bad model dims"); return EGNN_EINVAL; }
+  if (Wx > 128 * kMaxCB || Wm > 128 * kMaxCB || M > 128 * kMaxCB || H > 32 * kPostMaxOB) {
+    set_error("unsupported width: hidden/message widths must be <= %d and H <= %d", 128 * kMaxCB, 32 * kPostMaxOB);
+    return EGNN_EINVAL;
+  }
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  for (auto& lp : c->layers) free_layer(lp);
+  c->layers.assign(L, LayerPack());
+  c->L = L; c->H = H; c->M = M; c->Wm = Wm; c->Wx = Wx; c->Wh = Wh;
+  c->cbx = pow2_ceil((Wx + 127) / 128);
+  c->cbm = pow2_ceil((M + 127) / 128);
+  c->WxP = 128 * c->cbx;          // K and N of mlp_x.2
+  c->WmP = round_up(Wm, 64);      // K of mlp_m.2
+  c->MP = 128 * c->cbm;           // N of mlp_m.2
+  c->WhP = round_up(Wh, 128);
+  c->HP = round_up(H, 32);
+  c->K1P = round_up(H + c->MP, 8);
+  c->TC = 2 * c->WxP + 2 * c->WmP;
+  c->cap_nodes = c->cap_tiles = c->cap_graphs = 0;  // MP / TC may have changed
+  if (post_smem_bytes(c->K1P, c->WhP) > 160 * 1024 || edge_smem_bytes(64, c->MP) > 160 * 1024) {
+    set_error("model does not fit the 160 KiB LDS budget");
+    return EGNN_EINVAL;
+  }
+  return EGNN_OK;
+}
+
+int egnn_pack_layer(egnn_ctx* c, void* stream, int l, const float* m0_w, const float* m0_b, const float* m2_w,
+                    const float* m2_b, const float* x0_w, const float* x0_b, const float* x2_w,
+                    const float* x2_b, const float* x4_w, const float* x4_b, const float* h0_w,
+                    const float* h0_b, const float* h2_w, const float* h2_b, const float* a_w,
+                    const float* a_b) {
+  if (!c || c->L == 0) { set_error("egnn_set_model first"); return EGNN_ESTATE; }
+  if (l < 0 || l >= c->L) { set_error("layer %d out of range", l); return EGNN_EINVAL; }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  EGNN_HIP(hipSetDevice(c->device));
+  LayerPack& lp = c->layers[l];
+  const int H = c->H, M = c->M, Wm = c->Wm, Wx = c->Wx, Wh = c->Wh;
+  const int WxP = c->WxP, WmP = c->WmP, MP = c->MP, WhP = c->WhP, HP = c->HP, K1P = c->K1P, TC = c->TC;
+  int rc;
+  if (!lp.w1catT) {
+    if ((rc = dev_alloc(&lp.w1catT, (size_t)H * TC))) return rc;
+    if ((rc = dev_alloc(&lp.b1cat, (size_t)TC))) return rc;
+    if ((rc = dev_alloc(&lp.wdx, (size_t)WxP))) return rc;
+    if ((rc = dev_alloc(&lp.wdm, (size_t)WmP))) return rc;
+    if ((rc = dev_alloc(&lp.w2x_f32, (size_t)WxP * WxP))) return rc;
+    __bf16* tmp = nullptr;
+    if ((rc = dev_alloc(&tmp, (size_t)WxP * WxP))) return rc;
+    lp.w2x_bf16 = tmp; tmp = nullptr;
+    if ((rc = dev_alloc(&lp.b2x, (size_t)WxP))) return rc;
+    if ((rc = dev_alloc(&lp.w3x, (size_t)WxP))) return rc;
+    if ((rc = dev_alloc(&lp.w2m_f32, (size_t)MP * WmP))) return rc;
+    if ((rc = dev_alloc(&tmp, (size_t)MP * WmP))) return rc;
+    lp.w2m_bf16 = tmp;
+    if ((rc = dev_alloc(&lp.b2m, (size_t)MP))) return rc;
+    if ((rc = dev_alloc(&lp.wa, (size_t)MP))) return rc;
+    if ((rc = dev_alloc(&lp.scal, (size_t)4))) return rc;
+    if ((rc = dev_alloc(&lp.w1h_f32, (size_t)WhP * K1P))) return rc;
+    if ((rc = dev_alloc(&lp.b1h, (size_t)WhP))) return rc;
+    if ((rc = dev_alloc(&lp.w2h_f32, (size_t)HP * WhP))) return rc;
+    if ((rc = dev_alloc(&lp.b2h, (size_t)HP))) return rc;
+  }
+  const dim3 g(256), b(256);
+  hipLaunchKernelGGL(pack_first, g, b, 0, st, x0_w, x0_b, m0_w, m0_b, H, Wx, Wm, WxP, WmP, lp.w1catT, lp.b1cat);
+  hipLaunchKernelGGL(pad_copy, dim3(8), b, 0, st, x0_w + 2 * H, Wx, 2 * H + 1, lp.wdx, WxP);
+  hipLaunchKernelGGL(pad_copy, dim3(8), b, 0, st, m0_w + 2 * H, Wm, 2 * H + 1, lp.wdm, WmP);
+  hipLaunchKernelGGL(pack_frags_f32, g, b, 0, st, x2_w, Wx, Wx, Wx, WxP, WxP, lp.w2x_f32);
+  hipLaunchKernelGGL(pack_frags_bf16, g, b, 0, st, x2_w, Wx, Wx, Wx, WxP, WxP, reinterpret_cast<__bf16*>(lp.w2x_bf16));
+  hipLaunchKernelGGL(pad_copy, dim3(8), b, 0, st, x2_b, Wx, 1, lp.b2x, WxP);
+  hipLaunchKernelGGL(pad_copy, dim3(8), b, 0, st, x4_w, Wx, 1, lp.w3x, WxP);
+  hipLaunchKernelGGL(pack_frags_f32, g, b, 0, st, m2_w, M, Wm, Wm, MP, WmP, lp.w2m_f32);
+  hipLaunchKernelGGL(pack_frags_bf16, g, b, 0, st, m2_w, M, Wm, Wm, MP, WmP, reinterpret_cast<__bf16*>(lp.w2m_bf16));
+  hipLaunchKernelGGL(pad_copy, dim3(8), b, 0, st, m2_b, M, 1, lp.b2m, MP);
+  hipLaunchKernelGGL(pad_copy, dim3(8), b, 0, st, a_w, M, 1, lp.wa, MP);
+  hipLaunchKernelGGL(pad_copy, dim3(1), dim3(64), 0, st, x4_b, 1, 1, lp.scal, 1);
+  hipLaunchKernelGGL(pad_copy, dim3(1), dim3(64), 0, st, a_b, 1, 1, lp.scal + 1, 1);
+  // mlp_h.0 sees [h | sum_m]; the kernel's K index is [h (H) | sum_m (MP, zero-padded beyond M)]
+  hipLaunchKernelGGL(pack_frags_f32, g, b, 0, st, h0_w, Wh, H + M, H + M, WhP, K1P, lp.w1h_f32);
+  hipLaunchKernelGGL(pad_copy, dim3(8), b, 0, st, h0_b, Wh, 1, lp.b1h, WhP);
+  hipLaunchKernelGGL(pack_frags_f32, g, b, 0, st, h2_w, H, Wh, Wh, HP, WhP, lp.w2h_f32);
+  hipLaunchKernelGGL(pad_copy, dim3(8), b, 0, st, h2_b, H, 1, lp.b2h, HP);
+  EGNN_HIP(hipGetLastError());
+  lp.packed = true;
+  return EGNN_OK;
+}
+
+int egnn_set_graph(egnn_ctx* c, int N, int E, int B, const int32_t* edge_dst, const int32_t* edge_src,
+                   const int32_t* row_ptr, const int32_t* graph_ptr, const int32_t* node_graph) {
+  if (!c || N < 1 || E < 0 || B < 1 || !row_ptr || !graph_ptr || !node_graph || (E > 0 && (!edge_dst || !edge_src))) {
+    set_error("bad graph arguments");
+    return EGNN_EINVAL;
+  }
+  if (c->L == 0) { set_error("egnn_set_model first"); return EGNN_ESTATE; }
+  EGNN_HIP(hipSetDevice(c->device));
+  c->N = N; c->E = E; c->B = B;
+  c->edge_dst = edge_dst; c->edge_src = edge_src; c->row_ptr = row_ptr; c->graph_ptr = graph_ptr;
+  c->node_graph = node_graph;
+  c->smp.ready = false;
+  return reserve(c);
+}
+
+static int check_ready(egnn_ctx* c, int prec, int norm_scope) {
+  if (!c || c->L == 0 || c->N == 0) { set_error("model/graph not set"); return EGNN_ESTATE; }
+  if (prec != EGNN_PREC_F32 && prec != EGNN_PREC_BF16) { set_error("bad precision %d", prec); return EGNN_EINVAL; }
+  if (norm_scope != EGNN_NORM_CALL && norm_scope != EGNN_NORM_GRAPH) { set_error("bad norm scope"); return EGNN_EINVAL; }
+  return EGNN_OK;
+}
+
+int egcl_forward(egnn_ctx* c, void* stream, int layer, int prec, int norm_scope, const float* h, const float* x,
+                 float* h_out, float* x_out) {
+  int rc = check_ready(c, prec, norm_scope);
+  if (rc) return rc;
+  if (layer < 0 || layer >= c->L || !h || !x || !h_out || !x_out || h == h_out || x == x_out) {
+    set_error("bad egcl_forward arguments");
+    return EGNN_EINVAL;
+  }
+  return launch_layer(c, reinterpret_cast<hipStream_t>(stream), layer, prec, norm_scope, h, x, h_out, x_out);
+}
+
+int egnn_forward(egnn_ctx* c, void* stream, int prec, int norm_scope, const float* h, const float* x, float* h_out,
+                 float* x_out) {
+  int rc = check_ready(c, prec, norm_scope);
+  if (rc) return rc;
+  if (!h || !x || !h_out || !x_out || h == h_out || x == x_out) { set_error("bad egnn_forward arguments"); return EGNN_EINVAL; }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const float *hc = h, *xc = x;
+  for (int l = 0; l < c->L; ++l) {
+    float* ho = (l == c->L - 1) ? h_out : c->h_tmp[l & 1];
+    float* xo = (l == c->L - 1) ? x_out : c->x_tmp[l & 1];
+    if ((rc = launch_layer(c, st, l, prec, norm_scope, hc, xc, ho, xo))) return rc;
+    hc = ho; xc = xo;
+  }
+  return EGNN_OK;
+}
+
+int egnn_profile_enable(egnn_ctx* c, int enable) {
+  if (!c) return EGNN_EINVAL;
+  c->prof = enable != 0;
+  c->ev_used = 0;
+  return EGNN_OK;
+}
+
+int egnn_profile_read(egnn_ctx* c, float* edge_ms_avg, int* edge_launches, float* node_ms_avg) {
+  if (!c) return EGNN_EINVAL;
+  EGNN_HIP(hipDeviceSynchronize());
+  double se = 0, sn = 0;
+  int ne = 0, nn = 0;
+  for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) != hipSuccess) continue;
+    if (c->ev_kind[i / 2] == 0) { se += ms; ++ne; } else { sn += ms; ++nn; }
+  }
+  if (edge_ms_avg) *edge_ms_avg = ne ? (float)(se / ne) : 0.f;
+  if (edge_launches) *edge_launches = ne;
+  if (node_ms_avg) *node_ms_avg = nn ? (float)(sn / nn) : 0.f;
+  c->ev_used = 0;
+  return EGNN_OK;
+}
+
+}  // extern "C"

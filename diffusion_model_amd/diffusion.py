@@ -1,0 +1,198 @@
+"""Diffusion process with the reference's interface (diffusion_x_h.py:16-106; x-only variant of
+E3diffusion_new.py:16-115).  The schedule is evaluated by the library's host routine
+(schedule_table_build) and the per-step arithmetic runs in HIP kernels; Gaussian noise is drawn with
+torch's generator on the tensor's device, as the reference does (bit-parity of samples
+across devices is impossible, only eps-parity and statistics)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .snr import GammaNetwork
+
+
+def _graph_ptr_from_batch(batch_index: torch.Tensor):
+    b = batch_index.long()
+    if b.numel() > 1 and bool((b[1:] < b[:-1]).any()):
+        raise ValueError("batch_index must be sorted (PyG collate order)")
+    nb = int(b.max().item()) + 1
+    cnt = torch.bincount(b, minlength=nb)
+    ptr = torch.zeros(nb + 1, dtype=torch.int32, device=b.device)
+    ptr[1:] = torch.cumsum(cnt, 0).to(torch.int32)
+    return ptr, nb
+
+
+def remove_mean(x: torch.Tensor, batch_index: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """remove_mean(x, batch_index=None) (diffusion_x_h.py:5-14).  Like the reference, the
+    batch_index form updates ``x`` in place and returns it; the global form returns a new tensor."""
+    if not x.is_cuda:
+        raise RuntimeError("remove_mean needs a CUDA(ROCm) tensor; there is no CPU fallback")
+    xc = x.detach().to(torch.float32).contiguous()
+    out = torch.empty_like(xc)
+    n, d = xc.shape
+    if batch_index is None:
+        _lib.check(_lib.lib().egnn_remove_mean(_lib.stream_ptr(), n, d, None, 0, _lib.ptr(xc), _lib.ptr(out)))
+        return out
+    ptr, nb = _graph_ptr_from_batch(batch_index.to(x.device))
+    _lib.check(_lib.lib().egnn_remove_mean(_lib.stream_ptr(), n, d, _lib.ptr(ptr), nb, _lib.ptr(xc), _lib.ptr(out)))
+    x.copy_(out)
+    return x
+
+
+def build_schedule(T: int, s: float, power: float):
+    """(alpha [T+1], sigma [T+1], step table [T+1,4]) as CPU fp32 tensors (polynomial_schedule +
+    clip_noise_schedule, diffusion_x_h.py:92-106)."""
+    a = np.empty(T + 1, dtype=np.float32)
+    sg = np.empty(T + 1, dtype=np.float32)
+    tab = np.empty((T + 1) * 4, dtype=np.float32)
+    fp = C.POINTER(C.c_float)
+    _lib.check(_lib.lib().schedule_table_build(int(T), float(s), float(power), a.ctypes.data_as(fp),
+                                               sg.ctypes.data_as(fp), tab.ctypes.data_as(fp)))
+    return torch.from_numpy(a), torch.from_numpy(sg), torch.from_numpy(tab).view(T + 1, 4)
+
+
+def table_from_alpha(alpha: torch.Tensor, sigma: torch.Tensor) -> torch.Tensor:
+    a = alpha.detach().cpu().float().contiguous().numpy()
+    sg = sigma.detach().cpu().float().contiguous().numpy()
+    T = a.shape[0] - 1
+    tab = np.empty((T + 1) * 4, dtype=np.float32)
+    fp = C.POINTER(C.c_float)
+    _lib.check(_lib.lib().schedule_table_from_alpha(T, a.ctypes.data_as(fp), sg.ctypes.data_as(fp), tab.ctypes.data_as(fp)))
+    return torch.from_numpy(tab).view(T + 1, 4)
+
+
+class E3DiffusionProcess(nn.Module):
+    """E3DiffusionProcess(s, power, num_diffusion_timestep, noise_schedule='predefined')
+    (diffusion_x_h.py:16-30)."""
+
+    def __init__(self, s, power, num_diffusion_timestep: int, noise_schedule: str = "predefined"):
+        super().__init__()
+        self.noise_schedule = noise_schedule
+        self.num_diffusion_timestep = num_diffusion_timestep
+        if noise_schedule == "predefined":
+            self.noise_precision, self.power = s, power
+            self.t = torch.linspace(0, num_diffusion_timestep, num_diffusion_timestep + 1)
+            self.alpha_schedule, self.sigma_schedule, self._table = build_schedule(num_diffusion_timestep, s, power)
+        elif noise_schedule == "learned":
+            self.gamma = GammaNetwork()
+            self.t = torch.linspace(0, 1, num_diffusion_timestep + 1).view(num_diffusion_timestep + 1, 1)
+            self._table, self._gamma_sig = None, None
+        else:
+            raise ValueError(noise_schedule)
+        self._table_dev = {}
+
+    # -- schedule ------------------------------------------------------------------------------------
+    def gamma_schedule(self):
+        return self.gamma(self.t.to(self.gamma.gamma_0.device))
+
+    def _learned_tables(self):
+        """alpha = sqrt(sigmoid(-gamma)), sigma = sqrt(sigmoid(gamma)) over the whole grid (:40,:46),
+        tabulated once per parameter version instead of once per call."""
+        sig = tuple((p.data_ptr(), p._version) for p in self.gamma.parameters())
+        if sig != self._gamma_sig:
+            with torch.no_grad():
+                g = self.gamma_schedule().reshape(-1).float().cpu()
+            self.alpha_schedule = torch.sqrt(torch.sigmoid(-g))
+            self.sigma_schedule = torch.sqrt(torch.sigmoid(g))
+            self._table = table_from_alpha(self.alpha_schedule, self.sigma_schedule)
+            self._gamma_sig, self._table_dev = sig, {}
+
+    def alpha(self, t: int):
+        if self.noise_schedule == "learned":
+            self._learned_tables()
+        return self.alpha_schedule[t]
+
+    def sigma(self, t: int):
+        if self.noise_schedule == "learned":
+            self._learned_tables()
+        return self.sigma_schedule[t]
+
+    def step_table(self, device=None) -> torch.Tensor:
+        """[T+1, 4] per-step constants {1/alpha_ts, sigma2_ts/(alpha_ts sigma_t), std, t/T}."""
+        if self.noise_schedule == "learned":
+            self._learned_tables()
+        if device is None:
+            return self._table
+        key = str(device)
+        if key not in self._table_dev:
+            self._table_dev[key] = self._table.to(device).contiguous()
+        return self._table_dev[key]
+
+    # -- forward / reverse steps ---------------------------------------------------------------------
+    @staticmethod
+    def _prep(z):
+        if not z.is_cuda:
+            raise RuntimeError("E3DiffusionProcess steps need CUDA(ROCm) tensors; there is no CPU fallback")
+        return z.detach().to(torch.float32).contiguous()
+
+    def diffuse_zero_to_t(self, z: torch.Tensor, t: int, mode="pos"):
+        """z_t = alpha_t z + sigma_t eps, eps ~ N(0,I) mean-removed iff mode == 'pos' (:51-59)."""
+        zc = self._prep(z)
+        noise = torch.zeros_like(zc).normal_(mean=0, std=1)
+        if mode == "pos":
+            noise = remove_mean(noise)
+        out = torch.empty_like(zc)
+        n, d = zc.shape
+        _lib.check(_lib.lib().ddpm_reverse_step(_lib.stream_ptr(), n, d, 0, None, 0, float(self.alpha(t)), 0.0,
+                                                float(self.sigma(t)), _lib.ptr(zc), d, _lib.ptr(zc), _lib.ptr(noise),
+                                                _lib.ptr(out), d))
+        return out, noise
+
+    def calculate_mu(self, z: torch.Tensor, epsilon: torch.Tensor, t: int):
+        """mu = z/alpha_ts - sigma2_ts eps/(alpha_ts sigma_t) (:61-73)."""
+        zc, ec = self._prep(z), self._prep(epsilon)
+        c = self.step_table()[t]
+        out = torch.empty_like(zc)
+        n, d = zc.shape
+        _lib.check(_lib.lib().ddpm_reverse_step(_lib.stream_ptr(), n, d, 0, None, 0, float(c[0]), float(c[1]), 0.0,
+                                                _lib.ptr(zc), d, _lib.ptr(ec), _lib.ptr(ec), _lib.ptr(out), d))
+        return out
+
+    def reverse_diffuse_one_step(self, z, epsilon: torch.Tensor, t: int, mode="pos", noise: Optional[torch.Tensor] = None):
+        """z_{t-1} = mu + std * noise (:75-90); ``noise`` (extension) overrides the RNG draw."""
+        zc, ec = self._prep(z), self._prep(epsilon)
+        if noise is None:
+            noise = torch.zeros_like(zc).normal_(mean=0, std=1)
+        nz = self._prep(noise)
+        c = self.step_table()[t]
+        out = torch.empty_like(zc)
+        n, d = zc.shape
+        _lib.check(_lib.lib().ddpm_reverse_step(_lib.stream_ptr(), n, d, 1 if mode == "pos" else 0, None, 0,
+                                                float(c[0]), float(c[1]), float(c[2]), _lib.ptr(zc), d, _lib.ptr(ec),
+                                                _lib.ptr(nz), _lib.ptr(out), d))
+        return out
+
+    # -- reference helpers kept for API parity -------------------------------------------------------
+    def clip_noise_schedule(self, alphas2, clip_value=0.001):
+        alphas2 = torch.cat([torch.ones(1), alphas2], dim=0)
+        step = torch.clamp(alphas2[1:] / alphas2[:-1], min=clip_value, max=1.0)
+        return torch.cumprod(step, dim=0)
+
+    def polynomial_schedule(self, timesteps: int, s=1e-4, power=3.0):
+        return build_schedule(timesteps, s, power)[0]
+
+
+class E3DiffusionProcessXOnly(E3DiffusionProcess):
+    """Interface of the x-only process of E3diffusion_new.py:16-98 (used by the reference's train.py /
+    test.py): diffuse_zero_to_t(pos, t), calculate_mu(pos, eps, t) in the x_hat form (algebraically the
+    same mu as diffusion_x_h), reverse_diffuse_one_step(mu, t)."""
+
+    def diffuse_zero_to_t(self, pos, t):  # noqa: D102
+        return super().diffuse_zero_to_t(pos, t, mode="pos")
+
+    def reverse_diffuse_one_step(self, mu, t, noise: Optional[torch.Tensor] = None):  # noqa: D102
+        mc = self._prep(mu)
+        if noise is None:
+            noise = torch.zeros_like(mc).normal_(mean=0, std=1)
+        nz = self._prep(noise)
+        out = torch.empty_like(mc)
+        n, d = mc.shape
+        _lib.check(_lib.lib().ddpm_reverse_step(_lib.stream_ptr(), n, d, 1, None, 0, 1.0, 0.0,
+                                                float(self.step_table()[t][2]), _lib.ptr(mc), d, _lib.ptr(mc),
+                                                _lib.ptr(nz), _lib.ptr(out), d))
+        return out

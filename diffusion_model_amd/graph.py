@@ -1,0 +1,82 @@
+"""Graph topology handed to the kernels: edges sorted by the receiving node (CSR), graph ranges.
+
+Counterpart of what torch_geometric's propagate/collate provide to the reference
+(EquivariantGraphNeuralNetwork.py:10-11,68,70; parts/train_per_iretation.py:308-313): edge_index
+row 0 is the node that receives the message (flow='target_to_source'), row 1 its neighbour.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+
+
+def fully_connected_edge_index(num_atoms_per_graph, device=None) -> torch.Tensor:
+    """All ordered pairs i != j inside each graph (i-major), int64 [2, E]; same edge set and order
+    as parts/train_per_iretation.py:308-313 / split_to_train_and_test.py:88-92 with PyG's node
+    offsets for batches."""
+    if isinstance(num_atoms_per_graph, int):
+        num_atoms_per_graph = [num_atoms_per_graph]
+    sizes = torch.as_tensor(list(num_atoms_per_graph), dtype=torch.long)
+    if len(set(sizes.tolist())) == 1:
+        n, b = int(sizes[0]), len(sizes)
+        i = torch.arange(n, device=device).repeat_interleave(n)
+        j = torch.arange(n, device=device).repeat(n)
+        keep = i != j
+        i, j = i[keep], j[keep]
+        off = (torch.arange(b, device=device) * n).repeat_interleave(i.numel())
+        return torch.stack((i.repeat(b) + off, j.repeat(b) + off))
+    rows, cols, off = [], [], 0
+    for n in sizes.tolist():
+        i = torch.arange(n, device=device).repeat_interleave(n)
+        j = torch.arange(n, device=device).repeat(n)
+        keep = i != j
+        rows.append(i[keep] + off)
+        cols.append(j[keep] + off)
+        off += n
+    return torch.stack((torch.cat(rows), torch.cat(cols)))
+
+
+class GraphPlan:
+    """Device-resident CSR view of (edge_index, batch) in the layout libegnn_amd expects."""
+
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, batch: Optional[torch.Tensor] = None,
+                 sizes: Optional[Sequence[int]] = None):
+        if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+            raise ValueError("edge_index must be [2, E]")
+        dev = edge_index.device
+        self.N, self.E = int(num_nodes), int(edge_index.shape[1])
+        row, col = edge_index[0].long(), edge_index[1].long()
+        if self.E > 0:
+            if int(row.min()) < 0 or int(row.max()) >= self.N or int(col.min()) < 0 or int(col.max()) >= self.N:
+                raise ValueError("edge_index refers to nodes outside [0, N)")
+            if bool((row[1:] < row[:-1]).any()):
+                order = torch.argsort(row, stable=True)   # keep the caller's order inside a node
+                row, col = row[order], col[order]
+        self.edge_dst = row.to(torch.int32).contiguous()
+        self.edge_src = col.to(torch.int32).contiguous()
+        deg = torch.bincount(row, minlength=self.N) if self.E > 0 else torch.zeros(self.N, dtype=torch.long, device=dev)
+        self.row_ptr = torch.zeros(self.N + 1, dtype=torch.int32, device=dev)
+        self.row_ptr[1:] = torch.cumsum(deg, 0).to(torch.int32)
+        if sizes is not None:
+            sz = torch.as_tensor(list(sizes), dtype=torch.long, device=dev)
+            if int(sz.sum()) != self.N:
+                raise ValueError("graph sizes do not add up to N")
+            batch = torch.repeat_interleave(torch.arange(len(sizes), device=dev), sz)
+        if batch is None:
+            batch = torch.zeros(self.N, dtype=torch.long, device=dev)
+        batch = batch.to(dev).long()
+        if batch.numel() != self.N:
+            raise ValueError("batch must have one entry per node")
+        if self.N > 1 and bool((batch[1:] < batch[:-1]).any()):
+            raise ValueError("graphs must be contiguous in the node order (PyG collate order)")
+        self.B = int(batch.max().item()) + 1
+        cnt = torch.bincount(batch, minlength=self.B)
+        if bool((cnt == 0).any()):
+            raise ValueError("batch ids must be consecutive")
+        self.graph_ptr = torch.zeros(self.B + 1, dtype=torch.int32, device=dev)
+        self.graph_ptr[1:] = torch.cumsum(cnt, 0).to(torch.int32)
+        self.node_graph = batch.to(torch.int32).contiguous()
+        self.batch = batch
+        if self.E > 0 and bool((batch[row] != batch[col]).any()):
+            raise ValueError("an edge connects two different graphs")

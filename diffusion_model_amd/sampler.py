@@ -1,0 +1,190 @@
+"""Reverse-diffusion sampling: the reference's generate() (parts/train_per_iretation.py:264-444) on a
+device-resident, hipGraph-replayed loop.
+
+The reference samples one graph at a time with >= 3 host syncs per step.  Here any number of graphs is
+sampled in one batched state (norm_scope='graph' reproduces the reference's per-call coordinate
+normaliser for every graph of the batch), the step index and the non-finite flags stay on the device,
+and one reverse step (L layers x 3 kernels + 1 fused update kernel) is replayed from a hipGraph."""
+from __future__ import annotations
+
+import ctypes as C
+from types import SimpleNamespace
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from .graph import GraphPlan, fully_connected_edge_index
+
+
+class DeviceSampler:
+    """Batched device-resident sampler for ``sizes`` fully connected graphs.
+
+    cond: [N, H - A - 1] constant conditioning columns ([compressed spectrum | exO]) or None.
+    """
+
+    def __init__(self, egnn, diffusion_process, sizes: Sequence[int], cond: Optional[torch.Tensor],
+                 atom_type_size: int = 2, onehot_scaling_factor: float = 1.0, seed: int = 0,
+                 precision: Optional[str] = None, norm_scope: str = "graph", device=None,
+                 edge_index: Optional[torch.Tensor] = None):
+        self.device = torch.device(device if device is not None else "cuda")
+        if self.device.type != "cuda":
+            raise RuntimeError("DeviceSampler needs an AMD GPU ('cuda' device); there is no CPU fallback")
+        self.egnn = egnn
+        self.diffusion = diffusion_process
+        self.sizes = list(sizes)
+        self.N = sum(self.sizes)
+        self.A = atom_type_size
+        self.T = diffusion_process.num_diffusion_timestep
+        self.precision = _lib.PRECISIONS[precision or egnn.precision]
+        self.norm_scope = _lib.NORM_SCOPES[norm_scope]
+        H = egnn.egcl_list[0].dims["H"]
+        ncond = H - self.A - 1
+        if ncond < 0:
+            raise ValueError("h width smaller than atom types + time column")
+        if ncond > 0:
+            if cond is None or tuple(cond.shape) != (self.N, ncond):
+                raise ValueError(f"cond must be [{self.N}, {ncond}]")
+            cond = cond.detach().to(self.device, torch.float32).contiguous()
+        ei = edge_index if edge_index is not None else fully_connected_edge_index(self.sizes, device=self.device)
+        self.plan = GraphPlan(ei.to(self.device), self.N, sizes=self.sizes)
+        self.ctx = egnn.context_for(self.plan)
+        self.table = diffusion_process.step_table(self.device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._cond = cond
+        torch.cuda.current_stream().synchronize()
+        _lib.check(_lib.lib().egnn_sampler_prepare(self.ctx.handle, self.T, self.A, float(onehot_scaling_factor),
+                                                   _lib.ptr(self.table), _lib.ptr(cond), C.c_uint64(seed)))
+
+    def _sp(self):
+        return C.c_void_p(self.stream.cuda_stream)
+
+    def init(self, pos_init: Optional[torch.Tensor] = None, x_init: Optional[torch.Tensor] = None):
+        """x_T ~ N(0,I) mean-removed per graph, h_T ~ N(0,I) (:301-305), or explicit initial state."""
+        self.egnn.context_for(self.plan)  # re-pack if the weights changed
+        self.stream.wait_stream(torch.cuda.current_stream())
+        keep = [t.detach().to(self.device, torch.float32).contiguous() if t is not None else None for t in (pos_init, x_init)]
+        _lib.check(_lib.lib().egnn_sampler_init(self.ctx.handle, self._sp(), _lib.ptr(keep[0]), _lib.ptr(keep[1])))
+        self.stream.synchronize()
+
+    def run(self, nsteps: Optional[int] = None, use_graph: bool = True, noise_pos: Optional[torch.Tensor] = None,
+            noise_h: Optional[torch.Tensor] = None, sync: bool = True):
+        """Advance ``nsteps`` reverse steps (default: all remaining)."""
+        t = self.t
+        nsteps = t if nsteps is None else nsteps
+        if noise_pos is not None or noise_h is not None:
+            use_graph = False
+        keep = [x.detach().to(self.device, torch.float32).contiguous() if x is not None else None for x in (noise_pos, noise_h)]
+        self.stream.wait_stream(torch.cuda.current_stream())
+        _lib.check(_lib.lib().egnn_sampler_run(self.ctx.handle, self._sp(), self.precision, self.norm_scope, int(nsteps),
+                                               1 if use_graph else 0, _lib.ptr(keep[0]), _lib.ptr(keep[1])))
+        if sync:
+            self.stream.synchronize()
+        else:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        self._keep = keep
+
+    @property
+    def t(self) -> int:
+        th = C.c_int(0)
+        _lib.check(_lib.lib().egnn_sampler_state(self.ctx.handle, self._sp(), None, None, None, C.byref(th)))
+        return th.value
+
+    def state(self):
+        """(pos [N,3], x_types [N,A], bad flags [B]) of the current step."""
+        pos = torch.empty(self.N, 3, device=self.device)
+        xt = torch.empty(self.N, self.A, device=self.device)
+        bad = torch.empty(len(self.sizes), dtype=torch.int32, device=self.device)
+        th = C.c_int(0)
+        _lib.check(_lib.lib().egnn_sampler_state(self.ctx.handle, self._sp(), _lib.ptr(pos), _lib.ptr(xt), _lib.ptr(bad), C.byref(th)))
+        self.stream.synchronize()
+        return pos, xt, bad
+
+    def final(self, noise_pos: Optional[torch.Tensor] = None, noise_h: Optional[torch.Tensor] = None):
+        """t = 0 decode (:391-428) -> (pos_0 [N,3], h_0 continuous [N,A], one-hot int64 [N,A], bad [B])."""
+        pos = torch.empty(self.N, 3, device=self.device)
+        hc = torch.empty(self.N, self.A, device=self.device)
+        oh = torch.empty(self.N, self.A, dtype=torch.int32, device=self.device)
+        keep = [x.detach().to(self.device, torch.float32).contiguous() if x is not None else None for x in (noise_pos, noise_h)]
+        _lib.check(_lib.lib().egnn_sampler_final(self.ctx.handle, self._sp(), self.precision, self.norm_scope,
+                                                 _lib.ptr(keep[0]), _lib.ptr(keep[1]), _lib.ptr(pos), _lib.ptr(hc), _lib.ptr(oh)))
+        bad = torch.empty(len(self.sizes), dtype=torch.int32, device=self.device)
+        _lib.check(_lib.lib().egnn_sampler_state(self.ctx.handle, self._sp(), None, None, _lib.ptr(bad), None))
+        self.stream.synchronize()
+        return pos, hc, oh.long(), bad
+
+    def sample(self, use_graph: bool = True):
+        self.init()
+        self.run(use_graph=use_graph)
+        return self.final()
+
+
+def build_condition(nn_dict, data, params, device):
+    """Constant conditioning columns of h for one datum: [compressed spectrum | spectrum][exO]
+    (parts/train_per_iretation.py:344-351).  The compressor is evaluated once (its input never changes
+    across steps)."""
+    cols = []
+    if params["conditional"]:
+        spec = data.spectrum.to(device=device, dtype=torch.float32)
+        if params["to_compress_spectrum"]:
+            with torch.no_grad():
+                spec = nn_dict["spectrum_compressor"].to(device).eval()(spec)
+        cols.append(spec)
+    if params["give_exO"]:
+        cols.append(data.exO.to(device=device, dtype=torch.float32))
+    if not cols:
+        return None
+    return torch.cat(cols, dim=1)
+
+
+def generate(nn_dict, test_data, params, diffusion_process, gen_num_per_spectrum=5, seed: Optional[int] = None,
+             use_graph: bool = True):
+    """generate(nn_dict, test_data, params, diffusion_process, gen_num_per_spectrum=5)
+    -> (original_graph_list, generated_graph_list)   (parts/train_per_iretation.py:264-444).
+
+    Each generated entry is a list whose last element carries ``.pos [N,3]`` and ``.x [N,A]`` (one-hot),
+    as in the reference (the reference's intermediate trajectory entries all alias the final state,
+    SURVEY Q5, so only the final state is stored).  The samples of one conditioning datum are drawn as
+    one device batch; a sample with a non-finite value is redrawn (at most 10 times per datum, :376-389)
+    and a sample with a coordinate > 1000 is rejected (:434).
+    """
+    egnn = nn_dict["egnn"]
+    device = torch.device("cuda")
+    egnn.to(device).eval()
+    A = params["atom_type_size"]
+    base_seed = int(params.get("seed", 0) if seed is None else seed)
+    original_graph_list, generated_graph_list = [], []
+    with torch.no_grad():
+        for idx in range(len(test_data)):
+            data = test_data[idx]
+            n_atoms = data.x.shape[0]
+            cond1 = build_condition(nn_dict, data, params, device)
+            done, n_nan, attempt = 0, 0, 0
+            while done != gen_num_per_spectrum:
+                k = gen_num_per_spectrum - done
+                cond = None if cond1 is None else cond1.repeat(k, 1)
+                smp = DeviceSampler(egnn, diffusion_process, [n_atoms] * k, cond, atom_type_size=A,
+                                    onehot_scaling_factor=params["onehot_scaling_factor"],
+                                    seed=base_seed * 1000003 + idx * 1009 + attempt, norm_scope="graph", device=device)
+                attempt += 1
+                pos, hc, onehot, bad = smp.sample(use_graph=use_graph)
+                bad = bad.cpu()
+                for g in range(k):
+                    sl = slice(g * n_atoms, (g + 1) * n_atoms)
+                    if int(bad[g]) != 0:
+                        n_nan += 1
+                        if n_nan >= 10:
+                            raise RuntimeError("too much nan was generated")
+                        continue
+                    if bool((pos[sl] > 1000).any()):
+                        continue
+                    graph = SimpleNamespace(x=onehot[sl].clone(), pos=pos[sl].clone(), h=hc[sl].clone(),
+                                            edge_index=fully_connected_edge_index(n_atoms, device=device))
+                    if params["conditional"]:
+                        graph.spectrum = data.spectrum
+                    if params["give_exO"]:
+                        graph.exO = data.exO
+                    generated_graph_list.append([graph])
+                    original_graph_list.append(data if params["conditional"] else -1)
+                    done += 1
+    return original_graph_list, generated_graph_list

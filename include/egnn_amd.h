@@ -1,0 +1,153 @@
+/*
+ * egnn_amd.h -- C ABI of the MI355X (gfx950) EGNN denoiser library (libegnn_amd.so).
+ *
+ * The reference (Ren-Okubo/diffusion_model) is pure Python and has no FFI layer; its de-facto
+ * operator interface for the eps_theta(x_t, h_t, t) path is two call signatures and a state-dict
+ * layout.  Each entry point below names the reference interface it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative EGNN_E* code; nothing throws;
+ *   - all pointers named d_* are DEVICE pointers owned by the caller; the library allocates
+ *     device memory only inside the opaque egnn_ctx workspace (freed by egnn_destroy);
+ *   - every launch goes to the hipStream_t passed in (as void*); no call synchronises the
+ *     device except egnn_create/egnn_destroy/egnn_reserve_*, egnn_sampler_prepare (allocation),
+ *     and the explicitly named *_sync helpers;
+ *   - a context is re-entrant across streams only if calls are externally ordered; it is not
+ *     thread-safe;
+ *   - tensors are row-major fp32 unless noted; weights are torch.nn.Linear layout [out, in].
+ */
+#ifndef EGNN_AMD_H
+#define EGNN_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct egnn_ctx egnn_ctx;
+
+enum {
+  EGNN_OK = 0,
+  EGNN_EINVAL = -22,   /* bad argument / unsupported dimension           */
+  EGNN_ENOMEM = -12,   /* device allocation failed                       */
+  EGNN_ESTATE = -1,    /* call order violated (model/graph/weights unset) */
+  EGNN_EHIP = -5       /* a HIP runtime call failed (see egnn_last_error) */
+};
+
+/* arithmetic of the per-edge MLP contractions */
+enum { EGNN_PREC_F32 = 0,   /* v_mfma_f32_32x32x2_f32: exact fp32 (parity mode)          */
+       EGNN_PREC_BF16 = 1 };/* v_mfma_f32_32x32x16_bf16, fp32 accumulate (throughput)    */
+
+/* scope of the coordinate normaliser ||X_i - X_j||_F of EquivariantGraphNeuralNetwork.py:64 */
+enum { EGNN_NORM_CALL = 0,  /* literal reference: one scalar over every edge of the call  */
+       EGNN_NORM_GRAPH = 1 };/* one scalar per graph (== reference when called per graph) */
+
+const char* egnn_last_error(void);
+int egnn_version(void);
+
+/* ---- workspace ------------------------------------------------------------------------ */
+int egnn_create(egnn_ctx** out, int device);
+int egnn_destroy(egnn_ctx* ctx);
+
+/* Model dimensions.  Replaces the constructor arguments of
+ * EquivariantGNN(L, m_input, m_hidden, m_output, x_input, x_hidden, x_output, h_input, h_hidden,
+ * h_output) (EquivariantGraphNeuralNetwork.py:74-78) under the wiring of main.py:102-121:
+ * m_input = x_input = 2*H+1, x_output = 1, h_input = H+M, h_output = H. */
+int egnn_set_model(egnn_ctx* ctx, int L, int H, int M, int Wm, int Wx, int Wh);
+
+/* Upload + repack the parameters of layer l (state-dict entries egcl_list.{l}.*; fp32 device
+ * pointers in nn.Linear layout).  Must be called again whenever the parameters change. */
+int egnn_pack_layer(egnn_ctx* ctx, void* stream, int l,
+                    const float* d_m0_w, const float* d_m0_b,   /* mlp_m.0  [Wm, 2H+1], [Wm] */
+                    const float* d_m2_w, const float* d_m2_b,   /* mlp_m.2  [M, Wm],    [M]  */
+                    const float* d_x0_w, const float* d_x0_b,   /* mlp_x.0  [Wx, 2H+1], [Wx] */
+                    const float* d_x2_w, const float* d_x2_b,   /* mlp_x.2  [Wx, Wx],   [Wx] */
+                    const float* d_x4_w, const float* d_x4_b,   /* mlp_x.4  [1, Wx],    [1]  */
+                    const float* d_h0_w, const float* d_h0_b,   /* mlp_h.0  [Wh, H+M],  [Wh] */
+                    const float* d_h2_w, const float* d_h2_b,   /* mlp_h.2  [H, Wh],    [H]  */
+                    const float* d_a_w, const float* d_a_b);    /* attention.0 [1, M],  [1]  */
+
+/* Graph topology for subsequent forwards.  Replaces the edge_index argument of
+ * EquivariantGNN.forward(edge_index, h, x) (:85) plus PyG's batch vector.
+ *   d_edge_dst/d_edge_src : int32[E], edges sorted by destination (edge_index[0]) -- the node
+ *                           that RECEIVES the message (flow='target_to_source', :10-11);
+ *   d_row_ptr             : int32[N+1] CSR offsets of that ordering;
+ *   d_graph_ptr           : int32[B+1] node ranges of the B graphs (graphs are contiguous);
+ *   d_node_graph          : int32[N] graph id of every node.
+ * The arrays are referenced, not copied: they must stay alive while the graph is set. */
+int egnn_set_graph(egnn_ctx* ctx, int N, int E, int B,
+                   const int32_t* d_edge_dst, const int32_t* d_edge_src, const int32_t* d_row_ptr,
+                   const int32_t* d_graph_ptr, const int32_t* d_node_graph);
+
+/* One EGCL layer: EGCL.forward(edge_index, h, coords) -> (h', x')
+ * (EquivariantGraphNeuralNetwork.py:67-71).  h [N,H], x [N,3]; outputs must not alias inputs. */
+int egcl_forward(egnn_ctx* ctx, void* stream, int layer, int prec, int norm_scope,
+                 const float* d_h, const float* d_x, float* d_h_out, float* d_x_out);
+
+/* EquivariantGNN.forward(edge_index, h, x) -> (h_L, x_L) (:85-88): all L layers. */
+int egnn_forward(egnn_ctx* ctx, void* stream, int prec, int norm_scope,
+                 const float* d_h, const float* d_x, float* d_h_out, float* d_x_out);
+
+/* epsilon extraction of the callers (parts/train_per_iretation.py:161-163, :367-369):
+ * eps_x = remove_mean(x_L - x_in), eps_h = h_L[:, :A].  d_graph_ptr int32[B+1] gives per-graph
+ * means (remove_mean(x, batch_index), diffusion_x_h.py:9-13); NULL = one mean over all N nodes
+ * (:6-8). */
+int egnn_eps(void* stream, int N, int H, int A, const int32_t* d_graph_ptr, int B, const float* d_h_out,
+             const float* d_x_out, const float* d_x_in, float* d_eps_x, float* d_eps_h);
+
+/* remove_mean(x, batch_index) (diffusion_x_h.py:5-14) on [N,D], out of place. */
+int egnn_remove_mean(void* stream, int N, int D, const int32_t* d_graph_ptr, int B, const float* d_in,
+                     float* d_out);
+
+/* ---- diffusion process ----------------------------------------------------------------- */
+/* polynomial_schedule + clip_noise_schedule (diffusion_x_h.py:92-106) evaluated on the host in
+ * fp32 in the same operation order.  alpha/sigma: float[T+1]; table: float[(T+1)*4] rows
+ * {1/alpha_ts, sigma2_ts/(alpha_ts*sigma_t), std, t/T}; row 0 = final decode constants
+ * {1/alpha_0, sigma_0/alpha_0, sigma_0/alpha_0, 0} (train_per_iretation.py:416-426).
+ * Any of the three outputs may be NULL. */
+int schedule_table_build(int T, double s, double power, float* alpha, float* sigma, float* table);
+/* same table from explicit alpha/sigma arrays (learned gamma schedule, diffusion_x_h.py:36-46) */
+int schedule_table_from_alpha(int T, const float* alpha, const float* sigma, float* table);
+
+/* reverse_diffuse_one_step(z, eps, t, mode) (diffusion_x_h.py:75-90) with the step constants
+ * c = {1/alpha_ts, sigma2_ts/(alpha_ts sigma_t), std}:  z_out = z*c0 - eps*c1 + c2*noise, noise
+ * mean-removed (per graph if d_graph_ptr, else over all nodes) when mode_pos != 0.  d_noise supplies
+ * the N(0,1) draw (the reference uses torch's global RNG).  z is [N, D] with row stride ldz.
+ * With (c0, c1, c2) = (alpha_t, 0, sigma_t) the same kernel is diffuse_zero_to_t (:51-59). */
+int ddpm_reverse_step(void* stream, int N, int D, int mode_pos, const int32_t* d_graph_ptr, int B,
+                      float c0, float c1, float c2, const float* d_z, int ldz, const float* d_eps,
+                      const float* d_noise, float* d_z_out, int ldo);
+
+/* ---- device-resident sampler (generate(), parts/train_per_iretation.py:264-444) ---------- */
+/* Allocates sampler state for the current graph: pos [N,3], h [N,H] = [s*x_types | cond | t/T].
+ * d_cond [N, H-A-1] is the constant conditioning block ([compressed spectrum | exO]); d_table is
+ * the DEVICE copy of schedule_table_build's table.  Noise comes from a counter-based Philox
+ * generator keyed by (seed, step, node, component) unless d_noise_* are given to
+ * egnn_sampler_step. */
+int egnn_sampler_prepare(egnn_ctx* ctx, int T, int A, float onehot_scale, const float* d_table,
+                         const float* d_cond, uint64_t seed);
+/* x_T ~ N(0,I) mean-removed per graph, h_T ~ N(0,I) (:301-305); or copy from the given arrays */
+int egnn_sampler_init(egnn_ctx* ctx, void* stream, const float* d_pos_init, const float* d_x_init);
+/* run `nsteps` reverse steps starting at the sampler's current t (initially T), optionally
+ * replaying a captured hipGraph of one step; explicit noise arrays [nsteps][N][3] / [nsteps][N][A]
+ * (step-major, first entry = highest t) may be NULL. */
+int egnn_sampler_run(egnn_ctx* ctx, void* stream, int prec, int norm_scope, int nsteps,
+                     int use_graph, const float* d_noise_pos, const float* d_noise_h);
+/* final t=0 decode (:391-428): pos_0, continuous h_0, argmax one-hot (int32 [N,A]) */
+int egnn_sampler_final(egnn_ctx* ctx, void* stream, int prec, int norm_scope,
+                       const float* d_noise_pos, const float* d_noise_h,
+                       float* d_pos_out, float* d_hc_out, int32_t* d_onehot_out);
+/* current state + sticky per-graph non-finite flags (int32[B]; :376-389, :431-434) */
+int egnn_sampler_state(egnn_ctx* ctx, void* stream, float* d_pos, float* d_x_types,
+                       int32_t* d_bad_flags, int* t_host);
+
+/* timing helper for bench.py: average duration (ms) of the fused edge kernel over the launches
+ * recorded since the last reset, measured with HIP events on the launch stream. */
+int egnn_profile_enable(egnn_ctx* ctx, int enable);
+int egnn_profile_read(egnn_ctx* ctx, float* edge_ms_avg, int* edge_launches, float* node_ms_avg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EGNN_AMD_H */

@@ -1,0 +1,137 @@
+"""CPU tests: the C-ABI library loads and exports every symbol the header declares; host-side logic
+(graph plan, schedule, module interface) matches the oracle / goldens.  No GPU compute here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import diffusion_model_amd as dma
+from diffusion_model_amd import _lib
+from oracle import egnn_ref
+from oracle.diffusion_ref import DiffusionRef
+from tests._util import dims_for, golden_case, load_golden, sd_sha256
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G_EGNN = load_golden("egnn_golden.npz")
+G_DIFF = load_golden("diffusion_golden.npz")
+
+
+def _header_functions():
+    txt = open(os.path.join(ROOT, "include", "egnn_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(?:int|const char\*)\s+(\w+)\s*\(", txt)))
+
+
+def test_library_exports_every_header_symbol():
+    names = _header_functions()
+    assert len(names) >= 20
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(handle, n), f"{n} declared in include/egnn_amd.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
+    assert sorted(_lib.SIGNATURES) == names
+    assert _lib.lib().egnn_version() >= 1
+
+
+def test_schedule_host_routine_matches_reference_tables():
+    for tag in ("T1000", "T50", "T200"):
+        T, p, s = G_DIFF[f"{tag}.params"]
+        proc = dma.E3DiffusionProcess(float(s), float(p), int(T))
+        assert torch.equal(proc.alpha_schedule, torch.from_numpy(G_DIFF[f"{tag}.alpha"]))       # bit exact
+        sig = torch.from_numpy(G_DIFF[f"{tag}.sigma"])
+        # torch's vectorised CPU sqrt is 1 ulp off the correctly rounded value for a few entries
+        assert ((proc.sigma_schedule - sig).abs() <= 1.2e-7 * sig.abs() + 1e-38).all()
+        ref = DiffusionRef(float(s), float(p), int(T)).step_table()
+        got = proc.step_table()
+        assert ((got - ref).abs() <= 2e-6 * ref.abs() + 1e-12).all()
+        assert proc.num_diffusion_timestep == int(T) and proc.t.shape[0] == int(T) + 1
+        assert float(proc.alpha(0)) == float(proc.alpha_schedule[0])
+
+
+def test_graph_plan_and_edge_builder_on_cpu():
+    sizes = [5, 1, 9, 3]
+    ei = dma.fully_connected_edge_index(sizes)
+    assert torch.equal(ei, egnn_ref.fully_connected_edge_index(sizes))
+    assert torch.equal(dma.fully_connected_edge_index([4, 4, 4]), egnn_ref.fully_connected_edge_index([4, 4, 4]))
+    plan = dma.GraphPlan(ei, sum(sizes), sizes=sizes)
+    assert plan.B == 4 and plan.E == ei.shape[1]
+    assert plan.graph_ptr.tolist() == [0, 5, 6, 15, 18]
+    deg = (plan.row_ptr[1:] - plan.row_ptr[:-1]).tolist()
+    assert deg == [4] * 5 + [0] + [8] * 9 + [2] * 3
+    # unsorted input is stably sorted by the receiving node
+    perm = torch.randperm(ei.shape[1], generator=torch.Generator().manual_seed(0))
+    plan2 = dma.GraphPlan(ei[:, perm], sum(sizes), sizes=sizes)
+    assert torch.equal(plan2.edge_dst, plan.edge_dst)
+    for n in range(sum(sizes)):
+        lo, hi = int(plan2.row_ptr[n]), int(plan2.row_ptr[n + 1])
+        assert sorted(plan2.edge_src[lo:hi].tolist()) == plan.edge_src[lo:hi].tolist()
+    with pytest.raises(ValueError):
+        dma.GraphPlan(torch.tensor([[0], [5]]), 6, sizes=[3, 3])       # edge across graphs
+    with pytest.raises(ValueError):
+        dma.GraphPlan(torch.tensor([[0], [7]]), 6)                     # node out of range
+
+
+def test_module_interface_matches_reference_state_dict():
+    L, H, M, W = 2, 36, 128, 256
+    d = dims_for(H, M, W, W, W)
+    torch.manual_seed(12)
+    net = dma.EquivariantGNN(L, d["m_input"], d["m_hidden"], d["m_output"], d["x_input"], d["x_hidden"],
+                             d["x_output"], d["h_input"], d["h_hidden"], d["h_output"])
+    ref_keys = sorted(k[len("W.w12_L2_H36."):] for k in G_EGNN.files if k.startswith("W.w12_L2_H36."))
+    assert sorted(net.state_dict().keys()) == ref_keys
+    # same construction order => same weights as the reference for the same seed
+    want = bytes(G_EGNN["g8_H36.sha"]).decode()
+    assert sd_sha256(net.state_dict()) == want
+    sd, *_ = golden_case(G_EGNN, "g8_H36")
+    net.load_state_dict(sd)
+    with pytest.raises(ValueError):
+        dma.EquivariantGNN(1, 10, 8, 8, 73, 8, 1, 44, 8, 36)           # inconsistent wiring
+    # parameter count of the default model quoted in SURVEY 8(a)
+    dd = dims_for(36, 256, 1024, 1024, 1024)
+    one = dma.EGCL(**dd)
+    assert sum(p.numel() for p in one.parameters()) == 1801766
+
+
+def test_cpu_tensors_fail_loudly():
+    d = dims_for(3, 128, 256, 256, 256)
+    net = dma.EquivariantGNN(1, **d)
+    ei = dma.fully_connected_edge_index(2)
+    with pytest.raises(RuntimeError):
+        with torch.no_grad():
+            net(ei, torch.zeros(2, 3), torch.zeros(2, 3))
+    with pytest.raises(RuntimeError):
+        dma.remove_mean(torch.zeros(3, 3))
+    proc = dma.E3DiffusionProcess(1e-5, 2.0, 10)
+    with pytest.raises(RuntimeError):
+        proc.reverse_diffuse_one_step(torch.zeros(3, 3), torch.zeros(3, 3), 3)
+
+
+def test_gamma_and_compressor_modules_match_reference():
+    G = load_golden("aux_golden.npz")
+    g = dma.GammaNetwork()
+    g.load_state_dict({k[len("gamma.W."):]: torch.from_numpy(G[k]) for k in G.files if k.startswith("gamma.W.")})
+    with torch.no_grad():
+        out = g(torch.from_numpy(G["gamma.t"]))
+    assert torch.allclose(out, torch.from_numpy(G["gamma.out"]), rtol=1e-6, atol=1e-6)
+    c = dma.SpectrumCompressor(200, [150, 100, 50], 32)
+    c.load_state_dict({k[len("comp.W."):]: torch.from_numpy(G[k]) for k in G.files if k.startswith("comp.W.")})
+    with torch.no_grad():
+        outc = c(torch.from_numpy(G["comp.in"]))
+    assert torch.allclose(outc, torch.from_numpy(G["comp.out"]), rtol=1e-6, atol=1e-6)
+    # same-seed construction reproduces the reference's initial weights
+    torch.manual_seed(5)
+    g2 = dma.GammaNetwork()
+    for k, v in g2.state_dict().items():
+        assert torch.equal(v, torch.from_numpy(G["gamma.W." + k])), k
+    torch.manual_seed(6)
+    c2 = dma.SpectrumCompressor(200, [150, 100, 50], 32)
+    for k, v in c2.state_dict().items():
+        assert torch.equal(v, torch.from_numpy(G["comp.W." + k])), k
+    # learned schedule: alpha^2 + sigma^2 = 1 and monotone alpha
+    proc = dma.E3DiffusionProcess(1e-5, 2.0, 20, noise_schedule="learned")
+    a = torch.stack([proc.alpha(t) for t in range(21)])
+    s = torch.stack([proc.sigma(t) for t in range(21)])
+    assert torch.allclose(a ** 2 + s ** 2, torch.ones(21), atol=1e-6) and bool((a[1:] <= a[:-1]).all())

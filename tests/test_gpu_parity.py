@@ -1,0 +1,346 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against
+the CPU oracle and the committed golden vectors.
+
+Tolerances
+  fp32 path  : 1e-4 relative (BASELINE.json north_star); measured errors are ~1e-6.
+  bf16 path  : MFMA operands are rounded to bf16 (8 significant bits) with fp32 accumulation;
+               5e-2 relative to the oracle on eps, stated in each test.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import diffusion_model_amd as dma
+from oracle import egnn_ref
+from oracle.diffusion_ref import DiffusionRef
+from oracle.sampler_ref import sample_one_graph
+from tests._util import dims_for, golden_case, load_golden, max_rel, rel_err
+
+pytestmark = pytest.mark.gpu
+G_EGNN = load_golden("egnn_golden.npz")
+G_DIFF = load_golden("diffusion_golden.npz")
+EGNN_CASES = [str(c) for c in G_EGNN["cases"]]
+DEV = "cuda"
+
+
+def build_net(sd, d, L, precision="fp32", norm_scope="call"):
+    net = dma.EquivariantGNN(L, d["m_input"], d["m_hidden"], d["m_output"], d["x_input"], d["x_hidden"],
+                             d["x_output"], d["h_input"], d["h_hidden"], d["h_output"])
+    net.load_state_dict(sd)
+    net.to(DEV).eval()
+    net.precision, net.norm_scope = precision, norm_scope
+    return net
+
+
+@pytest.mark.parametrize("tag", EGNN_CASES)
+def test_egnn_fp32_matches_reference_golden(tag):
+    sd, h, x, sizes, layers, d = golden_case(G_EGNN, tag)
+    L = len(layers)
+    net = build_net(sd, d, L)
+    ei = dma.fully_connected_edge_index(sizes, device=DEV)
+    with torch.no_grad():
+        h_o, x_o = net(ei, h.to(DEV), x.to(DEV))
+    assert max_rel(h_o.cpu(), layers[-1][0]) <= 1e-4
+    assert max_rel(x_o.cpu(), layers[-1][1]) <= 1e-4
+    # per-layer: run the single-layer module chain
+    hh, xx = h.to(DEV), x.to(DEV)
+    with torch.no_grad():
+        for l in range(L):
+            hh, xx = net.egcl_list[l](ei, hh, xx)
+            assert max_rel(hh.cpu(), layers[l][0]) <= 1e-4, f"layer {l} h"
+            assert max_rel(xx.cpu(), layers[l][1]) <= 1e-4, f"layer {l} x"
+
+
+@pytest.mark.parametrize("tag", ["g64_H36", "g16x3_H36", "full_g64"])
+def test_egnn_bf16_close_to_oracle(tag):
+    sd, h, x, sizes, layers, d = golden_case(G_EGNN, tag)
+    net = build_net(sd, d, len(layers), precision="bf16")
+    ei = dma.fully_connected_edge_index(sizes, device=DEV)
+    with torch.no_grad():
+        h_o, x_o = net(ei, h.to(DEV), x.to(DEV))
+    # bf16 operands, fp32 accumulation: tolerance 5e-2 on the layer outputs / eps
+    assert rel_err(h_o.cpu(), layers[-1][0]) <= 5e-2
+    assert rel_err(x_o.cpu() - x, layers[-1][1] - x) <= 5e-2
+    assert torch.isfinite(h_o).all() and torch.isfinite(x_o).all()
+
+
+def test_norm_scope_graph_equals_single_graph_calls_on_gpu():
+    sd, h, x, sizes, layers, d = golden_case(G_EGNN, "g16x3_H36")
+    L = len(layers)
+    net = build_net(sd, d, L, norm_scope="graph")
+    ei = dma.fully_connected_edge_index(sizes, device=DEV)
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes)).to(DEV)
+    with torch.no_grad():
+        hb, xb = net(ei, h.to(DEV), x.to(DEV), batch=batch)
+    ptr = torch.tensor([0] + list(np.cumsum(sizes)))
+    ho, xo = egnn_ref.egnn_forward(sd, egnn_ref.fully_connected_edge_index(sizes), h, x, "graph", ptr)
+    assert max_rel(hb.cpu(), ho) <= 1e-4 and max_rel(xb.cpu(), xo) <= 1e-4
+    single = build_net(sd, d, L, norm_scope="call")
+    off = 0
+    for n in sizes:
+        e1 = dma.fully_connected_edge_index(n, device=DEV)
+        with torch.no_grad():
+            h1, x1 = single(e1, h[off:off + n].to(DEV), x[off:off + n].to(DEV))
+        assert max_rel(hb[off:off + n], h1) <= 1e-4 and max_rel(xb[off:off + n], x1) <= 1e-4
+        off += n
+
+
+def _random_graph(n, e, seed, self_loops=True):
+    g = torch.Generator().manual_seed(seed)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    if not self_loops:
+        ei = ei[:, ei[0] != ei[1]]
+    return ei
+
+
+@pytest.mark.parametrize("n,e,seed", [(40, 300, 1), (200, 9000, 2), (7, 0, 3), (130, 129 * 130, 4)])
+def test_generic_edge_lists_unsorted_duplicates_isolated(n, e, seed):
+    """Arbitrary edge_index: unsorted, duplicate edges, self loops, nodes without edges, nodes whose
+    degree exceeds the tile (partial-sum path), and E = 0."""
+    sd, _, _, _, layers, d = golden_case(G_EGNN, "g8_H36")
+    L = len(layers)
+    net = build_net(sd, d, L)
+    g = torch.Generator().manual_seed(100 + seed)
+    h, x = torch.randn(n, 36, generator=g), torch.randn(n, 3, generator=g)
+    if e == 129 * 130:
+        ei = egnn_ref.fully_connected_edge_index(n)       # degree 129 > 64-row tile
+    else:
+        ei = _random_graph(n, e, seed)
+        if e:
+            ei[0, : e // 3] = 5                            # one hub node with a very large in-degree
+    with torch.no_grad():
+        h_o, x_o = net(ei.to(DEV), h.to(DEV), x.to(DEV))
+    ho, xo = egnn_ref.egnn_forward(sd, ei, h, x)
+    assert max_rel(h_o.cpu(), ho) <= 1e-4
+    assert max_rel(x_o.cpu(), xo) <= 1e-4
+
+
+def test_bitwise_deterministic_and_inputs_untouched():
+    sd, h, x, sizes, layers, d = golden_case(G_EGNN, "g64_H36")
+    net = build_net(sd, d, len(layers), precision="bf16")
+    ei = dma.fully_connected_edge_index(sizes, device=DEV)
+    hd, xd = h.to(DEV), x.to(DEV)
+    with torch.no_grad():
+        a = net(ei, hd, xd)
+        b = net(ei, hd, xd)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert torch.equal(hd.cpu(), h) and torch.equal(xd.cpu(), x)
+
+
+def _rot(seed):
+    g = torch.Generator().manual_seed(seed)
+    q, r = torch.linalg.qr(torch.randn(3, 3, generator=g))
+    q = q * torch.sign(torch.diagonal(r))
+    if torch.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    return q
+
+
+def c2_inputs(batch, n_atoms=64, H=36, seed=0):
+    """Synthetic 64-atom SiO2-like cells of SURVEY 8(d): jittered 4x4x4 grid, spacing 1.6 A."""
+    g = torch.Generator().manual_seed(seed)
+    side = round(n_atoms ** (1 / 3))
+    grid = torch.stack(torch.meshgrid(*[torch.arange(side, dtype=torch.float32)] * 3, indexing="ij"), -1).reshape(-1, 3) * 1.6
+    pos = grid.repeat(batch, 1) + 0.1 * torch.randn(batch * n_atoms, 3, generator=g)
+    pos = pos - pos.view(batch, n_atoms, 3).mean(1, keepdim=True).repeat_interleave(n_atoms, 0).view(-1, 3)
+    types = torch.zeros(n_atoms, 2)
+    types[0, 0] = 1
+    types[1:22, 1] = 1
+    types[22:, 0] = 1
+    h = torch.zeros(batch * n_atoms, H)
+    h[:, :2] = types.repeat(batch, 1)
+    h[:, 2:H - 2] = torch.randn(batch * n_atoms, H - 4, generator=g)
+    h[::n_atoms, H - 2] = 1.0
+    h[:, H - 1] = 0.5
+    return h, pos
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16", 6e-2)])
+def test_full_size_c2_properties(precision, tol):
+    """BASELINE configs[1] size (256 graphs x 64 atoms, L=4, widths 1024/256): size-independent
+    properties -- E(3) equivariance, graph-permutation equivariance, batch == single-graph calls --
+    plus a spot check of two graphs against the oracle."""
+    B, n = 256, 64
+    d = dims_for(36, 256, 1024, 1024, 1024)
+    torch.manual_seed(2024)
+    net = dma.EquivariantGNN(4, **d).to(DEV).eval()
+    net.precision, net.norm_scope = precision, "graph"
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    h, x = c2_inputs(B)
+    sizes = [n] * B
+    ei = dma.fully_connected_edge_index(sizes, device=DEV)
+    batch = torch.arange(B).repeat_interleave(n).to(DEV)
+    with torch.no_grad():
+        h0, x0 = net(ei, h.to(DEV), x.to(DEV), batch=batch)
+        R, tvec = _rot(5), torch.tensor([0.7, -0.2, 1.1])
+        h1, x1 = net(ei, h.to(DEV), (x @ R.T + tvec).to(DEV), batch=batch)
+    assert torch.isfinite(h0).all() and torch.isfinite(x0).all()
+    etol = 1e-4 if precision == "fp32" else tol
+    assert rel_err(h1.cpu(), h0.cpu()) <= etol
+    assert rel_err((x1.cpu() - (x @ R.T + tvec)), (x0.cpu() - x) @ R.T) <= etol
+    # permuting whole graphs permutes the outputs (bitwise: same tiles, same arithmetic)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(3))
+    idx = (perm.repeat_interleave(n) * n + torch.arange(n).repeat(B))
+    with torch.no_grad():
+        h2, x2 = net(ei, h[idx].to(DEV), x[idx].to(DEV), batch=batch)
+    assert torch.equal(h2.cpu(), h0.cpu()[idx]) and torch.equal(x2.cpu(), x0.cpu()[idx])
+    # oracle spot check on graphs 0 and 137
+    e1 = egnn_ref.fully_connected_edge_index(n)
+    for gidx in (0, 137):
+        sl = slice(gidx * n, (gidx + 1) * n)
+        ho, xo = egnn_ref.egnn_forward(sd, e1, h[sl], x[sl])
+        assert rel_err(h0[sl].cpu(), ho) <= tol
+        assert rel_err(x0[sl].cpu() - x[sl], xo - x[sl]) <= tol
+
+
+@pytest.mark.parametrize("tag", ["T1000", "T50", "T200"])
+def test_diffusion_steps_match_reference_golden(tag):
+    T, p, s = G_DIFF[f"{tag}.params"]
+    proc = dma.E3DiffusionProcess(float(s), float(p), int(T))
+    z3, e3 = torch.from_numpy(G_DIFF[f"{tag}.z3"]).to(DEV), torch.from_numpy(G_DIFF[f"{tag}.e3"]).to(DEV)
+    z2, e2 = torch.from_numpy(G_DIFF[f"{tag}.z2"]).to(DEV), torch.from_numpy(G_DIFF[f"{tag}.e2"]).to(DEV)
+    for t in [int(v) for v in G_DIFF[f"{tag}.ts"]]:
+        f = lambda k: torch.from_numpy(G_DIFF[f"{tag}.{k}.t{t}"])
+        # fp32 elementwise arithmetic with pre-divided constants: 1e-5 relative to the largest entry
+        assert max_rel(proc.calculate_mu(z3, e3, t).cpu(), f("mu3")) <= 1e-5
+        assert max_rel(proc.calculate_mu(z2, e2, t).cpu(), f("mu2")) <= 1e-5
+        got = proc.reverse_diffuse_one_step(z3, e3, t, mode="pos", noise=f("noise_pos").to(DEV))
+        assert max_rel(got.cpu(), f("rev_pos")) <= 1e-5
+        got = proc.reverse_diffuse_one_step(z2, e2, t, mode="h", noise=f("noise_h").to(DEV))
+        assert max_rel(got.cpu(), f("rev_h")) <= 1e-5
+    xo = dma.diffusion.E3DiffusionProcessXOnly(float(s), float(p), int(T))
+    t = int(G_DIFF[f"{tag}.ts"][2])
+    mu = xo.calculate_mu(z3, e3, t)
+    assert max_rel(mu.cpu(), torch.from_numpy(G_DIFF[f"{tag}.mu3_xhat.t{t}"])) <= 1e-4
+    got = xo.reverse_diffuse_one_step(mu, t, noise=torch.from_numpy(G_DIFF[f"{tag}.noise_xhat.t{t}"]).to(DEV))
+    assert max_rel(got.cpu(), torch.from_numpy(G_DIFF[f"{tag}.rev_xhat.t{t}"])) <= 1e-4
+    # forward noising: statistics only (torch RNG on the device)
+    zt, noise = proc.diffuse_zero_to_t(z3, t, mode="pos")
+    assert noise.mean(0).abs().max() < 1e-5
+    assert max_rel(zt.cpu(), (proc.alpha(t) * z3.cpu() + proc.sigma(t) * noise.cpu())) <= 1e-5
+
+
+def test_remove_mean_matches_reference_golden():
+    v = torch.from_numpy(G_DIFF["rm.in"]).to(DEV)
+    bi = torch.from_numpy(G_DIFF["rm.batch"]).to(DEV)
+    assert max_rel(dma.remove_mean(v.clone()).cpu(), torch.from_numpy(G_DIFF["rm.global"])) <= 1e-6
+    w = v.clone()
+    out = dma.remove_mean(w, bi)
+    assert out is w                                              # in place, like the reference
+    assert max_rel(w.cpu(), torch.from_numpy(G_DIFF["rm.per_graph"])) <= 1e-6
+
+
+def _noise_bank(T, n, A, seed):
+    g = torch.Generator().manual_seed(seed)
+    bank = {"init_pos": torch.randn(n, 3, generator=g), "init_h": torch.randn(n, A, generator=g)}
+    bank["pos"] = torch.randn(T + 1, n, 3, generator=g)
+    bank["h"] = torch.randn(T + 1, n, A, generator=g)
+    return bank
+
+
+@pytest.mark.parametrize("use_cond", [False, True])
+def test_sampler_loop_matches_oracle_with_explicit_noise(use_cond):
+    """generate()'s reverse loop + final decode for T=12 with the SAME noise fed to the oracle loop and
+    to the device sampler (two graphs in one device batch == two oracle runs)."""
+    T, n, A = 12, 6, 2
+    H = 36 if use_cond else 3
+    d = dims_for(H, 128, 256, 256, 256)
+    torch.manual_seed(77)
+    net = dma.EquivariantGNN(2, **d).to(DEV).eval()
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    proc = dma.E3DiffusionProcess(1e-5, 2.0, T)
+    ref = DiffusionRef(1e-5, 2.0, T)
+    banks = [_noise_bank(T, n, A, 10), _noise_bank(T, n, A, 11)]
+    g = torch.Generator().manual_seed(5)
+    conds = [torch.randn(n, H - A - 1, generator=g) if use_cond else None for _ in range(2)]
+    outs = []
+    for bank, cond in zip(banks, conds):
+        fn = lambda tag, step, shape, bank=bank: (bank[tag].clone() if tag.startswith("init") else bank[tag][step].clone())
+        outs.append(sample_one_graph(sd, ref, n, cond, fn, atom_type_size=A))
+    cond = torch.cat(conds) if use_cond else None
+    smp = dma.DeviceSampler(net, proc, [n, n], cond, atom_type_size=A, norm_scope="graph", precision="fp32")
+    smp.init(pos_init=torch.cat([b["init_pos"] for b in banks]), x_init=torch.cat([b["init_h"] for b in banks]))
+    # step-major noise, first entry = t = T
+    npos = torch.stack([torch.cat([b["pos"][t] for b in banks]) for t in range(T, 0, -1)])
+    nh = torch.stack([torch.cat([b["h"][t] for b in banks]) for t in range(T, 0, -1)])
+    smp.run(noise_pos=npos, noise_h=nh)
+    assert smp.t == 0
+    pos, hc, onehot, bad = smp.final(noise_pos=torch.cat([b["pos"][0] for b in banks]),
+                                     noise_h=torch.cat([b["h"][0] for b in banks]))
+    assert int(bad.sum()) == 0
+    for gi, (p_ref, hc_ref, oh_ref, ok) in enumerate(outs):
+        assert ok
+        sl = slice(gi * n, (gi + 1) * n)
+        # 13 chained EGNN evaluations: 1e-3 relative
+        assert rel_err(pos[sl].cpu(), p_ref) <= 1e-3
+        assert rel_err(hc[sl].cpu(), hc_ref) <= 1e-3
+        assert torch.equal(onehot[sl].cpu(), oh_ref)
+
+
+def test_sampler_graph_replay_equals_eager_and_is_seed_deterministic():
+    T, n, A, H = 20, 16, 2, 36
+    d = dims_for(H, 128, 256, 256, 256)
+    torch.manual_seed(3)
+    net = dma.EquivariantGNN(2, **d).to(DEV).eval()
+    net.precision = "bf16"
+    proc = dma.E3DiffusionProcess(1e-5, 2.0, T)
+    cond = torch.randn(3 * n, H - A - 1, generator=torch.Generator().manual_seed(1))
+    res = []
+    for use_graph in (True, False, True):
+        smp = dma.DeviceSampler(net, proc, [n] * 3, cond, atom_type_size=A, seed=1234)
+        res.append(smp.sample(use_graph=use_graph))
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    for a, b in zip(res[0], res[2]):
+        assert torch.equal(a, b)
+    pos = res[0][0]
+    assert torch.isfinite(pos).all()
+    # positions stay mean-free per graph (noise and eps_x are mean-removed, x_T is mean-free)
+    assert pos.view(3, n, 3).mean(1).abs().max() < 1e-3
+    smp2 = dma.DeviceSampler(net, proc, [n] * 3, cond, atom_type_size=A, seed=999)
+    assert not torch.equal(smp2.sample()[0], pos)
+
+
+def test_device_noise_statistics():
+    """Philox / Box-Muller draws used by the sampler: mean 0, variance 1, no cross-step correlation."""
+    T, n, A, H = 4, 4096, 2, 3
+    d = dims_for(H, 128, 256, 256, 256)
+    net = dma.EquivariantGNN(1, **d).to(DEV).eval()
+    proc = dma.E3DiffusionProcess(1e-5, 2.0, T)
+    ei = torch.zeros(2, 0, dtype=torch.long, device=DEV)               # no edges: state init only
+    smp = dma.DeviceSampler(net, proc, [n], None, atom_type_size=A, seed=7, edge_index=ei)
+    smp.init()
+    pos, xt, _ = smp.state()
+    for v in (pos, xt):
+        assert abs(float(v.mean())) < 0.05 and abs(float(v.var()) - 1.0) < 0.05
+    assert pos.mean(0).abs().max() < 1e-5
+    k = float(((pos - pos.mean()) ** 4).mean() / pos.var() ** 2)
+    assert abs(k - 3.0) < 0.25
+
+
+def test_generate_interface():
+    from types import SimpleNamespace
+    params = dict(num_diffusion_timestep=8, conditional=True, atom_type_size=2, spectrum_size=200,
+                  onehot_scaling_factor=1.0, to_compress_spectrum=True, give_exO=True, noise_schedule="predefined",
+                  seed=2024)
+    H = 2 + 32 + 1 + 1
+    d = dims_for(H, 128, 256, 256, 256)
+    torch.manual_seed(0)
+    nn_dict = {"egnn": dma.EquivariantGNN(2, **d), "spectrum_compressor": dma.SpectrumCompressor(200, [150, 100, 50], 32)}
+    proc = dma.E3DiffusionProcess(1e-5, 2.0, 8)
+    data = []
+    for n in (5, 9):
+        spec = torch.zeros(n, 200)
+        spec[0] = torch.rand(200)
+        exo = torch.zeros(n, 1)
+        exo[0] = 1
+        data.append(SimpleNamespace(x=torch.zeros(n, 2), pos=torch.zeros(n, 3), spectrum=spec, exO=exo))
+    orig, gen = dma.generate(nn_dict, data, params, proc, gen_num_per_spectrum=3)
+    assert len(orig) == len(gen) == 6
+    for o, gl in zip(orig, gen):
+        g = gl[-1]
+        n = o.x.shape[0]
+        assert g.pos.shape == (n, 3) and g.x.shape == (n, 2)
+        assert torch.isfinite(g.pos).all() and bool((g.x.sum(1) == 1).all())
