@@ -244,14 +244,16 @@ def _noise_bank(T, n, A, seed):
 def test_sampler_loop_matches_oracle_with_explicit_noise(use_cond):
     """generate()'s reverse loop + final decode for T=12 with the SAME noise fed to the oracle loop and
     to the device sampler (two graphs in one device batch == two oracle runs)."""
-    T, n, A = 12, 6, 2
+    # s = 0.2 keeps the 12-step chain numerically tame with untrained weights (alpha_T ~ 0.2); the
+    # reference's s = 1e-5 at T = 12 overflows in the oracle too -- see test_sampler_nan_flag below
+    T, n, A, S = 12, 6, 2, 0.2
     H = 36 if use_cond else 3
     d = dims_for(H, 128, 256, 256, 256)
     torch.manual_seed(77)
     net = dma.EquivariantGNN(2, **d).to(DEV).eval()
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
-    proc = dma.E3DiffusionProcess(1e-5, 2.0, T)
-    ref = DiffusionRef(1e-5, 2.0, T)
+    proc = dma.E3DiffusionProcess(S, 2.0, T)
+    ref = DiffusionRef(S, 2.0, T)
     banks = [_noise_bank(T, n, A, 10), _noise_bank(T, n, A, 11)]
     g = torch.Generator().manual_seed(5)
     conds = [torch.randn(n, H - A - 1, generator=g) if use_cond else None for _ in range(2)]
@@ -279,24 +281,68 @@ def test_sampler_loop_matches_oracle_with_explicit_noise(use_cond):
         assert torch.equal(onehot[sl].cpu(), oh_ref)
 
 
+def test_sampler_first_steps_of_T1000_and_nan_flag():
+    """(a) the reference schedule (T=1000, s=1e-5): first 6 reverse steps from t=T against the oracle;
+    (b) failure detection: a schedule that overflows in the oracle (T=12, s=1e-5, untrained weights)
+    raises the device's sticky per-graph non-finite flag (train_per_iretation.py:376-389)."""
+    n, A, H = 8, 2, 36
+    d = dims_for(H, 128, 256, 256, 256)
+    torch.manual_seed(78)
+    net = dma.EquivariantGNN(2, **d).to(DEV).eval()
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    cond = torch.randn(n, H - A - 1, generator=torch.Generator().manual_seed(2))
+    T, K = 1000, 6
+    bank = _noise_bank(T, n, A, 20)
+    fn = lambda tag, step, shape: (bank[tag].clone() if tag.startswith("init") else bank[tag][step].clone())
+    p_ref, x_ref, _, ok = sample_one_graph(sd, DiffusionRef(1e-5, 2.0, T), n, cond, fn, atom_type_size=A, n_steps=K)
+    assert ok
+    smp = dma.DeviceSampler(net, dma.E3DiffusionProcess(1e-5, 2.0, T), [n], cond, atom_type_size=A, precision="fp32")
+    smp.init(pos_init=bank["init_pos"], x_init=bank["init_h"])
+    smp.run(nsteps=K, noise_pos=torch.stack([bank["pos"][t] for t in range(T, T - K, -1)]),
+            noise_h=torch.stack([bank["h"][t] for t in range(T, T - K, -1)]))
+    assert smp.t == T - K
+    pos, xt, bad = smp.state()
+    assert int(bad.sum()) == 0
+    assert rel_err(pos.cpu(), p_ref) <= 1e-3 and rel_err(xt.cpu(), x_ref) <= 1e-3
+    # (b)
+    T2 = 12
+    bank = _noise_bank(T2, n, A, 21)
+    out = sample_one_graph(sd, DiffusionRef(1e-5, 2.0, T2), n, cond, fn, atom_type_size=A)
+    assert out[3] is False
+    smp = dma.DeviceSampler(net, dma.E3DiffusionProcess(1e-5, 2.0, T2), [n], cond, atom_type_size=A, precision="fp32")
+    smp.init(pos_init=bank["init_pos"], x_init=bank["init_h"])
+    smp.run(noise_pos=torch.stack([bank["pos"][t] for t in range(T2, 0, -1)]),
+            noise_h=torch.stack([bank["h"][t] for t in range(T2, 0, -1)]))
+    assert int(smp.state()[2][0]) == 1
+
+
+def _tame(net, f=1e-2):
+    """untrained weights make the reverse chain explode; shrink the coordinate head"""
+    with torch.no_grad():
+        for layer in net.egcl_list:
+            layer.mlp_x[4].weight.mul_(f)
+            layer.mlp_x[4].bias.mul_(f)
+    return net
+
+
 def test_sampler_graph_replay_equals_eager_and_is_seed_deterministic():
     T, n, A, H = 20, 16, 2, 36
     d = dims_for(H, 128, 256, 256, 256)
     torch.manual_seed(3)
-    net = dma.EquivariantGNN(2, **d).to(DEV).eval()
+    net = _tame(dma.EquivariantGNN(2, **d)).to(DEV).eval()
     net.precision = "bf16"
-    proc = dma.E3DiffusionProcess(1e-5, 2.0, T)
+    proc = dma.E3DiffusionProcess(0.2, 2.0, T)
     cond = torch.randn(3 * n, H - A - 1, generator=torch.Generator().manual_seed(1))
     res = []
     for use_graph in (True, False, True):
         smp = dma.DeviceSampler(net, proc, [n] * 3, cond, atom_type_size=A, seed=1234)
         res.append(smp.sample(use_graph=use_graph))
+    pos = res[0][0]
+    assert torch.isfinite(pos).all() and int(res[0][3].sum()) == 0
     for a, b in zip(res[0], res[1]):
         assert torch.equal(a, b)
     for a, b in zip(res[0], res[2]):
         assert torch.equal(a, b)
-    pos = res[0][0]
-    assert torch.isfinite(pos).all()
     # positions stay mean-free per graph (noise and eps_x are mean-removed, x_T is mean-free)
     assert pos.view(3, n, 3).mean(1).abs().max() < 1e-3
     smp2 = dma.DeviceSampler(net, proc, [n] * 3, cond, atom_type_size=A, seed=999)
@@ -328,8 +374,8 @@ def test_generate_interface():
     H = 2 + 32 + 1 + 1
     d = dims_for(H, 128, 256, 256, 256)
     torch.manual_seed(0)
-    nn_dict = {"egnn": dma.EquivariantGNN(2, **d), "spectrum_compressor": dma.SpectrumCompressor(200, [150, 100, 50], 32)}
-    proc = dma.E3DiffusionProcess(1e-5, 2.0, 8)
+    nn_dict = {"egnn": _tame(dma.EquivariantGNN(2, **d)), "spectrum_compressor": dma.SpectrumCompressor(200, [150, 100, 50], 32)}
+    proc = dma.E3DiffusionProcess(0.2, 2.0, 8)
     data = []
     for n in (5, 9):
         spec = torch.zeros(n, 200)
