@@ -3,8 +3,8 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC  := diffusion_model_amd/csrc
 OUT   := diffusion_model_amd/libegnn_amd.so
-SRCS  := $(CSRC)/egnn_forward.hip $(CSRC)/sampler.hip
-HDRS  := $(CSRC)/common.h include/egnn_amd.h
+SRCS  := $(CSRC)/egnn_forward.hip $(CSRC)/edge_bf16.hip $(CSRC)/sampler.hip
+HDRS  := $(CSRC)/common.h $(CSRC)/kernels.h include/egnn_amd.h
 FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -ffp-contract=off
 
 OBJS := $(SRCS:.hip=.o)

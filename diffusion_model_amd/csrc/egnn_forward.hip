@@ -20,6 +20,7 @@
 #include <stdarg.h>
 
 #include "common.h"
+#include "kernels.h"
 
 namespace egnn {
 
@@ -30,19 +31,6 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-
-__device__ __forceinline__ float silu_f(float v) {
-  // v * sigmoid(v); exp(-v) = inf for very negative v gives rcp = 0 and the correct limit -0
-  return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
-}
-__device__ __forceinline__ float sigmoid_f(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
-
-// row of accumulator register `reg` of a 32x32 MFMA tile for this lane (C/D layout, gfx950)
-__device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 // ------------------------------------------------------------------------------------------------
 // parameter packing
@@ -166,30 +154,6 @@ __global__ __launch_bounds__(kThreads) void graph_scale_kernel(const float* __re
 // ------------------------------------------------------------------------------------------------
 // fused edge kernel
 // ------------------------------------------------------------------------------------------------
-struct EdgeParams {
-  int N, E;
-  const int* edge_dst;
-  const int* edge_src;
-  const int* row_ptr;
-  const float* x;      // [N][3]
-  const float* table;  // [N][TC]
-  int TC, WxP, WmP, MP, cbx, cbm;
-  const float *wdx, *wdm, *b2x, *w3x, *b2m, *wa, *scal;
-  const void *w2x, *w2m;
-  float *agg_m, *agg_x, *part_m, *part_x;
-};
-
-// layout helper used by both host (size) and device (carve): ints/floats 12*R*4 bytes, then 2 A1
-// buffers, then the message tile.
-__host__ __device__ inline size_t edge_smem_small(int R) { return (size_t)12 * R * 4; }
-__host__ __device__ inline size_t edge_a1_bytes(int R) {
-  const size_t bf = (size_t)8 * (R + 1) * 16, f32 = (size_t)32 * R * 4;
-  return (bf > f32 ? bf : f32);
-}
-__host__ __device__ inline size_t edge_smem_bytes(int R, int MP) {
-  return edge_smem_small(R) + 2 * edge_a1_bytes(R) + (size_t)R * (MP + 1) * 4;
-}
-
 // ---- second-layer GEMM of one edge MLP over a tile of R = 32*RB edges --------------------------
 // acc[rb][cb] (+)= SiLU(P[dst] + Q[src] + wd*d2)[R, KP] . W2^T[KP, wave's 32*CB columns]
 // The hidden activation is produced KC columns at a time into a double-buffered LDS chunk that all
@@ -441,7 +405,6 @@ __global__ __launch_bounds__(kThreads, 1) void edge_kernel(const EdgeParams p) {
 
   // ---- coordinate branch ----
   switch (p.cbx) {
-    case 1: phase_x<PREC, RB, 1>(p, s_dst, s_src, s_d2, s_a1, s_part); break;
     case 2: phase_x<PREC, RB, 2>(p, s_dst, s_src, s_d2, s_a1, s_part); break;
     case 4: phase_x<PREC, RB, 4>(p, s_dst, s_src, s_d2, s_a1, s_part); break;
     default: phase_x<PREC, RB, 8>(p, s_dst, s_src, s_d2, s_a1, s_part); break;
@@ -451,7 +414,6 @@ __global__ __launch_bounds__(kThreads, 1) void edge_kernel(const EdgeParams p) {
 
   // ---- message branch ----
   switch (p.cbm) {
-    case 1: phase_m<PREC, RB, 1>(p, s_dst, s_src, s_d2, s_a1, s_msg); break;
     case 2: phase_m<PREC, RB, 2>(p, s_dst, s_src, s_d2, s_a1, s_msg); break;
     case 4: phase_m<PREC, RB, 4>(p, s_dst, s_src, s_d2, s_a1, s_msg); break;
     default: phase_m<PREC, RB, 8>(p, s_dst, s_src, s_d2, s_a1, s_msg); break;
@@ -768,8 +730,10 @@ int launch_layer(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_scop
     const int tiles = (E + R - 1) / R;
     const size_t smem = edge_smem_bytes(R, c->MP);
     prof_begin(c, st, 0);
-    int rc = prec == EGNN_PREC_BF16 ? launch_edge<EGNN_PREC_BF16, 2>(p, tiles, smem, st)
-                                    : launch_edge<EGNN_PREC_F32, 2>(p, tiles, smem, st);
+    int rc;
+    if (prec == EGNN_PREC_BF16 && edge_bf16_v2_supported(p)) rc = launch_edge_bf16_v2(p, tiles, st);
+    else if (prec == EGNN_PREC_BF16) rc = launch_edge<EGNN_PREC_BF16, 2>(p, tiles, smem, st);
+    else rc = launch_edge<EGNN_PREC_F32, 2>(p, tiles, smem, st);
     prof_end(c, st);
     if (rc) return rc;
   }
@@ -861,11 +825,13 @@ int egnn_set_model(egnn_ctx* c, int L, int H, int M, int Wm, int Wx, int Wh) {
   for (auto& lp : c->layers) free_layer(lp);
   c->layers.assign(L, LayerPack());
   c->L = L; c->H = H; c->M = M; c->Wm = Wm; c->Wx = Wx; c->Wh = Wh;
-  c->cbx = pow2_ceil((Wx + 127) / 128);
-  c->cbm = pow2_ceil((M + 127) / 128);
-  c->WxP = 128 * c->cbx;          // K and N of mlp_x.2
-  c->WmP = round_up(Wm, 64);      // K of mlp_m.2
-  c->MP = 128 * c->cbm;           // N of mlp_m.2
+  // widths are padded to 256 * 2^k: 8 waves x 32-column blocks in the bf16 kernel, 4 waves x 64 in the
+  // fp32 one; zero-padded weights/biases contribute SiLU(0) * 0 = 0
+  c->WxP = 256 * pow2_ceil((Wx + 255) / 256);   // K and N of mlp_x.2
+  c->WmP = 256 * pow2_ceil((Wm + 255) / 256);   // K of mlp_m.2
+  c->MP = 256 * pow2_ceil((M + 255) / 256);     // N of mlp_m.2
+  c->cbx = c->WxP / 128;
+  c->cbm = c->MP / 128;
   c->WhP = round_up(Wh, 128);
   c->HP = round_up(H, 32);
   c->K1P = round_up(H + c->MP, 8);
