@@ -10,7 +10,7 @@ out = sys.argv[1]
 
 
 def short(name):
-    name = name.split("(")[0]
+    name = name.replace("(anonymous namespace)::", "").split("(")[0]
     for k in ("edge_kernel", "node_post_kernel", "node_pre_kernel", "node_d2_kernel", "graph_scale_kernel",
               "sampler_step_kernel", "advance_t_kernel"):
         if k in name:
