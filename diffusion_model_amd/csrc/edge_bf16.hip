@@ -17,6 +17,8 @@
 // Nothing of size [E, *] is written to HBM: the [64, 1024] and [64, 256] second-layer outputs stay in
 // accumulators and are reduced to s_ij (mlp_x.4) / gated messages, then segment-summed per receiving
 // node exactly as in the fp32 kernel (bitwise deterministic, no atomics).
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace egnn {
@@ -27,28 +29,89 @@ constexpr int kT2 = 512;  // threads
 constexpr int kR = 64, kRB = 2, kRPAD = kR + 1, kKC = 64;
 constexpr size_t kA1 = (size_t)8 * kRPAD * 16;  // bytes of one activation chunk [8 k-groups][65][8 bf16]
 
-__host__ __device__ inline size_t v2_small_bytes() { return (size_t)(2 + 1 + 3 + 1 + 1 + 8) * kR * 4; }
+constexpr int kMaxSegFast = 8;  // segments per tile handled by the in-register segment sums
+// dst, src, d2, diff[3], sval, gate, part[8], partg[8], seg tables[5] + misc, gseg[kMaxSegFast]
+__host__ __device__ inline size_t v2_small_bytes() { return (size_t)(2 + 1 + 3 + 1 + 1 + 8 + 8 + 6 + kMaxSegFast) * kR * 4; }
 __host__ __device__ inline size_t v2_smem_bytes(int MP) { return v2_small_bytes() + 4 * kA1 + (size_t)kR * (MP + 1) * 4; }
 
-struct Unit {  // one build unit in flight: 8 columns of one row of one MLP
-  f32x4 p0, p1, q0, q1, w0, w1;
-};
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
-__device__ __forceinline__ void unit_load(Unit& u, const float* __restrict__ prow, const float* __restrict__ qrow,
-                                          const float* __restrict__ wd, int k0) {
-  u.p0 = *reinterpret_cast<const f32x4*>(prow + k0);
-  u.p1 = *reinterpret_cast<const f32x4*>(prow + k0 + 4);
-  u.q0 = *reinterpret_cast<const f32x4*>(qrow + k0);
-  u.q1 = *reinterpret_cast<const f32x4*>(qrow + k0 + 4);
-  u.w0 = *reinterpret_cast<const f32x4*>(wd + k0);
-  u.w1 = *reinterpret_cast<const f32x4*>(wd + k0 + 4);
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
 }
-__device__ __forceinline__ void unit_finish(const Unit& u, float d2, char* slot) {
+// soff must be wave-uniform; readfirstlane makes that provable to the compiler (else it wraps the load
+// in a waterfall loop)
+__device__ __forceinline__ f32x4 ldbuf_f32x4(rsrc_t rs, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, __builtin_amdgcn_readfirstlane(soff), 0));
+}
+__device__ __forceinline__ bf16x8 ldbuf_bf16x8(rsrc_t rs, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, __builtin_amdgcn_readfirstlane(soff), 0));
+}
+
+// ---- cross-lane row reduction without LDS ------------------------------------------------------------
+// v[q], q = 0..31, per lane.  Returns the sum over the 32 lanes of this half-wave of value index
+// q = (lane & 31).  Halving butterfly: every step pairs two lanes, each keeps one half of the value
+// indices: v_permlane16_swap for lane^16, DPP row_ror:8 / row_half_mirror / quad_perm inside a row of
+// 16, bank-masked DPP moves as the per-lane select.  ~80 VALU instructions, no LDS traffic.
+// (The swap is inline asm: hipcc 7.2 folds the two results of __builtin_amdgcn_permlane16_swap into
+// one when they are summed as floats.  s_nop 1 = the 2 wait states between a VALU write and the swap.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), CTRL, 0xF, 0xF, true));
+}
+template <int BANK>
+__device__ __forceinline__ float dpp_sel(float a, float b) {  // lanes of the banks in BANK take b
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, a), __builtin_bit_cast(int, b), 0xE4, 0xF, BANK, false));
+}
+__device__ __forceinline__ float butterfly32(float (&v)[32], int lane) {
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    float a = v[q], b = v[q + 16];
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    v[q] = a + b;   // even rows: index q over lanes {l, l+16}; odd rows: index q + 16
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const float ta = v[q] + dpp_mov<0x128>(v[q]);          // row_ror:8  (lane ^ 8)
+    const float tb = v[q + 8] + dpp_mov<0x128>(v[q + 8]);
+    v[q] = dpp_sel<0xC>(ta, tb);                            // lanes with (lane & 8) keep index q + 8
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float ta = v[q] + dpp_mov<0x141>(v[q]);          // row_half_mirror (pairs lane l with 7 - l)
+    const float tb = v[q + 4] + dpp_mov<0x141>(v[q + 4]);
+    v[q] = dpp_sel<0xA>(ta, tb);                            // lanes with (lane & 4) keep index q + 4
+  }
+  const bool b2 = (lane & 2) != 0, b1 = (lane & 1) != 0;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const float ta = v[q] + dpp_mov<0x4E>(v[q]);           // quad_perm [2,3,0,1]
+    const float tb = v[q + 2] + dpp_mov<0x4E>(v[q + 2]);
+    v[q] = b2 ? tb : ta;
+  }
+  const float ta = v[0] + dpp_mov<0xB1>(v[0]);             // quad_perm [1,0,3,2]
+  const float tb = v[1] + dpp_mov<0xB1>(v[1]);
+  return b1 ? tb : ta;
+}
+
+struct Unit {  // one build unit in flight: 8 columns of one row of one MLP
+  f32x4 p0, p1, q0, q1;
+};
+// table rows through a buffer descriptor: voffset = byte offset of the row, soffset = column offset
+__device__ __forceinline__ void unit_load(Unit& u, rsrc_t tab, unsigned vdst, unsigned vsrc, unsigned sP, unsigned sQ) {
+  u.p0 = ldbuf_f32x4(tab, vdst, sP);
+  u.p1 = ldbuf_f32x4(tab, vdst + 16, sP);
+  u.q0 = ldbuf_f32x4(tab, vsrc, sQ);
+  u.q1 = ldbuf_f32x4(tab, vsrc + 16, sQ);
+}
+__device__ __forceinline__ void unit_finish(const Unit& u, const float* wd, float d2, char* slot) {
+  const f32x4 w0 = *reinterpret_cast<const f32x4*>(wd), w1 = *reinterpret_cast<const f32x4*>(wd + 4);
   bf16x8 o;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    o[j] = (__bf16)silu_f(fmaf(u.w0[j], d2, u.p0[j] + u.q0[j]));
-    o[j + 4] = (__bf16)silu_f(fmaf(u.w1[j], d2, u.p1[j] + u.q1[j]));
+    o[j] = (__bf16)silu_f(fmaf(w0[j], d2, u.p0[j] + u.q0[j]));
+    o[j + 4] = (__bf16)silu_f(fmaf(w1[j], d2, u.p1[j] + u.q1[j]));
   }
   *reinterpret_cast<bf16x8*>(slot) = o;
 }
@@ -62,11 +125,23 @@ __global__ __launch_bounds__(kT2, 2) void edge_kernel_bf16_v2(const EdgeParams p
   float* s_diff = s_d2 + kR;  // [3][R]
   float* s_sval = s_diff + 3 * kR;
   float* s_gate = s_sval + kR;
-  float* s_part = s_gate + kR;  // [8][R]
+  float* s_part = s_gate + kR;   // [8][R] mlp_x partial row sums per wave
+  float* s_partg = s_part + 8 * kR;  // [8][R] gate partial row sums per wave
+  int* s_seg_of_row = reinterpret_cast<int*>(s_partg + 8 * kR);
+  int* s_seg_node = s_seg_of_row + kR;
+  int* s_seg_rs = s_seg_node + kR;
+  int* s_seg_re = s_seg_rs + kR;
+  int* s_seg_mode = s_seg_re + kR;   // 2 = whole node -> agg, 1 / 0 = partial slot of this tile
+  int* s_misc = s_seg_mode + kR;     // [0] = number of segments in the tile
+  float* s_gseg = reinterpret_cast<float*>(s_misc + kR);  // [kMaxSegFast][R] gate * [row in segment]
   char* s_a1 = smem + v2_small_bytes();  // [x0, x1, m0, m1]
   float* s_msg = reinterpret_cast<float*>(s_a1 + 4 * kA1);
+  // the d^2 weight columns live in the (not yet used) message tile during the K-loop
+  float* s_wdx = s_msg;
+  float* s_wdm = s_msg + p.WxP;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, hh = lane >> 5;
   const int tile = xcd_tile(blockIdx.x, gridDim.x);
   const int e0 = tile * kR;
@@ -87,29 +162,35 @@ __global__ __launch_bounds__(kT2, 2) void edge_kernel_bf16_v2(const EdgeParams p
     s_diff[tid] = dx; s_diff[kR + tid] = dy; s_diff[2 * kR + tid] = dz;
     const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);  // norm(...)**2 as in the reference (:56)
     s_d2[tid] = nrm * nrm;
+    // segments = runs of equal receiving node (CSR order); tid < 64 is exactly wave 0
+    const int dprev = __shfl_up(d, 1), dnext = __shfl_down(d, 1);
+    const bool valid = tid < nvalid;
+    const bool is_start = valid && (tid == 0 || dprev != d);
+    const bool is_end = valid && (tid == nvalid - 1 || dnext != d);
+    const unsigned long long starts = __ballot(is_start);
+    const int seg = __popcll(starts & ((2ull << tid) - 1ull)) - 1;
+    s_seg_of_row[tid] = valid ? seg : -1;
+    if (is_start) { s_seg_node[seg] = d; s_seg_rs[seg] = tid; }
+    if (is_end) s_seg_re[seg] = tid;
+    if (tid == 0) s_misc[0] = __popcll(starts);
   }
+  for (int i = tid; i < p.WxP; i += kT2) { s_wdx[i] = p.wdx[i]; s_wdm[i] = p.wdm[i]; }
   __syncthreads();
 
   // ---- fused K-loop ----
   const int KP = p.WxP;            // == p.WmP (checked on the host)
   const int NC = KP / kKC, KS = KP / 16;
   const int brow = tid >> 3, kg = tid & 7;   // build unit of this thread
-  const float* trow_d = p.table + (size_t)s_dst[brow] * p.TC;
-  const float* trow_s = p.table + (size_t)s_src[brow] * p.TC;
+  const rsrc_t rs_tab = make_rsrc(p.table, (p.dbg & 2) ? 0u : (unsigned)((size_t)p.N * p.TC * 4));
+  const rsrc_t rs_wx = make_rsrc(p.w2x, (p.dbg & 1) ? 0u : (unsigned)((size_t)KP * KP * 2));
+  const rsrc_t rs_wm = make_rsrc(p.w2m, (p.dbg & 1) ? 0u : (unsigned)((size_t)p.MP * KP * 2));
+  const unsigned vdst = (unsigned)s_dst[brow] * (unsigned)p.TC * 4u + (unsigned)kg * 32u;
+  const unsigned vsrc = (unsigned)s_src[brow] * (unsigned)p.TC * 4u + (unsigned)kg * 32u;
   const float d2r = s_d2[brow];
-  const int offPx = 0, offQx = p.WxP, offPm = 2 * p.WxP, offQm = 2 * p.WxP + p.WmP;
+  const unsigned offPx = 0, offQx = p.WxP * 4u, offPm = 2u * p.WxP * 4u, offQm = (2u * p.WxP + p.WmP) * 4u;
   char* slot_base = s_a1 + ((size_t)kg * kRPAD + brow) * 16;  // + buffer offset
-
-  const bf16x8* wbx[CBX];
-  const bf16x8* wbm[CBM];
-  {
-    const bf16x8* w2x = reinterpret_cast<const bf16x8*>(p.w2x);
-    const bf16x8* w2m = reinterpret_cast<const bf16x8*>(p.w2m);
-#pragma unroll
-    for (int cb = 0; cb < CBX; ++cb) wbx[cb] = w2x + ((size_t)(wave * CBX + cb) * KS) * 64 + lane;
-#pragma unroll
-    for (int cb = 0; cb < CBM; ++cb) wbm[cb] = w2m + ((size_t)(wave * CBM + cb) * KS) * 64 + lane;
-  }
+  const unsigned lane16 = lane * 16u;
+  const unsigned wx0 = (unsigned)(wave * CBX) * KS * 1024u, wm0 = (unsigned)(wave * CBM) * KS * 1024u;  // scalar
 
   f32x16 accx[kRB][CBX], accm[kRB][CBM];
 #pragma unroll
@@ -126,34 +207,34 @@ __global__ __launch_bounds__(kT2, 2) void edge_kernel_bf16_v2(const EdgeParams p
 
   {  // chunk 0
     Unit u;
-    unit_load(u, trow_d + offPx, trow_s + offQx, p.wdx, kg * 8);
-    unit_finish(u, d2r, slot_base);
-    unit_load(u, trow_d + offPm, trow_s + offQm, p.wdm, kg * 8);
-    unit_finish(u, d2r, slot_base + 2 * kA1);
+    unit_load(u, rs_tab, vdst, vsrc, offPx, offQx);
+    unit_finish(u, s_wdx + kg * 8, d2r, slot_base);
+    unit_load(u, rs_tab, vdst, vsrc, offPm, offQm);
+    unit_finish(u, s_wdm + kg * 8, d2r, slot_base + 2 * kA1);
   }
   bf16x8 bx[CBX], bm[CBM], bxn[CBX], bmn[CBM];
 #pragma unroll
-  for (int cb = 0; cb < CBX; ++cb) bx[cb] = wbx[cb][0];
+  for (int cb = 0; cb < CBX; ++cb) bx[cb] = ldbuf_bf16x8(rs_wx, lane16, wx0 + (unsigned)cb * KS * 1024u);
 #pragma unroll
-  for (int cb = 0; cb < CBM; ++cb) bm[cb] = wbm[cb][0];
+  for (int cb = 0; cb < CBM; ++cb) bm[cb] = ldbuf_bf16x8(rs_wm, lane16, wm0 + (unsigned)cb * KS * 1024u);
   __syncthreads();
 
-  for (int c = 0; c < NC; ++c) {
+  auto chunk = [&](const int c, auto more_tag) {
+    constexpr bool MORE = decltype(more_tag)::value;
     const char* curx = s_a1 + (size_t)(c & 1) * kA1;
     const char* curm = s_a1 + (size_t)(2 + (c & 1)) * kA1;
     char* nslot = slot_base + (size_t)((c + 1) & 1) * kA1;
-    const bool more = c + 1 < NC;
-    const int k0n = (c + 1) * kKC + kg * 8;
+    const unsigned kb = (unsigned)(c + 1) * kKC * 4u;   // byte offset of the next chunk's columns
     Unit u;
-    if (more) unit_load(u, trow_d + offPx, trow_s + offQx, p.wdx, k0n);
+    if (MORE) unit_load(u, rs_tab, vdst, vsrc, offPx + kb, offQx + kb);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int ks = c * 4 + s;
-      const int ksn = ks + 1 < KS ? ks + 1 : ks;
+      const unsigned ksn = (unsigned)((!MORE && s == 3) ? ks : ks + 1) * 1024u;
 #pragma unroll
-      for (int cb = 0; cb < CBX; ++cb) bxn[cb] = wbx[cb][(size_t)ksn * 64];
+      for (int cb = 0; cb < CBX; ++cb) bxn[cb] = ldbuf_bf16x8(rs_wx, lane16, wx0 + (unsigned)cb * KS * 1024u + ksn);
 #pragma unroll
-      for (int cb = 0; cb < CBM; ++cb) bmn[cb] = wbm[cb][(size_t)ksn * 64];
+      for (int cb = 0; cb < CBM; ++cb) bmn[cb] = ldbuf_bf16x8(rs_wm, lane16, wm0 + (unsigned)cb * KS * 1024u + ksn);
       bf16x8 a[kRB];
 #pragma unroll
       for (int rb = 0; rb < kRB; ++rb)
@@ -171,26 +252,54 @@ __global__ __launch_bounds__(kT2, 2) void edge_kernel_bf16_v2(const EdgeParams p
 #pragma unroll
         for (int cb = 0; cb < CBM; ++cb)
           accm[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rb], bm[cb], accm[rb][cb], 0, 0, 0);
-      if (s == 1 && more) {
-        unit_finish(u, d2r, nslot);
-        unit_load(u, trow_d + offPm, trow_s + offQm, p.wdm, k0n);
+      if (MORE && s == 1) {
+        unit_finish(u, s_wdx + (c + 1) * kKC + kg * 8, d2r, nslot);
+        unit_load(u, rs_tab, vdst, vsrc, offPm + kb, offQm + kb);
       }
-      if (s == 3 && more) unit_finish(u, d2r, nslot + 2 * kA1);
+      if (MORE && s == 3) unit_finish(u, s_wdm + (c + 1) * kKC + kg * 8, d2r, nslot + 2 * kA1);
 #pragma unroll
       for (int cb = 0; cb < CBX; ++cb) bx[cb] = bxn[cb];
 #pragma unroll
       for (int cb = 0; cb < CBM; ++cb) bm[cb] = bmn[cb];
     }
     __syncthreads();
+  };
+  if (p.dbg & 8) {  // timing experiment: K-loop without the activation build
+    for (int c = 0; c < NC; ++c) chunk(c, std::false_type{});
+  } else {
+    for (int c = 0; c < NC - 1; ++c) chunk(c, std::true_type{});
+    chunk(NC - 1, std::false_type{});
+  }
+  if (p.dbg & 4) {  // timing experiment: stop after the K-loop (keep the accumulators alive)
+    float keep = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < kRB; ++rb) {
+#pragma unroll
+      for (int cb = 0; cb < CBX; ++cb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) keep += accx[rb][cb][i];
+#pragma unroll
+      for (int cb = 0; cb < CBM; ++cb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) keep += accm[rb][cb][i];
+    }
+    if (keep == 1.2345e-30f) p.agg_x[tid] = keep;
+    return;
   }
 
+  // ---- segment bookkeeping (one thread per segment): where does each segment's sum go? ----
+  const int S = s_misc[0];
+  if (tid < S) {
+    const int n = s_seg_node[tid];
+    const bool first = (e0 + s_seg_rs[tid]) == p.row_ptr[n];
+    const bool last = (e0 + s_seg_re[tid] + 1) == p.row_ptr[n + 1];
+    s_seg_mode[tid] = (first && last) ? 2 : (first ? 1 : 0);
+  }
   // ---- mlp_x epilogue: s[row] = b3 + sum_n w3[n] * SiLU(acc + b2[n]) ----
   {
-    float part[kRB][16];
+    float part[32];
 #pragma unroll
-    for (int rb = 0; rb < kRB; ++rb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) part[rb][i] = 0.f;
+    for (int q = 0; q < 32; ++q) part[q] = 0.f;
 #pragma unroll
     for (int cb = 0; cb < CBX; ++cb) {
       const int n = 32 * (wave * CBX + cb) + r;
@@ -198,77 +307,103 @@ __global__ __launch_bounds__(kT2, 2) void edge_kernel_bf16_v2(const EdgeParams p
 #pragma unroll
       for (int rb = 0; rb < kRB; ++rb)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) part[rb][i] = fmaf(w, silu_f(accx[rb][cb][i] + b), part[rb][i]);
+        for (int i = 0; i < 16; ++i) part[rb * 16 + i] = fmaf(w, silu_f(accx[rb][cb][i] + b), part[rb * 16 + i]);
     }
+    const float tot = butterfly32(part, lane);   // row-sum of value index q = r over this wave's columns
+    s_part[wave * kR + 32 * (r >> 4) + acc_row(r & 15, lane)] = tot;
+  }
+  // ---- mlp_m epilogue: m = SiLU(acc + b2), gate = sigmoid(wa . m + ba) (:31-34, :59-60) ----
+  static_assert(CBM == 1, "in-register message epilogue assumes one 32-column block per wave");
+  float mval[32];
+  const int ncol = 32 * wave + r;   // message column of this lane
+  {
+    const float b = p.b2m[ncol], wa = p.wa[ncol];
+    float g[32];
 #pragma unroll
     for (int rb = 0; rb < kRB; ++rb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        float v = part[rb][i];
-        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
-        v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
-        if (r == 0) s_part[wave * kR + 32 * rb + acc_row(i, lane)] = v;
+        mval[rb * 16 + i] = silu_f(accm[rb][0][i] + b);
+        g[rb * 16 + i] = wa * mval[rb * 16 + i];
       }
-  }
-  // ---- mlp_m epilogue: m = SiLU(acc + b2) into the LDS message tile ----
-  {
-    const int ld = p.MP + 1;
-#pragma unroll
-    for (int cb = 0; cb < CBM; ++cb) {
-      const int n = 32 * (wave * CBM + cb) + r;
-      const float b = p.b2m[n];
-#pragma unroll
-      for (int rb = 0; rb < kRB; ++rb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s_msg[(32 * rb + acc_row(i, lane)) * ld + n] = silu_f(accm[rb][cb][i] + b);
-    }
+    const float tot = butterfly32(g, lane);
+    s_partg[wave * kR + 32 * (r >> 4) + acc_row(r & 15, lane)] = tot;
   }
   __syncthreads();
   if (tid < kR) {
-    float v = p.scal[0];
+    float v = p.scal[0], gsum = p.scal[1];
 #pragma unroll
-    for (int w = 0; w < 8; ++w) v += s_part[w * kR + tid];
+    for (int w = 0; w < 8; ++w) { v += s_part[w * kR + tid]; gsum += s_partg[w * kR + tid]; }
     s_sval[tid] = v;
-  }
-  {  // attention gate, 8 threads per row
-    const int row = tid >> 3, sub = tid & 7, ld = p.MP + 1;
-    float s = 0.f;
-    for (int c = sub; c < p.MP; c += 8) s = fmaf(p.wa[c], s_msg[row * ld + c], s);
-    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
-    if (sub == 0) s_gate[row] = sigmoid_f(s + p.scal[1]);
+    s_gate[tid] = sigmoid_f(gsum);
   }
   __syncthreads();
 
-  // ---- segment sums per receiving node (same rule as the fp32 kernel) ----
-  auto flush = [&](int n, int rs, int re, float v, float* agg, float* part, int ld, int c) {
-    const bool first = (e0 + rs) == p.row_ptr[n];
-    const bool last = (e0 + re + 1) == p.row_ptr[n + 1];
-    if (first && last) agg[(size_t)n * ld + c] = v;
-    else part[((size_t)tile * 2 + (first ? 1 : 0)) * ld + c] = v;
-  };
-  const int ld = p.MP + 1;
-  for (int c = tid; c < p.MP; c += kT2) {
-    float sum = 0.f;
-    int rs = 0;
-    for (int rr = 0; rr < nvalid; ++rr) {
-      sum = fmaf(s_msg[rr * ld + c], s_gate[rr], sum);
-      if (rr == nvalid - 1 || s_dst[rr + 1] != s_dst[rr]) {
-        flush(s_dst[rr], rs, rr, sum, p.agg_m, p.part_m, p.MP, c);
-        sum = 0.f;
-        rs = rr + 1;
+  // ---- segment sums per receiving node (aggr='sum' into edge_index[0], :10-11) ----
+  // A segment holding all edges of its node is stored directly; otherwise it goes to the tile's partial
+  // slot (1 = holds the node's first edge, 0 = continues a node begun in an earlier tile) and node_post
+  // adds the partials in tile order: fixed summation order, no atomics.
+  if (S <= kMaxSegFast) {
+    {  // gate weight of every row for every segment (0 outside the segment and for padding rows)
+      const int seg = tid >> 6, row = tid & 63;
+      if (seg < S) s_gseg[seg * kR + row] = (s_seg_of_row[row] == seg) ? s_gate[row] : 0.f;
+    }
+    __syncthreads();
+    for (int seg = 0; seg < S; ++seg) {
+      const float* gw = s_gseg + seg * kR + 4 * hh;
+      float v = 0.f;
+#pragma unroll
+      for (int rb = 0; rb < kRB; ++rb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v = fmaf(mval[rb * 16 + i], gw[32 * rb + (i & 3) + 8 * (i >> 2)], v);
+      v += __shfl_xor(v, 32);
+      if (hh == 0) {
+        const int mode = s_seg_mode[seg];
+        float* dstp = mode == 2 ? p.agg_m + (size_t)s_seg_node[seg] * p.MP : p.part_m + ((size_t)tile * 2 + mode) * p.MP;
+        dstp[ncol] = v;
       }
     }
-  }
-  if (tid >= 448 && tid < 451) {  // coordinate messages on an otherwise idle wave
-    const int d = tid - 448;
-    float sum = 0.f;
-    int rs = 0;
-    for (int rr = 0; rr < nvalid; ++rr) {
-      sum = fmaf(s_diff[d * kR + rr], s_sval[rr], sum);
-      if (rr == nvalid - 1 || s_dst[rr + 1] != s_dst[rr]) {
-        flush(s_dst[rr], rs, rr, sum, p.agg_x, p.part_x, 4, d);
-        sum = 0.f;
-        rs = rr + 1;
+    if (wave == 7) {  // coordinate messages (x_i - x_j) * s_ij; 1/(G+1) is applied in node_post
+      const int row = lane, myseg = s_seg_of_row[row];
+      const float sv = s_sval[row];
+      const float c0 = s_diff[row] * sv, c1 = s_diff[kR + row] * sv, c2 = s_diff[2 * kR + row] * sv;
+      for (int seg = 0; seg < S; ++seg) {
+        const bool in = myseg == seg;
+        float a0 = in ? c0 : 0.f, a1 = in ? c1 : 0.f, a2 = in ? c2 : 0.f;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { a0 += __shfl_xor(a0, m); a1 += __shfl_xor(a1, m); a2 += __shfl_xor(a2, m); }
+        if (lane < 3) {
+          const int mode = s_seg_mode[seg];
+          float* dstp = mode == 2 ? p.agg_x + (size_t)s_seg_node[seg] * 4 : p.part_x + ((size_t)tile * 2 + mode) * 4;
+          dstp[lane] = lane == 0 ? a0 : (lane == 1 ? a1 : a2);
+        }
+      }
+    }
+  } else {
+    // many short segments (sparse graphs): stage the gated messages in LDS, one thread per column
+    const int ld = p.MP + 1;
+#pragma unroll
+    for (int rb = 0; rb < kRB; ++rb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = 32 * rb + acc_row(i, lane);
+        s_msg[row * ld + ncol] = mval[rb * 16 + i] * s_gate[row];
+      }
+    __syncthreads();
+    for (int c = tid; c < p.MP + 3; c += kT2) {
+      const bool isx = c >= p.MP;   // three extra "columns" carry the coordinate messages
+      const int d = c - p.MP;
+      for (int seg = 0; seg < S; ++seg) {
+        const int rs = s_seg_rs[seg], re = s_seg_re[seg], mode = s_seg_mode[seg];
+        float sum = 0.f;
+        for (int rr = rs; rr <= re; ++rr) sum += isx ? s_diff[d * kR + rr] * s_sval[rr] : s_msg[rr * ld + c];
+        if (isx) {
+          float* dstp = mode == 2 ? p.agg_x + (size_t)s_seg_node[seg] * 4 : p.part_x + ((size_t)tile * 2 + mode) * 4;
+          dstp[d] = sum;
+        } else {
+          float* dstp = mode == 2 ? p.agg_m + (size_t)s_seg_node[seg] * p.MP : p.part_m + ((size_t)tile * 2 + mode) * p.MP;
+          dstp[c] = sum;
+        }
       }
     }
   }
@@ -292,7 +427,7 @@ int launch_v2(const EdgeParams& p, int tiles, hipStream_t st) {
 bool edge_bf16_v2_supported(const EdgeParams& p) {
   const int cbx = p.WxP / 256;
   return p.WxP == p.WmP && p.WxP % 256 == 0 && (cbx == 1 || cbx == 2 || cbx == 4) && p.MP == 256 &&
-         v2_smem_bytes(p.MP) <= 160 * 1024;
+         v2_smem_bytes(p.MP) <= 160 * 1024 && (size_t)p.N * p.TC * 4 < ((size_t)1 << 32);
 }
 
 int launch_edge_bf16_v2(const EdgeParams& p, int tiles, hipStream_t st) {

@@ -18,6 +18,7 @@
 // v_mfma_f32_32x32x16_bf16 with fp32 accumulation for the two big per-edge GEMMs.  Geometry (d^2,
 // coordinate differences), SiLU/sigmoid, all segment sums and the node MLP stay fp32 in both.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "common.h"
 #include "kernels.h"
@@ -727,6 +728,10 @@ int launch_layer(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_scop
     p.w2x = prec == EGNN_PREC_BF16 ? lp.w2x_bf16 : (const void*)lp.w2x_f32;
     p.w2m = prec == EGNN_PREC_BF16 ? lp.w2m_bf16 : (const void*)lp.w2m_f32;
     p.agg_m = c->agg_m; p.agg_x = c->agg_x; p.part_m = c->part_m; p.part_x = c->part_x;
+    {
+      static const int dbg = getenv("EGNN_DEBUG") ? atoi(getenv("EGNN_DEBUG")) : 0;
+      p.dbg = dbg;
+    }
     const int tiles = (E + R - 1) / R;
     const size_t smem = edge_smem_bytes(R, c->MP);
     prof_begin(c, st, 0);

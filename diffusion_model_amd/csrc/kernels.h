@@ -37,6 +37,7 @@ struct EdgeParams {
   const float *wdx, *wdm, *b2x, *w3x, *b2m, *wa, *scal;
   const void *w2x, *w2m;
   float *agg_m, *agg_x, *part_m, *part_x;
+  int dbg;  // timing experiments only (EGNN_DEBUG): bit0 drop weight loads, bit1 drop table loads
 };
 
 // layout helper used by both host (size) and device (carve): ints/floats 12*R*4 bytes, then 2 A1
