@@ -8,6 +8,7 @@ from .graph import GraphPlan, fully_connected_edge_index  # noqa: F401
 from .sampler import DeviceSampler, generate  # noqa: F401
 from .preprocessor import SpectrumCompressor  # noqa: F401
 from .snr import GammaNetwork, PositiveLinear  # noqa: F401
+from .training import GradAllReducer, diffuse_as_batch, train_step, training_loss  # noqa: F401
 
 __all__ = ["EGCL", "EquivariantGNN", "E3DiffusionProcess", "remove_mean", "GraphPlan",
            "fully_connected_edge_index", "DeviceSampler", "generate", "SpectrumCompressor",

@@ -1,0 +1,121 @@
+"""Training path: gradients of the HIP-forward / library-GEMM-backward EGNN against the oracle's
+autograd (GPU), and the data-parallel gradient exchange with gloo on CPU (world_size 2)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import diffusion_model_amd as dma
+from oracle.diffusion_ref import DiffusionRef
+from oracle.egnn_ref import fully_connected_edge_index
+from oracle.sampler_ref import training_loss as oracle_training_loss
+from tests._util import dims_for, rel_err
+
+
+def _problem(seed=0, sizes=(6, 4, 7), H=36, A=2):
+    g = torch.Generator().manual_seed(seed)
+    n = sum(sizes)
+    pos0 = torch.randn(n, 3, generator=g)
+    x0 = torch.nn.functional.one_hot(torch.randint(0, A, (n,), generator=g), A).float()
+    cond = torch.randn(n, H - A - 1, generator=g)
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    ei = fully_connected_edge_index(list(sizes))
+    noise_pos, noise_h = torch.randn(n, 3, generator=g), torch.randn(n, A, generator=g)
+    times = [17, 3, 40][: len(sizes)]
+    return pos0, x0, cond, batch, ei, noise_pos, noise_h, times
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("norm_scope", ["graph", "call"])
+def test_gradients_match_oracle_autograd(norm_scope):
+    H, A, T = 36, 2, 50
+    d = dims_for(H, 128, 256, 256, 256)
+    torch.manual_seed(5)
+    net = dma.EquivariantGNN(2, **d)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    pos0, x0, cond, batch, ei, npos, nh, times = _problem()
+    ref = DiffusionRef(1e-5, 2.0, T)
+    ptr = torch.tensor([0, 6, 10, 17])
+    loss_ref, ex_ref, eh_ref, _, _ = oracle_training_loss(sd, ref, pos0, x0, cond, ei, batch, times, npos.clone(), nh.clone(),
+                                                         atom_type_size=A, norm_scope=norm_scope, graph_ptr=ptr)
+    loss_ref.backward()
+    dev = "cuda"
+    net.to(dev).train()
+    net.precision, net.norm_scope = "fp32", norm_scope
+    proc = dma.E3DiffusionProcess(1e-5, 2.0, T)
+    noised = dma.diffuse_as_batch(pos0.to(dev), x0.to(dev), batch.to(dev), proc, times=times,
+                                  noise_pos=npos.to(dev), noise_h=nh.to(dev))
+    loss, ex, eh = dma.training_loss(net, ei.to(dev), batch.to(dev), noised, cond.to(dev), A)
+    loss.backward()
+    assert abs(float(loss) - float(loss_ref)) <= 1e-4 * abs(float(loss_ref))
+    assert rel_err(ex.detach().cpu(), ex_ref.detach()) <= 1e-4 and rel_err(eh.detach().cpu(), eh_ref.detach()) <= 1e-4
+    for k, p in net.named_parameters():
+        assert p.grad is not None, k
+        assert rel_err(p.grad.cpu(), sd[k].grad) <= 2e-3, k
+
+
+@pytest.mark.gpu
+def test_train_step_reduces_loss():
+    from types import SimpleNamespace
+    H, A, T = 36, 2, 50
+    params = dict(conditional=True, to_compress_spectrum=True, give_exO=True, atom_type_size=A)
+    d = dims_for(H, 128, 256, 256, 256)
+    torch.manual_seed(1)
+    dev = "cuda"
+    nn_dict = {"egnn": dma.EquivariantGNN(2, **d).to(dev), "spectrum_compressor": dma.SpectrumCompressor(200, [150, 100, 50], 32).to(dev)}
+    nn_dict["egnn"].norm_scope = "graph"
+    pos0, x0, _, batch, ei, *_ = _problem()
+    spec = torch.zeros(pos0.shape[0], 200)
+    spec[[0, 6, 10]] = torch.rand(3, 200)
+    exo = torch.zeros(pos0.shape[0], 1)
+    exo[[0, 6, 10]] = 1
+    data = SimpleNamespace(pos=pos0.to(dev), x=x0.to(dev), batch=batch.to(dev), edge_index=ei.to(dev),
+                           spectrum=spec.to(dev), exO=exo.to(dev))
+    proc = dma.E3DiffusionProcess(1e-5, 2.0, T)
+    opt = torch.optim.Adam(list(nn_dict["egnn"].parameters()) + list(nn_dict["spectrum_compressor"].parameters()), lr=1e-4)
+    losses = [float(dma.train_step(nn_dict, data, params, proc, opt, times=[20, 20, 20])) for _ in range(12)]
+    assert all(l == l for l in losses)
+    assert min(losses[-3:]) < losses[0]
+    assert all(p.grad is not None for p in nn_dict["spectrum_compressor"].parameters())
+
+
+# ---------------- data-parallel exchange, gloo on CPU ----------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _ddp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.SiLU(), torch.nn.Linear(7, 3))
+    g = torch.Generator().manual_seed(42)
+    x_all, y_all = torch.randn(8, 5, generator=g), torch.randn(8, 3, generator=g)      # 8 "graphs"
+    shard = slice(rank * 3, rank * 3 + 3) if rank == 0 else slice(3, 8)                   # uneven shards: 3 + 5
+    n_global = dma.training.global_graph_count(x_all[shard].shape[0], "cpu")
+    loss = ((model(x_all[shard]) - y_all[shard]) ** 2).sum() / n_global
+    loss.backward()
+    dma.GradAllReducer([model]).reduce()
+    if rank == 0:
+        ref = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.SiLU(), torch.nn.Linear(7, 3))
+        ref.load_state_dict(model.state_dict())
+        (((ref(x_all) - y_all) ** 2).sum() / 8).backward()
+        errs = [float((a.grad - b.grad).abs().max()) for a, b in zip(model.parameters(), ref.parameters())]
+        torch.save({"n_global": n_global, "errs": errs}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world_size_2_gloo(tmp_path):
+    out = str(tmp_path / "r.pt")
+    mp.spawn(_ddp_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    res = torch.load(out, weights_only=True)
+    assert res["n_global"] == 8
+    assert max(res["errs"]) < 1e-6
