@@ -50,9 +50,11 @@ def cpu_baseline(sd, H, A, T, n_atoms, target_seconds=15.0):
     from oracle.egnn_ref import egnn_forward, fully_connected_edge_index
     B = 4
     try:
-        cores = len(os.sched_getaffinity(0))
+        avail = len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
+        avail = os.cpu_count() or 1
+    # a 1-GPU box's CPU share is 16 cores; more torch threads than that only oversubscribes the host
+    cores = int(os.environ.get("BENCH_CPU_THREADS", min(avail, 16)))
     torch.set_num_threads(cores)
     ref = DiffusionRef(1e-5, 2.0, T)
     g = torch.Generator().manual_seed(0)
