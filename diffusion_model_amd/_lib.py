@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libegnn_amd.so")
+LIB_PATH = os.environ.get("EGNN_LIB", os.path.join(_HERE, "libegnn_amd.so"))   # EGNN_LIB: timing-experiment builds
 
 PREC_F32, PREC_BF16 = 0, 1
 NORM_CALL, NORM_GRAPH = 0, 1
@@ -35,6 +35,7 @@ SIGNATURES = {
     "egnn_sampler_run": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "egnn_sampler_final": (_i, [_vp, _vp, _i, _i] + [_vp] * 5),
     "egnn_sampler_state": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(_i)]),
+    "egnn_debug_stamps": (_i, [_vp, C.POINTER(C.c_uint64)]),
     "egnn_profile_enable": (_i, [_vp, _i]),
     "egnn_profile_read": (_i, [_vp, _fp, C.POINTER(_i), _fp]),
 }

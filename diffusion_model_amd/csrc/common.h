@@ -89,6 +89,7 @@ struct egnn_ctx {
   float* part_x = nullptr;   // [tiles][2][4]
   float* node_d2 = nullptr;  // [N]
   float* gscale = nullptr;   // [B] 1/(G+1)
+  unsigned long long* stamps = nullptr;  // [2 kernels][8 waves][32 chunks][4] diagnostic time stamps
   float* h_tmp[2] = {nullptr, nullptr};  // [N][H] ping-pong between layers
   float* x_tmp[2] = {nullptr, nullptr};  // [N][3]
   egnn::Sampler smp;

@@ -1,0 +1,468 @@
+// Fused per-edge kernels, bf16 MFMA, 128-edge tiles with the output columns split over workgroups (gfx950).
+//
+// Why: at a 64-edge tile every CU must stream 40 KiB of weight fragments per 640 MFMA-cycles = 64 B/clk,
+// the per-CU L2 fill rate, and the tile cannot grow because the fp32 accumulators of all 1280 output
+// columns (mlp_x.2: 1024, mlp_m.2: 256) already fill the register file.  Here one 128-edge tile is
+// processed by three workgroups, each holding only a slice of the columns:
+//
+//     X half 0 / X half 1 : mlp_x (EquivariantGraphNeuralNetwork.py:19-25, :62-65) columns [0,512) / [512,1024)
+//     M                   : mlp_m + attention gate (:13-18, :31-34, :55-61), all 256 columns
+//
+// Every weight fragment now feeds 4 row blocks (128 edges) instead of 2, halving the weight bytes per
+// MFMA; each workgroup rebuilds the SiLU(P[dst] + Q[src] + wd*d2) activations it needs (mlp_x's are
+// built twice -- the price of not exchanging them between workgroups).  s_ij is linear in the column
+// halves, so the two X workgroups write separate coordinate sums that node_post adds: no inter-workgroup
+// communication, bitwise deterministic.
+//
+// Workgroup = 8 wave64 (2 per SIMD), wave w owns 32*CB columns; per 16-deep k-step: 4 A fragments from
+// the double-buffered LDS activation chunk, CB B fragments straight from the packed weights, 4*CB MFMAs.
+#include <type_traits>
+
+#include "kernels.h"
+
+namespace egnn {
+
+namespace {
+
+constexpr int kT3 = 512;
+constexpr int kR3 = 128, kRB3 = 4, kRPAD3 = kR3 + 1;
+constexpr int kKC3 = 64;
+constexpr size_t kA1_3 = (size_t)8 * kRPAD3 * 16;  // one activation chunk [8 k-groups][129][8 bf16]
+constexpr int kSegFast3 = 8;
+
+// LDS carve (bytes)
+constexpr size_t kOffDst = 0;                                  // int[R]
+constexpr size_t kOffSrc = kOffDst + kR3 * 4;                  // int[R]
+constexpr size_t kOffD2 = kOffSrc + kR3 * 4;                   // float[R]
+constexpr size_t kOffDiff = kOffD2 + kR3 * 4;                  // float[3][R]
+constexpr size_t kOffVal = kOffDiff + 3 * kR3 * 4;             // float[R]   s_ij (X) / gate (M)
+constexpr size_t kOffPart = kOffVal + kR3 * 4;                 // float[8][R] per-wave partial row sums
+constexpr size_t kOffSegRow = kOffPart + 8 * kR3 * 4;          // int[R]
+constexpr size_t kOffSegNode = kOffSegRow + kR3 * 4;           // int[R]
+constexpr size_t kOffSegRs = kOffSegNode + kR3 * 4;            // int[R]
+constexpr size_t kOffSegRe = kOffSegRs + kR3 * 4;              // int[R]
+constexpr size_t kOffSegMode = kOffSegRe + kR3 * 4;            // int[R]
+constexpr size_t kOffMisc = kOffSegMode + kR3 * 4;             // int[16]
+constexpr size_t kOffGseg = kOffMisc + 64;                     // float[kSegFast3][R]
+constexpr size_t kOffA1 = kOffGseg + kSegFast3 * kR3 * 4;      // 2 activation chunks, then wd[KP]
+__host__ __device__ inline size_t v3_smem_bytes(int KP, int MP, bool is_m) {
+  const size_t loop = 2 * kA1_3 + (size_t)KP * 4;
+  const size_t msg = is_m ? (size_t)kR3 * (MP + 1) * 4 : 0;   // fallback message tile aliases the loop buffers
+  return kOffA1 + (loop > msg ? loop : msg);
+}
+
+template <int CB, bool IS_M>
+__global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* s_dst = reinterpret_cast<int*>(smem + kOffDst);
+  int* s_src = reinterpret_cast<int*>(smem + kOffSrc);
+  float* s_d2 = reinterpret_cast<float*>(smem + kOffD2);
+  float* s_diff = reinterpret_cast<float*>(smem + kOffDiff);
+  float* s_val = reinterpret_cast<float*>(smem + kOffVal);
+  float* s_part = reinterpret_cast<float*>(smem + kOffPart);
+  int* s_seg_of_row = reinterpret_cast<int*>(smem + kOffSegRow);
+  int* s_seg_node = reinterpret_cast<int*>(smem + kOffSegNode);
+  int* s_seg_rs = reinterpret_cast<int*>(smem + kOffSegRs);
+  int* s_seg_re = reinterpret_cast<int*>(smem + kOffSegRe);
+  int* s_seg_mode = reinterpret_cast<int*>(smem + kOffSegMode);
+  int* s_misc = reinterpret_cast<int*>(smem + kOffMisc);
+  float* s_gseg = reinterpret_cast<float*>(smem + kOffGseg);
+  char* s_a1 = smem + kOffA1;
+  float* s_wd = reinterpret_cast<float*>(s_a1 + 2 * kA1_3);
+  float* s_msg = reinterpret_cast<float*>(s_a1);   // M fallback path only, after the K-loop
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int KP = IS_M ? p.WmP : p.WxP;
+  const int nsplit = IS_M ? 1 : p.WxP / (256 * CB);
+  const int j = xcd_tile(blockIdx.x, gridDim.x);
+  const int tile = j / nsplit, half = j - tile * nsplit;
+  const int e0 = tile * kR3;
+  const int nvalid = min(kR3, p.E - e0);
+
+  // ---- prologue: edge rows, geometry, segment (= receiving node) structure ----
+  if (tid < kR3) {
+    int d = 0, s = 0;
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (tid < nvalid) {
+      d = p.edge_dst[e0 + tid];
+      s = p.edge_src[e0 + tid];
+      dx = p.x[3 * d] - p.x[3 * s];
+      dy = p.x[3 * d + 1] - p.x[3 * s + 1];
+      dz = p.x[3 * d + 2] - p.x[3 * s + 2];
+    }
+    s_dst[tid] = d;
+    s_src[tid] = s;
+    s_diff[tid] = dx; s_diff[kR3 + tid] = dy; s_diff[2 * kR3 + tid] = dz;
+    const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);  // norm(...)**2 as in the reference (:56)
+    s_d2[tid] = nrm * nrm;
+  }
+  {
+    const float* wd = IS_M ? p.wdm : p.wdx;
+    for (int i = tid; i < KP; i += kT3) s_wd[i] = wd[i];
+  }
+  __syncthreads();
+  bool is_start = false, is_end = false;
+  unsigned long long starts = 0;
+  if (tid < kR3) {   // waves 0 and 1
+    const bool valid = tid < nvalid;
+    const int d = s_dst[tid];
+    is_start = valid && (tid == 0 || s_dst[tid - 1] != d);
+    is_end = valid && (tid == nvalid - 1 || s_dst[tid + 1] != d);
+    starts = __ballot(is_start);
+    if (lane == 0) s_misc[1 + wave] = __popcll(starts);
+  }
+  __syncthreads();
+  if (tid < kR3) {
+    const int seg = (wave == 1 ? s_misc[1] : 0) + __popcll(starts & ((2ull << lane) - 1ull)) - 1;
+    s_seg_of_row[tid] = tid < nvalid ? seg : -1;
+    if (is_start) { s_seg_node[seg] = s_dst[tid]; s_seg_rs[seg] = tid; }
+    if (is_end) s_seg_re[seg] = tid;
+    if (tid == 0) s_misc[0] = s_misc[1] + s_misc[2];
+  }
+  __syncthreads();
+  const int S = s_misc[0];
+  if (tid < S) {   // where does each segment's sum go?  (same rule as the other edge kernels)
+    const int n = s_seg_node[tid];
+    const bool first = (e0 + s_seg_rs[tid]) == p.row_ptr[n];
+    const bool last = (e0 + s_seg_re[tid] + 1) == p.row_ptr[n + 1];
+    s_seg_mode[tid] = (first && last) ? 2 : (first ? 1 : 0);
+  }
+
+  // ---- K-loop ----
+  const int NC = KP / kKC3, KS = KP / 16;
+  const int brow = tid >> 3, kg = tid & 7;   // this thread builds rows brow and brow + 64
+  const rsrc_t rs_tab = make_rsrc(p.table, (p.dbg & 2) ? 0u : (unsigned)((size_t)p.N * p.TC * 4));
+  const rsrc_t rs_w = make_rsrc(IS_M ? p.w2m : p.w2x, (p.dbg & 1) ? 0u : (unsigned)((size_t)(IS_M ? p.MP : p.WxP) * KP * 2));
+  const unsigned vdst0 = (unsigned)s_dst[brow] * (unsigned)p.TC * 4u + (unsigned)kg * 32u;
+  const unsigned vsrc0 = (unsigned)s_src[brow] * (unsigned)p.TC * 4u + (unsigned)kg * 32u;
+  const unsigned vdst1 = (unsigned)s_dst[brow + 64] * (unsigned)p.TC * 4u + (unsigned)kg * 32u;
+  const unsigned vsrc1 = (unsigned)s_src[brow + 64] * (unsigned)p.TC * 4u + (unsigned)kg * 32u;
+  const float d2r0 = s_d2[brow], d2r1 = s_d2[brow + 64];
+  const unsigned offP = (IS_M ? 2u * p.WxP : 0u) * 4u, offQ = (IS_M ? 2u * p.WxP + p.WmP : (unsigned)p.WxP) * 4u;
+  char* slot0 = s_a1 + ((size_t)kg * kRPAD3 + brow) * 16;
+  char* slot1 = slot0 + 64 * 16;
+  const unsigned lane16 = lane * 16u;
+  const int colblk0 = half * 8 * CB + wave * CB;   // first 32-column block of this wave
+  const unsigned w0 = (unsigned)colblk0 * KS * 1024u;
+
+  f32x16 acc[kRB3][CB];
+#pragma unroll
+  for (int rb = 0; rb < kRB3; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[rb][cb][i] = 0.f;
+
+  {  // chunk 0
+    Unit u;
+    unit_load(u, rs_tab, vdst0, vsrc0, offP, offQ);
+    unit_finish(u, s_wd + kg * 8, d2r0, slot0);
+    unit_load(u, rs_tab, vdst1, vsrc1, offP, offQ);
+    unit_finish(u, s_wd + kg * 8, d2r1, slot1);
+  }
+  bf16x8 bq[4][CB];   // weight fragments of the 4 k-steps of the current chunk
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) bq[s][cb] = ldbuf_bf16x8(rs_w, lane16, w0 + ((unsigned)cb * KS + s) * 1024u);
+  __syncthreads();
+
+  // matrix phase of chunk c: 4 k-steps x (4 row blocks x CB column blocks)
+  // Operand pipeline of the matrix phase: the weight fragments of k-step s of chunk c+1 are requested right
+  // after the MFMAs of k-step s of chunk c were issued (a whole chunk = 4 k-steps of distance, enough to cover
+  // an L2 round trip under load), the LDS A fragments one k-step ahead.
+  auto mphase = [&](const int c, const bool last) {
+    const char* cur = s_a1 + (size_t)(c & 1) * kA1_3 + ((size_t)hh * kRPAD3 + r) * 16;
+    bf16x8 a[kRB3], an[kRB3];
+#pragma unroll
+    for (int rb = 0; rb < kRB3; ++rb) a[rb] = *reinterpret_cast<const bf16x8*>(cur + (size_t)(32 * rb) * 16);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s < 3) {
+#pragma unroll
+        for (int rb = 0; rb < kRB3; ++rb)
+          an[rb] = *reinterpret_cast<const bf16x8*>(cur + ((size_t)((s + 1) * 2) * kRPAD3 + 32 * rb) * 16);
+      }
+#pragma unroll
+      for (int rb = 0; rb < kRB3; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#ifndef EGNN_EXP_NO_MFMA
+          acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rb], bq[s][cb], acc[rb][cb], 0, 0, 0);
+#else
+          acc[rb][cb][0] += (float)a[rb][0] * (float)bq[s][cb][0];   // timing experiment: no MFMA
+#endif
+      if (!last) {
+        const unsigned ksn = (unsigned)((c + 1) * 4 + s) * 1024u;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) bq[s][cb] = ldbuf_bf16x8(rs_w, lane16, w0 + (unsigned)cb * KS * 1024u + ksn);
+      }
+      if (s < 3) {
+#pragma unroll
+        for (int rb = 0; rb < kRB3; ++rb) a[rb] = an[rb];
+      }
+    }
+  };
+  Unit u0, u1;
+  auto vload = [&](const int c) {   // table rows for the activations of chunk c
+    const unsigned kb = (unsigned)c * kKC3 * 4u;
+    unit_load(u0, rs_tab, vdst0, vsrc0, offP + kb, offQ + kb);
+    unit_load(u1, rs_tab, vdst1, vsrc1, offP + kb, offQ + kb);
+  };
+  auto vfinish = [&](const int c) {  // SiLU + bf16 pack of chunk c into its LDS buffer
+    const size_t nbuf = (size_t)(c & 1) * kA1_3;
+    // vector work wins issue arbitration over the partner wave's MFMAs (which only need 1 slot in 4)
+    __builtin_amdgcn_s_setprio(3);
+    unit_finish(u0, s_wd + c * kKC3 + kg * 8, d2r0, slot0 + nbuf);
+    unit_finish(u1, s_wd + c * kKC3 + kg * 8, d2r1, slot1 + nbuf);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // The two waves that share a SIMD (w and w+4) run the chunk in opposite phase: waves 0-3 multiply chunk c
+  // and then build chunk c+1, waves 4-7 build chunk c+1 first (from table rows requested one chunk earlier)
+  // and then multiply chunk c -- one wave's vector work runs under its partner's matrix work instead of
+  // both alternating in lockstep.  One barrier per chunk either way.
+#ifdef EGNN_EXP_STAMP
+  const bool stamp_wg = blockIdx.x == gridDim.x / 2;
+  unsigned long long* st_base = p.stamps + ((size_t)(IS_M ? 1 : 0) * 8 + wave) * 32 * 4;
+#define STAMP(c, k)                                                                               \
+  do {                                                                                            \
+    unsigned long long t_;                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    if (stamp_wg && lane == 0 && (c) < 32) st_base[(c) * 4 + (k)] = t_;                           \
+  } while (0)
+#else
+#define STAMP(c, k)
+#endif
+#ifdef EGNN_EXP_NO_BUILD
+  for (int c = 0; c < NC; ++c) { mphase(c, c == NC - 1); __syncthreads(); }
+#else
+  // (the steady-state loop bodies are branch-free so that hipcc's waitcnt insertion can keep counted
+  // vmcnt waits across the back edge instead of draining the queue at every control-flow join)
+  if (wave < 4) {
+    for (int c = 0; c < NC - 1; ++c) {
+      STAMP(c, 0);
+      vload(c + 1);
+      __builtin_amdgcn_sched_barrier(0);   // keep the table-row requests ahead of the matrix phase
+      mphase(c, false);
+      STAMP(c, 1);
+      vfinish(c + 1);
+      STAMP(c, 2);
+      __syncthreads();
+      STAMP(c, 3);
+    }
+    mphase(NC - 1, true);
+    __syncthreads();
+  } else {
+    if (NC > 1) vload(1);
+    for (int c = 0; c < NC - 2; ++c) {
+      STAMP(c, 0);
+      vfinish(c + 1);
+      vload(c + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      STAMP(c, 1);
+      mphase(c, false);
+      STAMP(c, 2);
+      __syncthreads();
+      STAMP(c, 3);
+    }
+    if (NC > 1) {
+      vfinish(NC - 1);
+      mphase(NC - 2, false);
+      __syncthreads();
+    }
+    mphase(NC - 1, true);
+    __syncthreads();
+  }
+#endif
+#ifdef EGNN_EXP_NO_EPI
+  {
+    float keep = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < kRB3; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) keep += acc[rb][cb][i];
+    if (keep == 1.2345e-30f) p.agg_x[tid] = keep;
+    return;
+  }
+#endif
+
+  // row of value index q (q = rb*16 + reg) for this lane
+  auto row_of = [&](int q) { return 32 * (q >> 4) + acc_row(q & 15, lane); };
+
+  if constexpr (!IS_M) {
+    // ---- mlp_x epilogue: s[row] = [b3] + sum_n w3[n] * SiLU(acc + b2[n]) over this workgroup's columns ----
+    float part[64];
+#pragma unroll
+    for (int q = 0; q < 64; ++q) part[q] = 0.f;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+      const int n = 32 * (colblk0 + cb) + r;
+      const float bb = p.b2x[n], w = p.w3x[n];
+#pragma unroll
+      for (int rb = 0; rb < kRB3; ++rb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) part[rb * 16 + i] = fmaf(w, silu_f(acc[rb][cb][i] + bb), part[rb * 16 + i]);
+    }
+    {
+      float lo[32], hi[32];
+#pragma unroll
+      for (int q = 0; q < 32; ++q) { lo[q] = part[q]; hi[q] = part[32 + q]; }
+      const float t0 = butterfly32(lo, lane), t1 = butterfly32(hi, lane);
+      s_part[wave * kR3 + row_of(r)] = t0;
+      s_part[wave * kR3 + 64 + row_of(r)] = t1;
+    }
+    __syncthreads();
+    if (tid < kR3) {
+      float v = half == 0 ? p.scal[0] : 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v += s_part[w * kR3 + tid];
+      s_val[tid] = v;
+    }
+    __syncthreads();
+    float* aggx = p.agg_x + (size_t)half * p.agg_x_stride;
+    float* partx = p.part_x + (size_t)half * p.part_x_stride;
+    if (S <= kSegFast3) {
+      if (wave == 0) {  // coordinate messages (x_i - x_j) * s_ij; 1/(G+1) is applied in node_post
+        float c[2][3];
+        int myseg[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int row = lane + 64 * u;
+          myseg[u] = s_seg_of_row[row];
+          const float sv = s_val[row];
+          c[u][0] = s_diff[row] * sv; c[u][1] = s_diff[kR3 + row] * sv; c[u][2] = s_diff[2 * kR3 + row] * sv;
+        }
+        for (int seg = 0; seg < S; ++seg) {
+          float a0 = (myseg[0] == seg ? c[0][0] : 0.f) + (myseg[1] == seg ? c[1][0] : 0.f);
+          float a1 = (myseg[0] == seg ? c[0][1] : 0.f) + (myseg[1] == seg ? c[1][1] : 0.f);
+          float a2 = (myseg[0] == seg ? c[0][2] : 0.f) + (myseg[1] == seg ? c[1][2] : 0.f);
+#pragma unroll
+          for (int m = 32; m >= 1; m >>= 1) { a0 += __shfl_xor(a0, m); a1 += __shfl_xor(a1, m); a2 += __shfl_xor(a2, m); }
+          if (lane < 3) {
+            const int mode = s_seg_mode[seg];
+            float* dstp = mode == 2 ? aggx + (size_t)s_seg_node[seg] * 4 : partx + ((size_t)tile * 2 + mode) * 4;
+            dstp[lane] = lane == 0 ? a0 : (lane == 1 ? a1 : a2);
+          }
+        }
+      }
+    } else {
+      for (int t = tid; t < 3 * S; t += kT3) {
+        const int seg = t / 3, d = t - 3 * seg, mode = s_seg_mode[seg];
+        float sum = 0.f;
+        for (int rr = s_seg_rs[seg]; rr <= s_seg_re[seg]; ++rr) sum += s_diff[d * kR3 + rr] * s_val[rr];
+        float* dstp = mode == 2 ? aggx + (size_t)s_seg_node[seg] * 4 : partx + ((size_t)tile * 2 + mode) * 4;
+        dstp[d] = sum;
+      }
+    }
+  } else {
+    // ---- mlp_m epilogue: m = SiLU(acc + b2), gate = sigmoid(wa . m + ba) (:31-34, :59-60) ----
+    static_assert(!IS_M || CB == 1, "message epilogue assumes one 32-column block per wave");
+    float mval[64];
+    const int ncol = 32 * wave + r;
+    {
+      const float bb = p.b2m[ncol], wa = p.wa[ncol];
+      float lo[32], hi[32];
+#pragma unroll
+      for (int rb = 0; rb < kRB3; ++rb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float m = silu_f(acc[rb][0][i] + bb);
+          mval[rb * 16 + i] = m;
+          if (rb < 2) lo[rb * 16 + i] = wa * m; else hi[(rb - 2) * 16 + i] = wa * m;
+        }
+      const float t0 = butterfly32(lo, lane), t1 = butterfly32(hi, lane);
+      s_part[wave * kR3 + row_of(r)] = t0;
+      s_part[wave * kR3 + 64 + row_of(r)] = t1;
+    }
+    __syncthreads();
+    if (tid < kR3) {
+      float g = p.scal[1];
+#pragma unroll
+      for (int w = 0; w < 8; ++w) g += s_part[w * kR3 + tid];
+      s_val[tid] = sigmoid_f(g);
+    }
+    __syncthreads();
+    if (S <= kSegFast3) {
+      for (int t = tid; t < S * kR3; t += kT3) {
+        const int seg = t >> 7, row = t & 127;
+        s_gseg[t] = (s_seg_of_row[row] == seg) ? s_val[row] : 0.f;
+      }
+      __syncthreads();
+      for (int seg = 0; seg < S; ++seg) {
+        const float* gw = s_gseg + seg * kR3 + 4 * hh;
+        float v = 0.f;
+#pragma unroll
+        for (int rb = 0; rb < kRB3; ++rb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) v = fmaf(mval[rb * 16 + i], gw[32 * rb + (i & 3) + 8 * (i >> 2)], v);
+        v += __shfl_xor(v, 32);
+        if (hh == 0) {
+          const int mode = s_seg_mode[seg];
+          float* dstp = mode == 2 ? p.agg_m + (size_t)s_seg_node[seg] * p.MP : p.part_m + ((size_t)tile * 2 + mode) * p.MP;
+          dstp[ncol] = v;
+        }
+      }
+    } else {
+      // many short segments: stage the gated messages in LDS (over the finished K-loop buffers)
+      const int ld = p.MP + 1;
+#pragma unroll
+      for (int rb = 0; rb < kRB3; ++rb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = 32 * rb + acc_row(i, lane);
+          s_msg[row * ld + ncol] = mval[rb * 16 + i] * s_val[row];
+        }
+      __syncthreads();
+      for (int c = tid; c < p.MP; c += kT3) {
+        for (int seg = 0; seg < S; ++seg) {
+          const int mode = s_seg_mode[seg];
+          float sum = 0.f;
+          for (int rr = s_seg_rs[seg]; rr <= s_seg_re[seg]; ++rr) sum += s_msg[rr * ld + c];
+          float* dstp = mode == 2 ? p.agg_m + (size_t)s_seg_node[seg] * p.MP : p.part_m + ((size_t)tile * 2 + mode) * p.MP;
+          dstp[c] = sum;
+        }
+      }
+    }
+  }
+}
+
+template <int CB, bool IS_M>
+int launch_v3(const EdgeParams& p, int blocks, size_t smem, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v3<CB, IS_M>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((edge_kernel_bf16_v3<CB, IS_M>), dim3(blocks), dim3(kT3), smem, st, p);
+  EGNN_HIP(hipGetLastError());
+  return EGNN_OK;
+}
+
+}  // namespace
+
+int edge_v3_rows() { return kR3; }
+
+bool edge_bf16_v3_supported(const EdgeParams& p) {
+  return (p.WxP == 256 || p.WxP == 512 || p.WxP == 1024) && p.MP == 256 && p.WmP % 64 == 0 &&
+         v3_smem_bytes(p.WmP, p.MP, true) <= 160 * 1024 && v3_smem_bytes(p.WxP, p.MP, false) <= 160 * 1024 &&
+         (size_t)p.N * p.TC * 4 < ((size_t)1 << 32);
+}
+
+int launch_edge_bf16_v3(const EdgeParams& p, hipStream_t st) {
+  const int tiles = (p.E + kR3 - 1) / kR3;
+  int rc;
+  // X: CB = 2 (512 columns per workgroup) when the hidden width allows, else one 256-column workgroup
+  if (p.WxP >= 512) rc = launch_v3<2, false>(p, tiles * (p.WxP / 512), v3_smem_bytes(p.WxP, p.MP, false), st);
+  else rc = launch_v3<1, false>(p, tiles, v3_smem_bytes(p.WxP, p.MP, false), st);
+  if (rc) return rc;
+  return launch_v3<1, true>(p, tiles, v3_smem_bytes(p.WmP, p.MP, true), st);
+}
+
+}  // namespace egnn

@@ -482,6 +482,8 @@ struct PostParams {
   const float *h, *x;
   const int *row_ptr, *node_graph;
   const float *agg_m, *agg_x, *part_m, *part_x, *gscale;
+  size_t agg_x_stride, part_x_stride;
+  int nsplit_x;   // column-split copies of the coordinate sums to add
   int per_graph;
   const f32x4 *w1h, *w2h;
   const float *b1h, *b2h;
@@ -531,10 +533,14 @@ __global__ __launch_bounds__(kThreads, 1) void node_post_kernel(const PostParams
       float v = 0.f;
       if (rp1 > rp0) {
         const int t0 = rp0 / p.R, t1 = (rp1 - 1) / p.R;
-        if (t0 == t1) v = p.agg_x[(size_t)n * 4 + d];
-        else {
-          v = p.part_x[((size_t)t0 * 2 + 1) * 4 + d];
-          for (int t = t0 + 1; t <= t1; ++t) v += p.part_x[((size_t)t * 2) * 4 + d];
+        for (int hs = 0; hs < p.nsplit_x; ++hs) {
+          const float* ax = p.agg_x + (size_t)hs * p.agg_x_stride;
+          const float* px = p.part_x + (size_t)hs * p.part_x_stride;
+          if (t0 == t1) v += ax[(size_t)n * 4 + d];
+          else {
+            v += px[((size_t)t0 * 2 + 1) * 4 + d];
+            for (int t = t0 + 1; t <= t1; ++t) v += px[((size_t)t * 2) * 4 + d];
+          }
         }
       }
       const float g = p.gscale[p.per_graph ? p.node_graph[n] : 0];
@@ -644,7 +650,7 @@ int reserve(egnn_ctx* c) {
     const size_t n = c->N;
     if ((rc = dev_alloc(&c->table, n * c->TC))) return rc;
     if ((rc = dev_alloc(&c->agg_m, n * c->MP))) return rc;
-    if ((rc = dev_alloc(&c->agg_x, n * 4))) return rc;
+    if ((rc = dev_alloc(&c->agg_x, 2 * n * 4))) return rc;
     if ((rc = dev_alloc(&c->node_d2, n))) return rc;
     for (int i = 0; i < 2; ++i) {
       if ((rc = dev_alloc(&c->h_tmp[i], n * c->H))) return rc;
@@ -654,7 +660,7 @@ int reserve(egnn_ctx* c) {
   }
   if (tiles > c->cap_tiles) {
     if ((rc = dev_alloc(&c->part_m, (tiles + 1) * 2 * c->MP))) return rc;
-    if ((rc = dev_alloc(&c->part_x, (tiles + 1) * 2 * 4))) return rc;
+    if ((rc = dev_alloc(&c->part_x, 2 * (tiles + 1) * 2 * 4))) return rc;
     c->cap_tiles = tiles;
   }
   if ((size_t)c->B > c->cap_graphs) {
@@ -701,7 +707,9 @@ int launch_layer(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_scop
                  const float* x, float* h_out, float* x_out) {
   const LayerPack& lp = c->layers[layer];
   if (!lp.packed) { set_error("layer %d has no packed parameters", layer); return EGNN_ESTATE; }
-  const int N = c->N, E = c->E, R = edge_rows_per_tile(prec);
+  const int N = c->N, E = c->E;
+  int R = edge_rows_per_tile(prec), nsplit_x = 1;
+  const size_t agg_x_stride = (size_t)c->cap_nodes * 4, part_x_stride = (c->cap_tiles + 1) * 2 * 4;
   const int per_graph = norm_scope == EGNN_NORM_GRAPH;
 
   prof_begin(c, st, 1);
@@ -728,6 +736,9 @@ int launch_layer(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_scop
     p.w2x = prec == EGNN_PREC_BF16 ? lp.w2x_bf16 : (const void*)lp.w2x_f32;
     p.w2m = prec == EGNN_PREC_BF16 ? lp.w2m_bf16 : (const void*)lp.w2m_f32;
     p.agg_m = c->agg_m; p.agg_x = c->agg_x; p.part_m = c->part_m; p.part_x = c->part_x;
+    p.agg_x_stride = agg_x_stride; p.part_x_stride = part_x_stride;
+    if (!c->stamps) { if (hipMalloc((void**)&c->stamps, 2 * 8 * 32 * 4 * 8) == hipSuccess) (void)hipMemset(c->stamps, 0, 2 * 8 * 32 * 4 * 8); }
+    p.stamps = c->stamps;
     {
       static const int dbg = getenv("EGNN_DEBUG") ? atoi(getenv("EGNN_DEBUG")) : 0;
       p.dbg = dbg;
@@ -736,7 +747,12 @@ int launch_layer(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_scop
     const size_t smem = edge_smem_bytes(R, c->MP);
     prof_begin(c, st, 0);
     int rc;
-    if (prec == EGNN_PREC_BF16 && edge_bf16_v2_supported(p)) rc = launch_edge_bf16_v2(p, tiles, st);
+    static const int edge_sel = getenv("EGNN_EDGE") ? atoi(getenv("EGNN_EDGE")) : 3;   // A/B switch: 1, 2 or 3
+    if (prec == EGNN_PREC_BF16 && edge_sel >= 3 && edge_bf16_v3_supported(p)) {
+      R = edge_v3_rows();
+      nsplit_x = p.WxP >= 512 ? p.WxP / 512 : 1;
+      rc = launch_edge_bf16_v3(p, st);
+    } else if (prec == EGNN_PREC_BF16 && edge_sel >= 2 && edge_bf16_v2_supported(p)) rc = launch_edge_bf16_v2(p, tiles, st);
     else if (prec == EGNN_PREC_BF16) rc = launch_edge<EGNN_PREC_BF16, 2>(p, tiles, smem, st);
     else rc = launch_edge<EGNN_PREC_F32, 2>(p, tiles, smem, st);
     prof_end(c, st);
@@ -749,6 +765,7 @@ int launch_layer(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_scop
     q.h = h; q.x = x; q.row_ptr = c->row_ptr; q.node_graph = c->node_graph;
     q.agg_m = c->agg_m; q.agg_x = c->agg_x; q.part_m = c->part_m; q.part_x = c->part_x;
     q.gscale = c->gscale; q.per_graph = per_graph;
+    q.agg_x_stride = agg_x_stride; q.part_x_stride = part_x_stride; q.nsplit_x = nsplit_x;
     q.w1h = reinterpret_cast<const f32x4*>(lp.w1h_f32); q.w2h = reinterpret_cast<const f32x4*>(lp.w2h_f32);
     q.b1h = lp.b1h; q.b2h = lp.b2h; q.h_out = h_out; q.x_out = x_out;
     static bool attr_done = false;
@@ -954,6 +971,13 @@ int egnn_forward(egnn_ctx* c, void* stream, int prec, int norm_scope, const floa
     if ((rc = launch_layer(c, st, l, prec, norm_scope, hc, xc, ho, xo))) return rc;
     hc = ho; xc = xo;
   }
+  return EGNN_OK;
+}
+
+int egnn_debug_stamps(egnn_ctx* c, unsigned long long* host_out) {
+  if (!c || !c->stamps || !host_out) return EGNN_EINVAL;
+  EGNN_HIP(hipDeviceSynchronize());
+  EGNN_HIP(hipMemcpy(host_out, c->stamps, 2 * 8 * 32 * 4 * 8, hipMemcpyDeviceToHost));
   return EGNN_OK;
 }
 

@@ -37,6 +37,8 @@ struct EdgeParams {
   const float *wdx, *wdm, *b2x, *w3x, *b2m, *wa, *scal;
   const void *w2x, *w2m;
   float *agg_m, *agg_x, *part_m, *part_x;
+  size_t agg_x_stride, part_x_stride;  // elements between the column-split copies of agg_x / part_x
+  unsigned long long* stamps;  // diagnostic builds only (EGNN_EXP_STAMP): s_memtime stamps of one workgroup
   int dbg;  // timing experiments only (EGNN_DEBUG): bit0 drop weight loads, bit1 drop table loads
 };
 
@@ -52,7 +54,94 @@ __host__ __device__ inline size_t edge_smem_bytes(int R, int MP) {
 }
 
 
+// ---- helpers shared by the bf16 edge kernels ---------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+// soff must be wave-uniform; readfirstlane makes that provable to the compiler (else it wraps the load
+// in a waterfall loop)
+__device__ __forceinline__ f32x4 ldbuf_f32x4(rsrc_t rs, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, __builtin_amdgcn_readfirstlane(soff), 0));
+}
+__device__ __forceinline__ bf16x8 ldbuf_bf16x8(rsrc_t rs, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, __builtin_amdgcn_readfirstlane(soff), 0));
+}
+
+// ---- cross-lane row reduction without LDS ------------------------------------------------------------
+// v[q], q = 0..31, per lane.  Returns the sum over the 32 lanes of this half-wave of value index
+// q = (lane & 31).  Halving butterfly: every step pairs two lanes, each keeps one half of the value
+// indices: v_permlane16_swap for lane^16, DPP row_ror:8 / row_half_mirror / quad_perm inside a row of
+// 16, bank-masked DPP moves as the per-lane select.  ~80 VALU instructions, no LDS traffic.
+// (The swap is inline asm: hipcc 7.2 folds the two results of __builtin_amdgcn_permlane16_swap into
+// one when they are summed as floats.  s_nop 1 = the 2 wait states between a VALU write and the swap.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), CTRL, 0xF, 0xF, true));
+}
+template <int BANK>
+__device__ __forceinline__ float dpp_sel(float a, float b) {  // lanes of the banks in BANK take b
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, a), __builtin_bit_cast(int, b), 0xE4, 0xF, BANK, false));
+}
+__device__ __forceinline__ float butterfly32(float (&v)[32], int lane) {
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    float a = v[q], b = v[q + 16];
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    v[q] = a + b;   // even rows: index q over lanes {l, l+16}; odd rows: index q + 16
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const float ta = v[q] + dpp_mov<0x128>(v[q]);          // row_ror:8  (lane ^ 8)
+    const float tb = v[q + 8] + dpp_mov<0x128>(v[q + 8]);
+    v[q] = dpp_sel<0xC>(ta, tb);                            // lanes with (lane & 8) keep index q + 8
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float ta = v[q] + dpp_mov<0x141>(v[q]);          // row_half_mirror (pairs lane l with 7 - l)
+    const float tb = v[q + 4] + dpp_mov<0x141>(v[q + 4]);
+    v[q] = dpp_sel<0xA>(ta, tb);                            // lanes with (lane & 4) keep index q + 4
+  }
+  const bool b2 = (lane & 2) != 0, b1 = (lane & 1) != 0;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const float ta = v[q] + dpp_mov<0x4E>(v[q]);           // quad_perm [2,3,0,1]
+    const float tb = v[q + 2] + dpp_mov<0x4E>(v[q + 2]);
+    v[q] = b2 ? tb : ta;
+  }
+  const float ta = v[0] + dpp_mov<0xB1>(v[0]);             // quad_perm [1,0,3,2]
+  const float tb = v[1] + dpp_mov<0xB1>(v[1]);
+  return b1 ? tb : ta;
+}
+
+struct Unit {  // one build unit in flight: 8 columns of one row of one MLP
+  f32x4 p0, p1, q0, q1;
+};
+// table rows through a buffer descriptor: voffset = byte offset of the row, soffset = column offset
+__device__ __forceinline__ void unit_load(Unit& u, rsrc_t tab, unsigned vdst, unsigned vsrc, unsigned sP, unsigned sQ) {
+  u.p0 = ldbuf_f32x4(tab, vdst, sP);
+  u.p1 = ldbuf_f32x4(tab, vdst + 16, sP);
+  u.q0 = ldbuf_f32x4(tab, vsrc, sQ);
+  u.q1 = ldbuf_f32x4(tab, vsrc + 16, sQ);
+}
+__device__ __forceinline__ void unit_finish(const Unit& u, const float* wd, float d2, char* slot) {
+  const f32x4 w0 = *reinterpret_cast<const f32x4*>(wd), w1 = *reinterpret_cast<const f32x4*>(wd + 4);
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    o[j] = (__bf16)silu_f(fmaf(w0[j], d2, u.p0[j] + u.q0[j]));
+    o[j + 4] = (__bf16)silu_f(fmaf(w1[j], d2, u.p1[j] + u.q1[j]));
+  }
+  *reinterpret_cast<bf16x8*>(slot) = o;
+}
+
+
 int launch_edge_bf16_v2(const EdgeParams& p, int tiles, hipStream_t st);
+int launch_edge_bf16_v3(const EdgeParams& p, hipStream_t st);
+bool edge_bf16_v3_supported(const EdgeParams& p);
+int edge_v3_rows();
 bool edge_bf16_v2_supported(const EdgeParams& p);
 
 }  // namespace egnn

@@ -144,6 +144,8 @@ int egnn_sampler_state(egnn_ctx* ctx, void* stream, float* d_pos, float* d_x_typ
 
 /* timing helper for bench.py: average duration (ms) of the fused edge kernel over the launches
  * recorded since the last reset, measured with HIP events on the launch stream. */
+/* diagnostic builds only (-DEGNN_EXP_STAMP): s_memtime stamps [2][8][32][4] of one edge workgroup */
+int egnn_debug_stamps(egnn_ctx* ctx, unsigned long long* host_out);
 int egnn_profile_enable(egnn_ctx* ctx, int enable);
 int egnn_profile_read(egnn_ctx* ctx, float* edge_ms_avg, int* edge_launches, float* node_ms_avg);
 

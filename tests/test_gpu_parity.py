@@ -180,12 +180,14 @@ def test_full_size_c2_properties(precision, tol):
     etol = 1e-4 if precision == "fp32" else tol
     assert rel_err(h1.cpu(), h0.cpu()) <= etol
     assert rel_err((x1.cpu() - (x @ R.T + tvec)), (x0.cpu() - x) @ R.T) <= etol
-    # permuting whole graphs permutes the outputs (bitwise: same tiles, same arithmetic)
+    # permuting whole graphs permutes the outputs (up to the fp32 summation order of tile partials: a
+    # graph's 4032 edges need not start on a tile boundary)
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(3))
     idx = (perm.repeat_interleave(n) * n + torch.arange(n).repeat(B))
     with torch.no_grad():
         h2, x2 = net(ei, h[idx].to(DEV), x[idx].to(DEV), batch=batch)
-    assert torch.equal(h2.cpu(), h0.cpu()[idx]) and torch.equal(x2.cpu(), x0.cpu()[idx])
+    ptol = 1e-5 if precision == "fp32" else 1e-3   # bf16 re-rounding amplifies fp32 order differences
+    assert rel_err(h2.cpu(), h0.cpu()[idx]) <= ptol and rel_err(x2.cpu(), x0.cpu()[idx]) <= ptol
     # oracle spot check on graphs 0 and 137
     e1 = egnn_ref.fully_connected_edge_index(n)
     for gidx in (0, 137):

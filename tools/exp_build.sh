@@ -1,0 +1,7 @@
+#!/bin/bash
+# Build timing-experiment variants of the library: tools/exp_build.sh <name> <extra hipcc flags...>
+# -> diffusion_model_amd/exp_<name>.so  (select with EGNN_LIB=... ; results are wrong by construction)
+name=$1; shift
+C=diffusion_model_amd/csrc
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -shared "$@" \
+  $C/egnn_forward.hip $C/edge_bf16.hip $C/edge_bf16_v3.hip $C/sampler.hip -o diffusion_model_amd/exp_$name.so

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Diagnostic: run a few bench steps with the stamp build and print per-wave phase durations (cycles)."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import diffusion_model_amd as dma
+from diffusion_model_amd import _lib
+H, M, W, A, T, L, B, n = 36, 256, 1024, 2, 1000, 1, 256, 64
+torch.manual_seed(0)
+net = dma.EquivariantGNN(L, 2*H+1, W, M, 2*H+1, W, 1, H+M, W, H).cuda().eval(); net.precision = "bf16"
+for l in net.egcl_list:
+    l.mlp_x[4].weight.data.mul_(1e-3)
+proc = dma.E3DiffusionProcess(1e-5, 2.0, T)
+smp = dma.DeviceSampler(net, proc, [n]*B, torch.randn(B*n, H-A-1), atom_type_size=A)
+smp.init(); smp.run(nsteps=3, use_graph=False)
+buf = np.zeros(2*8*32*4, dtype=np.uint64)
+_lib.check(_lib.lib().egnn_debug_stamps(smp.ctx.handle, buf.ctypes.data_as(C.POINTER(C.c_uint64))))
+st = buf.reshape(2, 8, 32, 4).astype(np.int64)
+for k, name in enumerate(("X", "M")):
+    print("kernel", name)
+    for w in range(8):
+        s = st[k, w, :16]
+        if s[0, 0] == 0: continue
+        p1, p2, bar = s[:, 1]-s[:, 0], s[:, 2]-s[:, 1], s[:, 3]-s[:, 2]
+        tot = s[15, 3] - s[0, 0]
+        print(f" wave {w}: phase1 {p1[1:15].mean():7.0f}  phase2 {p2[1:15].mean():7.0f}  barrier {bar[1:15].mean():7.0f}  chunk {np.diff(s[:,0])[1:14].mean():7.0f}  loop total {tot}")
