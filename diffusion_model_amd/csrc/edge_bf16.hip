@@ -333,18 +333,22 @@ __global__ __launch_bounds__(kT2, 2) void edge_kernel_bf16_v2(const EdgeParams p
 
 template <int CBX, int CBM>
 int launch_v2(const EdgeParams& p, int tiles, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v2<CBX, CBM>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
   hipLaunchKernelGGL((edge_kernel_bf16_v2<CBX, CBM>), dim3(tiles), dim3(kT2), v2_smem_bytes(p.MP), st, p);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }
 
 }  // namespace
+
+int init_edge_bf16_v2_attributes() {
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v2<1, 1>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v2<2, 1>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v2<4, 1>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  return EGNN_OK;
+}
 
 bool edge_bf16_v2_supported(const EdgeParams& p) {
   const int cbx = p.WxP / 256;

@@ -434,18 +434,22 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
 
 template <int CB, bool IS_M>
 int launch_v3(const EdgeParams& p, int blocks, size_t smem, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v3<CB, IS_M>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
   hipLaunchKernelGGL((edge_kernel_bf16_v3<CB, IS_M>), dim3(blocks), dim3(kT3), smem, st, p);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }
 
 }  // namespace
+
+int init_edge_bf16_v3_attributes() {
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v3<2, false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v3<1, false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v3<1, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  return EGNN_OK;
+}
 
 int edge_v3_rows() { return kR3; }
 

@@ -663,6 +663,10 @@ int reserve(egnn_ctx* c) {
     if ((rc = dev_alloc(&c->part_x, 2 * (tiles + 1) * 2 * 4))) return rc;
     c->cap_tiles = tiles;
   }
+  if (!c->stamps) {
+    if ((rc = dev_alloc(&c->stamps, (size_t)2 * 8 * 32 * 4))) return rc;
+    EGNN_HIP(hipMemset(c->stamps, 0, 2 * 8 * 32 * 4 * 8));
+  }
   if ((size_t)c->B > c->cap_graphs) {
     if ((rc = dev_alloc(&c->gscale, (size_t)c->B + 1))) return rc;
     c->cap_graphs = c->B;
@@ -690,14 +694,25 @@ static void prof_end(egnn_ctx* c, hipStream_t st) {
   c->ev_used += 2;
 }
 
+int init_kernel_attributes() {
+  // raise the dynamic-LDS limit of every big kernel once, outside any stream capture
+  static bool done = false;
+  if (done) return EGNN_OK;
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel<EGNN_PREC_BF16, 2>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel<EGNN_PREC_F32, 2>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&node_post_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  int rc = init_edge_bf16_v2_attributes();
+  if (rc) return rc;
+  if ((rc = init_edge_bf16_v3_attributes())) return rc;
+  done = true;
+  return EGNN_OK;
+}
+
 template <int PREC, int RB>
 static int launch_edge(const EdgeParams& p, int tiles, size_t smem, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel<PREC, RB>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
   hipLaunchKernelGGL((edge_kernel<PREC, RB>), dim3(tiles), dim3(kThreads), smem, st, p);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
@@ -737,7 +752,6 @@ int launch_layer(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_scop
     p.w2m = prec == EGNN_PREC_BF16 ? lp.w2m_bf16 : (const void*)lp.w2m_f32;
     p.agg_m = c->agg_m; p.agg_x = c->agg_x; p.part_m = c->part_m; p.part_x = c->part_x;
     p.agg_x_stride = agg_x_stride; p.part_x_stride = part_x_stride;
-    if (!c->stamps) { if (hipMalloc((void**)&c->stamps, 2 * 8 * 32 * 4 * 8) == hipSuccess) (void)hipMemset(c->stamps, 0, 2 * 8 * 32 * 4 * 8); }
     p.stamps = c->stamps;
     {
       static const int dbg = getenv("EGNN_DEBUG") ? atoi(getenv("EGNN_DEBUG")) : 0;
@@ -768,12 +782,6 @@ int launch_layer(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_scop
     q.agg_x_stride = agg_x_stride; q.part_x_stride = part_x_stride; q.nsplit_x = nsplit_x;
     q.w1h = reinterpret_cast<const f32x4*>(lp.w1h_f32); q.w2h = reinterpret_cast<const f32x4*>(lp.w2h_f32);
     q.b1h = lp.b1h; q.b2h = lp.b2h; q.h_out = h_out; q.x_out = x_out;
-    static bool attr_done = false;
-    if (!attr_done) {
-      EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&node_post_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_done = true;
-    }
     prof_begin(c, st, 1);
     hipLaunchKernelGGL(node_post_kernel, dim3((N + kPostNodes - 1) / kPostNodes), dim3(kThreads),
                        post_smem_bytes(c->K1P, c->WhP), st, q);
@@ -803,6 +811,10 @@ int egnn_create(egnn_ctx** out, int device) {
     return EGNN_EHIP;
   }
   EGNN_HIP(hipSetDevice(device));
+  {
+    int rc = init_kernel_attributes();
+    if (rc) return rc;
+  }
   egnn_ctx* c = new egnn_ctx();
   c->device = device;
   *out = c;

@@ -142,6 +142,8 @@ int launch_edge_bf16_v2(const EdgeParams& p, int tiles, hipStream_t st);
 int launch_edge_bf16_v3(const EdgeParams& p, hipStream_t st);
 bool edge_bf16_v3_supported(const EdgeParams& p);
 int edge_v3_rows();
+int init_edge_bf16_v2_attributes();
+int init_edge_bf16_v3_attributes();
 bool edge_bf16_v2_supported(const EdgeParams& p);
 
 }  // namespace egnn
