@@ -47,6 +47,12 @@ struct LayerPack {
   float* b1h = nullptr;      // [WhP]
   float* w2h_f32 = nullptr;  // mlp_h.2 fragments, N = HP, K = WhP
   float* b2h = nullptr;      // [HP]
+  // bf16 fast path: SiLU is evaluated as t * rcp(1 + exp2(t)) on t = -log2(e) * z.  The first-layer table,
+  // biases and d^2 columns are pre-multiplied by -log2(e) and the following weights by -1/log2(e), which
+  // removes one multiply per SiLU.
+  float* sc = nullptr;       // [w1catT_s | b1cat_s | wdx_s | wdm_s | b2x_s | w3x_s | b2m_s | wa_s]
+  void* w2x_bf16s = nullptr;
+  void* w2m_bf16s = nullptr;
 };
 
 struct Sampler {

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(kT2, 2) void edge_kernel_bf16_v2(const EdgeParams p
 #pragma unroll
       for (int rb = 0; rb < kRB; ++rb)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) part[rb * 16 + i] = fmaf(w, silu_f(accx[rb][cb][i] + b), part[rb * 16 + i]);
+        for (int i = 0; i < 16; ++i) part[rb * 16 + i] = fmaf(w, silu_s(fmaf(accx[rb][cb][i], kNegLog2e, b)), part[rb * 16 + i]);
     }
     const float tot = butterfly32(part, lane);   // row-sum of value index q = r over this wave's columns
     s_part[wave * kR + 32 * (r >> 4) + acc_row(r & 15, lane)] = tot;
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(kT2, 2) void edge_kernel_bf16_v2(const EdgeParams p
     for (int rb = 0; rb < kRB; ++rb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        mval[rb * 16 + i] = silu_f(accm[rb][0][i] + b);
+        mval[rb * 16 + i] = silu_s(fmaf(accm[rb][0][i], kNegLog2e, b));   // = -log2(e) * m
         g[rb * 16 + i] = wa * mval[rb * 16 + i];
       }
     const float tot = butterfly32(g, lane);
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(kT2, 2) void edge_kernel_bf16_v2(const EdgeParams p
 #pragma unroll
     for (int w = 0; w < 8; ++w) { v += s_part[w * kR + tid]; gsum += s_partg[w * kR + tid]; }
     s_sval[tid] = v;
-    s_gate[tid] = sigmoid_f(gsum);
+    s_gate[tid] = sigmoid_f(gsum) * kNegInvLog2e;   // also undoes the scale of mval
   }
   __syncthreads();
 

@@ -307,7 +307,7 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
 #pragma unroll
       for (int rb = 0; rb < kRB3; ++rb)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) part[rb * 16 + i] = fmaf(w, silu_f(acc[rb][cb][i] + bb), part[rb * 16 + i]);
+        for (int i = 0; i < 16; ++i) part[rb * 16 + i] = fmaf(w, silu_s(fmaf(acc[rb][cb][i], kNegLog2e, bb)), part[rb * 16 + i]);
     }
     {
       float lo[32], hi[32];
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
       for (int rb = 0; rb < kRB3; ++rb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const float m = silu_f(acc[rb][0][i] + bb);
+          const float m = silu_s(fmaf(acc[rb][0][i], kNegLog2e, bb));   // = -log2(e) * m
           mval[rb * 16 + i] = m;
           if (rb < 2) lo[rb * 16 + i] = wa * m; else hi[(rb - 2) * 16 + i] = wa * m;
         }
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
       float g = p.scal[1];
 #pragma unroll
       for (int w = 0; w < 8; ++w) g += s_part[w * kR3 + tid];
-      s_val[tid] = sigmoid_f(g);
+      s_val[tid] = sigmoid_f(g) * kNegInvLog2e;   // also undoes the scale of mval
     }
     __syncthreads();
     if (S <= kSegFast3) {

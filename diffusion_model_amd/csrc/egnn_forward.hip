@@ -55,7 +55,7 @@ __global__ void pack_frags_f32(const float* __restrict__ W, int Nout, int K, int
 // v_mfma_f32_32x32x16_bf16: lane l holds B[k = 16*ks + 8*(l>>5) + j][n = 32*nb + (l&31)], j = 0..7.
 // out[((nb*KS + ks)*64 + lane)*8 + j]
 __global__ void pack_frags_bf16(const float* __restrict__ W, int Nout, int K, int ldw, int NP, int KP,
-                                __bf16* __restrict__ out) {
+                                __bf16* __restrict__ out, float scale) {
   const int KS = KP / 16;
   const size_t total = (size_t)(NP / 32) * KS * 64 * 8;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -63,8 +63,11 @@ __global__ void pack_frags_bf16(const float* __restrict__ W, int Nout, int K, in
     const size_t f = i >> 9;
     const int ks = f % KS, nb = f / KS;
     const int n = 32 * nb + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + j;
-    out[i] = (__bf16)((n < Nout && k < K) ? W[(size_t)n * ldw + k] : 0.f);
+    out[i] = (__bf16)((n < Nout && k < K) ? W[(size_t)n * ldw + k] * scale : 0.f);
   }
+}
+__global__ void scale_copy(const float* __restrict__ src, size_t n, float scale, float* __restrict__ dst) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i] * scale;
 }
 __global__ void pad_copy(const float* __restrict__ src, int n, int stride, float* __restrict__ dst, int nP) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nP; i += gridDim.x * blockDim.x)
@@ -727,11 +730,47 @@ int launch_layer(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_scop
   const size_t agg_x_stride = (size_t)c->cap_nodes * 4, part_x_stride = (c->cap_tiles + 1) * 2 * 4;
   const int per_graph = norm_scope == EGNN_NORM_GRAPH;
 
+  // choose the edge path first: the bf16 fast kernels consume the pre-scaled first-layer table
+  EdgeParams p;
+  p.N = N; p.E = E;
+  p.edge_dst = c->edge_dst; p.edge_src = c->edge_src; p.row_ptr = c->row_ptr;
+  p.x = x; p.table = c->table;
+  p.TC = c->TC; p.WxP = c->WxP; p.WmP = c->WmP; p.MP = c->MP; p.cbx = c->cbx; p.cbm = c->cbm;
+  p.wdx = lp.wdx; p.wdm = lp.wdm; p.b2x = lp.b2x; p.w3x = lp.w3x; p.b2m = lp.b2m; p.wa = lp.wa;
+  p.scal = lp.scal;
+  p.w2x = prec == EGNN_PREC_BF16 ? lp.w2x_bf16 : (const void*)lp.w2x_f32;
+  p.w2m = prec == EGNN_PREC_BF16 ? lp.w2m_bf16 : (const void*)lp.w2m_f32;
+  p.agg_m = c->agg_m; p.agg_x = c->agg_x; p.part_m = c->part_m; p.part_x = c->part_x;
+  p.agg_x_stride = agg_x_stride; p.part_x_stride = part_x_stride;
+  p.stamps = c->stamps;
+  {
+    static const int dbg = getenv("EGNN_DEBUG") ? atoi(getenv("EGNN_DEBUG")) : 0;
+    p.dbg = dbg;
+  }
+  static const int edge_sel = getenv("EGNN_EDGE") ? atoi(getenv("EGNN_EDGE")) : 3;   // A/B switch: 1, 2 or 3
+  int path = 1;
+  if (prec == EGNN_PREC_BF16 && edge_sel >= 3 && edge_bf16_v3_supported(p)) path = 3;
+  else if (prec == EGNN_PREC_BF16 && edge_sel >= 2 && edge_bf16_v2_supported(p)) path = 2;
+  const float* w1catT = lp.w1catT;
+  const float* b1cat = lp.b1cat;
+  if (path >= 2) {
+    const float* o = lp.sc;
+    w1catT = o; o += (size_t)c->H * c->TC;
+    b1cat = o; o += c->TC;
+    p.wdx = o; o += c->WxP;
+    p.wdm = o; o += c->WmP;
+    p.b2x = o; o += c->WxP;
+    p.w3x = o; o += c->WxP;
+    p.b2m = o; o += c->MP;
+    p.wa = o;
+    p.w2x = lp.w2x_bf16s; p.w2m = lp.w2m_bf16s;
+  }
+
   prof_begin(c, st, 1);
   {
     dim3 grid((N + kPreNodes - 1) / kPreNodes, (c->TC + kThreads - 1) / kThreads);
     hipLaunchKernelGGL(node_pre_kernel, grid, dim3(kThreads), (size_t)kPreNodes * c->H * sizeof(float), st, h, N,
-                       c->H, lp.w1catT, lp.b1cat, c->TC, c->table);
+                       c->H, w1catT, b1cat, c->TC, c->table);
     hipLaunchKernelGGL(node_d2_kernel, dim3((N + 255) / 256), dim3(256), 0, st, x, c->row_ptr, c->edge_src, N,
                        c->node_d2);
     hipLaunchKernelGGL(graph_scale_kernel, dim3(per_graph ? c->B : 1), dim3(kThreads), 0, st, c->node_d2,
@@ -741,32 +780,15 @@ int launch_layer(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_scop
   EGNN_HIP(hipGetLastError());
 
   if (E > 0) {
-    EdgeParams p;
-    p.N = N; p.E = E;
-    p.edge_dst = c->edge_dst; p.edge_src = c->edge_src; p.row_ptr = c->row_ptr;
-    p.x = x; p.table = c->table;
-    p.TC = c->TC; p.WxP = c->WxP; p.WmP = c->WmP; p.MP = c->MP; p.cbx = c->cbx; p.cbm = c->cbm;
-    p.wdx = lp.wdx; p.wdm = lp.wdm; p.b2x = lp.b2x; p.w3x = lp.w3x; p.b2m = lp.b2m; p.wa = lp.wa;
-    p.scal = lp.scal;
-    p.w2x = prec == EGNN_PREC_BF16 ? lp.w2x_bf16 : (const void*)lp.w2x_f32;
-    p.w2m = prec == EGNN_PREC_BF16 ? lp.w2m_bf16 : (const void*)lp.w2m_f32;
-    p.agg_m = c->agg_m; p.agg_x = c->agg_x; p.part_m = c->part_m; p.part_x = c->part_x;
-    p.agg_x_stride = agg_x_stride; p.part_x_stride = part_x_stride;
-    p.stamps = c->stamps;
-    {
-      static const int dbg = getenv("EGNN_DEBUG") ? atoi(getenv("EGNN_DEBUG")) : 0;
-      p.dbg = dbg;
-    }
     const int tiles = (E + R - 1) / R;
     const size_t smem = edge_smem_bytes(R, c->MP);
     prof_begin(c, st, 0);
     int rc;
-    static const int edge_sel = getenv("EGNN_EDGE") ? atoi(getenv("EGNN_EDGE")) : 3;   // A/B switch: 1, 2 or 3
-    if (prec == EGNN_PREC_BF16 && edge_sel >= 3 && edge_bf16_v3_supported(p)) {
+    if (path == 3) {
       R = edge_v3_rows();
       nsplit_x = p.WxP >= 512 ? p.WxP / 512 : 1;
       rc = launch_edge_bf16_v3(p, st);
-    } else if (prec == EGNN_PREC_BF16 && edge_sel >= 2 && edge_bf16_v2_supported(p)) rc = launch_edge_bf16_v2(p, tiles, st);
+    } else if (path == 2) rc = launch_edge_bf16_v2(p, tiles, st);
     else if (prec == EGNN_PREC_BF16) rc = launch_edge<EGNN_PREC_BF16, 2>(p, tiles, smem, st);
     else rc = launch_edge<EGNN_PREC_F32, 2>(p, tiles, smem, st);
     prof_end(c, st);
@@ -823,7 +845,7 @@ int egnn_create(egnn_ctx** out, int device) {
 
 static void free_layer(LayerPack& lp) {
   void* ptrs[] = {lp.w1catT, lp.b1cat, lp.wdx, lp.wdm, lp.w2x_f32, lp.w2x_bf16, lp.b2x, lp.w3x, lp.w2m_f32,
-                  lp.w2m_bf16, lp.b2m, lp.wa, lp.scal, lp.w1h_f32, lp.b1h, lp.w2h_f32, lp.b2h};
+                  lp.w2m_bf16, lp.b2m, lp.wa, lp.scal, lp.w1h_f32, lp.b1h, lp.w2h_f32, lp.b2h, lp.sc, lp.w2x_bf16s, lp.w2m_bf16s};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   lp = LayerPack();
@@ -912,17 +934,23 @@ int egnn_pack_layer(egnn_ctx* c, void* stream, int l, const float* m0_w, const f
     if ((rc = dev_alloc(&lp.b1h, (size_t)WhP))) return rc;
     if ((rc = dev_alloc(&lp.w2h_f32, (size_t)HP * WhP))) return rc;
     if ((rc = dev_alloc(&lp.b2h, (size_t)HP))) return rc;
+    if ((rc = dev_alloc(&lp.sc, (size_t)(H + 1) * TC + 3 * (size_t)WxP + WmP + 2 * (size_t)MP))) return rc;
+    tmp = nullptr;
+    if ((rc = dev_alloc(&tmp, (size_t)WxP * WxP))) return rc;
+    lp.w2x_bf16s = tmp; tmp = nullptr;
+    if ((rc = dev_alloc(&tmp, (size_t)MP * WmP))) return rc;
+    lp.w2m_bf16s = tmp;
   }
   const dim3 g(256), b(256);
   hipLaunchKernelGGL(pack_first, g, b, 0, st, x0_w, x0_b, m0_w, m0_b, H, Wx, Wm, WxP, WmP, lp.w1catT, lp.b1cat);
   hipLaunchKernelGGL(pad_copy, dim3(8), b, 0, st, x0_w + 2 * H, Wx, 2 * H + 1, lp.wdx, WxP);
   hipLaunchKernelGGL(pad_copy, dim3(8), b, 0, st, m0_w + 2 * H, Wm, 2 * H + 1, lp.wdm, WmP);
   hipLaunchKernelGGL(pack_frags_f32, g, b, 0, st, x2_w, Wx, Wx, Wx, WxP, WxP, lp.w2x_f32);
-  hipLaunchKernelGGL(pack_frags_bf16, g, b, 0, st, x2_w, Wx, Wx, Wx, WxP, WxP, reinterpret_cast<__bf16*>(lp.w2x_bf16));
+  hipLaunchKernelGGL(pack_frags_bf16, g, b, 0, st, x2_w, Wx, Wx, Wx, WxP, WxP, reinterpret_cast<__bf16*>(lp.w2x_bf16), 1.0f);
   hipLaunchKernelGGL(pad_copy, dim3(8), b, 0, st, x2_b, Wx, 1, lp.b2x, WxP);
   hipLaunchKernelGGL(pad_copy, dim3(8), b, 0, st, x4_w, Wx, 1, lp.w3x, WxP);
   hipLaunchKernelGGL(pack_frags_f32, g, b, 0, st, m2_w, M, Wm, Wm, MP, WmP, lp.w2m_f32);
-  hipLaunchKernelGGL(pack_frags_bf16, g, b, 0, st, m2_w, M, Wm, Wm, MP, WmP, reinterpret_cast<__bf16*>(lp.w2m_bf16));
+  hipLaunchKernelGGL(pack_frags_bf16, g, b, 0, st, m2_w, M, Wm, Wm, MP, WmP, reinterpret_cast<__bf16*>(lp.w2m_bf16), 1.0f);
   hipLaunchKernelGGL(pad_copy, dim3(8), b, 0, st, m2_b, M, 1, lp.b2m, MP);
   hipLaunchKernelGGL(pad_copy, dim3(8), b, 0, st, a_w, M, 1, lp.wa, MP);
   hipLaunchKernelGGL(pad_copy, dim3(1), dim3(64), 0, st, x4_b, 1, 1, lp.scal, 1);
@@ -932,6 +960,20 @@ int egnn_pack_layer(egnn_ctx* c, void* stream, int l, const float* m0_w, const f
   hipLaunchKernelGGL(pad_copy, dim3(8), b, 0, st, h0_b, Wh, 1, lp.b1h, WhP);
   hipLaunchKernelGGL(pack_frags_f32, g, b, 0, st, h2_w, H, Wh, Wh, HP, WhP, lp.w2h_f32);
   hipLaunchKernelGGL(pad_copy, dim3(8), b, 0, st, h2_b, H, 1, lp.b2h, HP);
+  {  // scaled copies for the bf16 fast path (see LayerPack::sc)
+    float* o = lp.sc;
+    const float s1 = kNegLog2e, s2 = kNegInvLog2e;
+    hipLaunchKernelGGL(scale_copy, g, b, 0, st, lp.w1catT, (size_t)H * TC, s1, o); o += (size_t)H * TC;
+    hipLaunchKernelGGL(scale_copy, dim3(8), b, 0, st, lp.b1cat, (size_t)TC, s1, o); o += TC;
+    hipLaunchKernelGGL(scale_copy, dim3(8), b, 0, st, lp.wdx, (size_t)WxP, s1, o); o += WxP;
+    hipLaunchKernelGGL(scale_copy, dim3(8), b, 0, st, lp.wdm, (size_t)WmP, s1, o); o += WmP;
+    hipLaunchKernelGGL(scale_copy, dim3(8), b, 0, st, lp.b2x, (size_t)WxP, s1, o); o += WxP;
+    hipLaunchKernelGGL(scale_copy, dim3(8), b, 0, st, lp.w3x, (size_t)WxP, s2, o); o += WxP;
+    hipLaunchKernelGGL(scale_copy, dim3(8), b, 0, st, lp.b2m, (size_t)MP, s1, o); o += MP;
+    hipLaunchKernelGGL(scale_copy, dim3(8), b, 0, st, lp.wa, (size_t)MP, s2, o);
+    hipLaunchKernelGGL(pack_frags_bf16, g, b, 0, st, x2_w, Wx, Wx, Wx, WxP, WxP, reinterpret_cast<__bf16*>(lp.w2x_bf16s), s2);
+    hipLaunchKernelGGL(pack_frags_bf16, g, b, 0, st, m2_w, M, Wm, Wm, MP, WmP, reinterpret_cast<__bf16*>(lp.w2m_bf16s), s2);
+  }
   EGNN_HIP(hipGetLastError());
   lp.packed = true;
   return EGNN_OK;

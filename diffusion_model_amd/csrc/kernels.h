@@ -12,6 +12,10 @@ __device__ __forceinline__ float silu_f(float v) {
   // v * sigmoid(v); exp(-v) = inf for very negative v gives rcp = 0 and the correct limit -0
   return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
 }
+// SiLU on a pre-scaled argument t = -log2(e) * z:  returns -log2(e) * silu(z)
+__device__ __forceinline__ float silu_s(float t) { return t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t)); }
+constexpr float kNegLog2e = -1.4426950408889634f;
+constexpr float kNegInvLog2e = -0.6931471805599453f;
 __device__ __forceinline__ float sigmoid_f(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 // row of accumulator register `reg` of a 32x32 MFMA tile for this lane (C/D layout, gfx950)
@@ -131,8 +135,8 @@ __device__ __forceinline__ void unit_finish(const Unit& u, const float* wd, floa
   bf16x8 o;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    o[j] = (__bf16)silu_f(fmaf(w0[j], d2, u.p0[j] + u.q0[j]));
-    o[j + 4] = (__bf16)silu_f(fmaf(w1[j], d2, u.p1[j] + u.q1[j]));
+    o[j] = (__bf16)silu_s(fmaf(w0[j], d2, u.p0[j] + u.q0[j]));   // table, wd pre-scaled by -log2(e)
+    o[j + 4] = (__bf16)silu_s(fmaf(w1[j], d2, u.p1[j] + u.q1[j]));
   }
   *reinterpret_cast<bf16x8*>(slot) = o;
 }
