@@ -187,7 +187,9 @@ def main():
                        "global_batch": world * B, "parallelism": f"replicas x{world} (no data-path collective)"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": None,
-                         "kernel": "edge_kernel", "avg_launch_ms": edge_ms.value, "launches": edge_n.value,
+                         "kernel": "fused edge pass of one EGCL layer (edge_kernel_bf16_v3 X+M launches, or "
+                                   "edge_kernel_bf16_v2 / edge_kernel<F32>)",
+                         "avg_launch_ms": edge_ms.value, "launches": edge_n.value,
                          "algorithmic_flop_per_launch": flops_per_launch},
             "graph_replay_ms_per_step": graph_ms,
             "node_kernels_ms_per_layer": node_ms.value * 2,
