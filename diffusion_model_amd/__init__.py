@@ -4,7 +4,9 @@ arithmetic on the path runs in libegnn_amd.so (hand-written HIP for gfx950) thro
 declared in include/egnn_amd.h."""
 from .egnn import EGCL, EquivariantGNN  # noqa: F401
 from .diffusion import E3DiffusionProcess, remove_mean  # noqa: F401
-from .graph import GraphPlan, fully_connected_edge_index  # noqa: F401
+from .graph import GraphPlan, fully_connected_edge_index, fully_connected_plan, plan_edge_index, radius_plan  # noqa: F401
+from . import stats  # noqa: F401
+from .optim import RAdamScheduleFree, define_optimizer  # noqa: F401
 from .sampler import DeviceSampler, generate  # noqa: F401
 from .preprocessor import SpectrumCompressor  # noqa: F401
 from .snr import GammaNetwork, PositiveLinear  # noqa: F401

@@ -35,6 +35,11 @@ SIGNATURES = {
     "egnn_sampler_run": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "egnn_sampler_final": (_i, [_vp, _vp, _i, _i] + [_vp] * 5),
     "egnn_sampler_state": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(_i)]),
+    "egnn_fc_graph_build": (_i, [_vp, _i, _i] + [_vp] * 6),
+    "egnn_radius_graph_count": (_i, [_vp, _i, _vp, _vp, _vp, _f, _vp]),
+    "egnn_radius_graph_fill": (_i, [_vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
+    "egnn_rdf": (_i, [_vp, _i, _vp, _vp, _f, _f, _f, _i, _i, _vp]),
+    "egnn_si_o_si": (_i, [_vp, _i, _i, _vp, _vp, _vp, _f, _vp]),
     "egnn_debug_stamps": (_i, [_vp, C.POINTER(C.c_uint64)]),
     "egnn_profile_enable": (_i, [_vp, _i]),
     "egnn_profile_read": (_i, [_vp, _fp, C.POINTER(_i), _fp]),

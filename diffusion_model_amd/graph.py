@@ -80,3 +80,74 @@ class GraphPlan:
         self.batch = batch
         if self.E > 0 and bool((batch[row] != batch[col]).any()):
             raise ValueError("an edge connects two different graphs")
+
+
+def _plan_from_sizes(sizes, device):
+    from . import _lib
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("device graph construction needs an AMD GPU ('cuda' device); there is no CPU fallback")
+    sz = torch.as_tensor(list(sizes), dtype=torch.long)
+    if sz.numel() == 0 or int(sz.min()) < 1:
+        raise ValueError("every graph needs at least one atom")
+    plan = GraphPlan.__new__(GraphPlan)
+    plan.N, plan.B = int(sz.sum()), int(sz.numel())
+    gp = torch.zeros(plan.B + 1, dtype=torch.int64)
+    gp[1:] = torch.cumsum(sz, 0)
+    plan.graph_ptr = gp.to(torch.int32).to(dev)
+    plan.batch = torch.repeat_interleave(torch.arange(plan.B), sz).to(dev)
+    plan.node_graph = plan.batch.to(torch.int32).contiguous()
+    plan._sizes = sz
+    return plan, _lib
+
+
+def fully_connected_plan(sizes: Sequence[int], device="cuda") -> "GraphPlan":
+    """GraphPlan of fully connected graphs built by the device kernels (egnn_fc_graph_build): same edge set
+    and order as ``fully_connected_edge_index`` without materialising an int64 edge_index on the host."""
+    plan, _lib = _plan_from_sizes(sizes, device)
+    sz = plan._sizes
+    per = sz * (sz - 1)
+    base = torch.zeros(plan.B, dtype=torch.int64)
+    base[1:] = torch.cumsum(per, 0)[:-1]
+    plan.E = int(per.sum())
+    if plan.E >= 2 ** 31:
+        raise ValueError("more than 2^31 edges")
+    dev = plan.graph_ptr.device
+    base_d = base.to(dev)
+    plan.row_ptr = torch.empty(plan.N + 1, dtype=torch.int32, device=dev)
+    plan.edge_dst = torch.empty(max(plan.E, 1), dtype=torch.int32, device=dev)[:plan.E]
+    plan.edge_src = torch.empty(max(plan.E, 1), dtype=torch.int32, device=dev)[:plan.E]
+    _lib.check(_lib.lib().egnn_fc_graph_build(_lib.stream_ptr(), plan.N, plan.B, _lib.ptr(plan.graph_ptr),
+                                              _lib.ptr(plan.node_graph), _lib.ptr(base_d), _lib.ptr(plan.row_ptr),
+                                              _lib.ptr(plan.edge_dst) if plan.E else None,
+                                              _lib.ptr(plan.edge_src) if plan.E else None))
+    plan._keep = base_d
+    return plan
+
+
+def radius_plan(x: torch.Tensor, sizes: Sequence[int], radius: float) -> "GraphPlan":
+    """GraphPlan of radius graphs |x_i - x_j| < radius inside each graph (BASELINE configs[4]; the reference
+    only has fully connected graphs)."""
+    plan, _lib = _plan_from_sizes(sizes, x.device)
+    if x.shape != (plan.N, 3):
+        raise ValueError("x must be [N, 3]")
+    xc = x.detach().to(torch.float32).contiguous()
+    dev = xc.device
+    deg = torch.empty(plan.N, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().egnn_radius_graph_count(_lib.stream_ptr(), plan.N, _lib.ptr(xc), _lib.ptr(plan.graph_ptr),
+                                                  _lib.ptr(plan.node_graph), float(radius), _lib.ptr(deg)))
+    plan.row_ptr = torch.zeros(plan.N + 1, dtype=torch.int32, device=dev)
+    plan.row_ptr[1:] = torch.cumsum(deg.long(), 0).to(torch.int32)
+    plan.E = int(plan.row_ptr[-1].item())
+    plan.edge_dst = torch.empty(max(plan.E, 1), dtype=torch.int32, device=dev)[:plan.E]
+    plan.edge_src = torch.empty(max(plan.E, 1), dtype=torch.int32, device=dev)[:plan.E]
+    if plan.E:
+        _lib.check(_lib.lib().egnn_radius_graph_fill(_lib.stream_ptr(), plan.N, _lib.ptr(xc), _lib.ptr(plan.graph_ptr),
+                                                     _lib.ptr(plan.node_graph), float(radius), _lib.ptr(plan.row_ptr),
+                                                     _lib.ptr(plan.edge_dst), _lib.ptr(plan.edge_src)))
+    return plan
+
+
+def plan_edge_index(plan: "GraphPlan") -> torch.Tensor:
+    """int64 [2, E] edge_index (row 0 = receiving node) of a plan, for code that expects the reference layout."""
+    return torch.stack((plan.edge_dst.long(), plan.edge_src.long()))

@@ -14,7 +14,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
-from .graph import GraphPlan, fully_connected_edge_index
+from .graph import GraphPlan, fully_connected_edge_index, fully_connected_plan
 
 
 class DeviceSampler:
@@ -46,8 +46,10 @@ class DeviceSampler:
             if cond is None or tuple(cond.shape) != (self.N, ncond):
                 raise ValueError(f"cond must be [{self.N}, {ncond}]")
             cond = cond.detach().to(self.device, torch.float32).contiguous()
-        ei = edge_index if edge_index is not None else fully_connected_edge_index(self.sizes, device=self.device)
-        self.plan = GraphPlan(ei.to(self.device), self.N, sizes=self.sizes)
+        if edge_index is None:
+            self.plan = fully_connected_plan(self.sizes, self.device)       # built by the device kernels
+        else:
+            self.plan = GraphPlan(edge_index.to(self.device), self.N, sizes=self.sizes)
         self.ctx = egnn.context_for(self.plan)
         self.table = diffusion_process.step_table(self.device)
         self.stream = torch.cuda.Stream(device=self.device)

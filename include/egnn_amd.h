@@ -142,6 +142,31 @@ int egnn_sampler_final(egnn_ctx* ctx, void* stream, int prec, int norm_scope,
 int egnn_sampler_state(egnn_ctx* ctx, void* stream, float* d_pos, float* d_x_types,
                        int32_t* d_bad_flags, int* t_host);
 
+/* ---- graph construction ----------------------------------------------------------
+ * Fully connected graphs in the edge kernels' CSR layout: node i receives from every j != i of its graph,
+ * j ascending -- the edge set and order of parts/train_per_iretation.py:308-313 /
+ * split_to_train_and_test.py:88-92 with PyG collate offsets.  d_edge_base int64[B] = number of edges of
+ * the graphs before g (host prefix sum of n(n-1)); edge arrays may be NULL to fill row_ptr only. */
+int egnn_fc_graph_build(void* stream, int N, int B, const int32_t* d_graph_ptr, const int32_t* d_node_graph,
+                        const int64_t* d_edge_base, int32_t* d_row_ptr, int32_t* d_edge_dst, int32_t* d_edge_src);
+/* Radius graph (not a reference feature; BASELINE configs[4]): pass 1 counts neighbours with |x_i-x_j| < r
+ * inside each graph, the caller prefix-sums deg into row_ptr, pass 2 fills the CSR edge list. */
+int egnn_radius_graph_count(void* stream, int N, const float* d_x, const int32_t* d_graph_ptr,
+                            const int32_t* d_node_graph, float radius, int32_t* d_deg);
+int egnn_radius_graph_fill(void* stream, int N, const float* d_x, const int32_t* d_graph_ptr,
+                           const int32_t* d_node_graph, float radius, const int32_t* d_row_ptr,
+                           int32_t* d_edge_dst, int32_t* d_edge_src);
+
+/* ---- evaluation statistics -------------------------------------------------------
+ * RDF(position, sigma, R, dR, Normalize) about atom 0 of every graph (evaluate_RDF.py:39-60), out
+ * float[B, nbins], nbins = number of entries of np.arange(dR, R + dR, dR). */
+int egnn_rdf(void* stream, int B, const float* d_pos, const int32_t* d_graph_ptr, float R, float dR, float sigma,
+             int normalize, int nbins, float* d_out);
+/* Si-O-Si selection + CN2 angle / bond lengths (evaluate_Si-O-Si.py:23-53, CN2_evaluate.py:12-21):
+ * out float[B,4] = {valid, angle in degrees, |r1-r0|, |r2-r0|}; onehot int32 [N, A], Si = [0,1]. */
+int egnn_si_o_si(void* stream, int B, int A, const float* d_pos, const int32_t* d_onehot,
+                 const int32_t* d_graph_ptr, float cutoff, float* d_out);
+
 /* timing helper for bench.py: average duration (ms) of the fused edge kernel over the launches
  * recorded since the last reset, measured with HIP events on the launch stream. */
 /* diagnostic builds only (-DEGNN_EXP_STAMP): s_memtime stamps [2][8][32][4] of one edge workgroup */

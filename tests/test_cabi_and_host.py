@@ -135,3 +135,38 @@ def test_gamma_and_compressor_modules_match_reference():
     a = torch.stack([proc.alpha(t) for t in range(21)])
     s = torch.stack([proc.sigma(t) for t in range(21)])
     assert torch.allclose(a ** 2 + s ** 2, torch.ones(21), atol=1e-6) and bool((a[1:] <= a[:-1]).all())
+
+
+def test_radam_schedule_free_properties():
+    """RAdamScheduleFree (parity unpinned: the schedulefree package is absent): train/eval round trip is
+    the identity, the silent phase leaves the weights untouched, and it minimises a quadratic."""
+    torch.manual_seed(0)
+    w = torch.nn.Parameter(torch.randn(6))
+    target = torch.arange(6.0)
+    opt = dma.RAdamScheduleFree([w], lr=0.05)
+    with pytest.raises(RuntimeError):
+        opt.step()
+    opt.train()
+    w0 = w.detach().clone()
+    for k in range(4):                      # rho_t <= 4 for the first 4 steps (beta2 = 0.999): silent phase, lr = 0
+        opt.zero_grad()
+        ((w - target) ** 2).sum().backward()
+        opt.step()
+        assert opt.param_groups[0]["scheduled_lr"] == 0.0
+    assert torch.equal(w.detach(), w0)
+    for k in range(600):
+        opt.zero_grad()
+        ((w - target) ** 2).sum().backward()
+        opt.step()
+    y = w.detach().clone()
+    opt.eval()
+    x = w.detach().clone()
+    opt.train()
+    assert torch.allclose(w.detach(), y, atol=1e-6)           # round trip
+    opt.eval()
+    assert torch.allclose(w.detach(), x, atol=1e-6)
+    assert float(((x - target) ** 2).sum()) < 1e-2            # averaged iterate converged
+    params = dict(lr=1e-5, weight_decay=1e-12, to_compress_spectrum=False, noise_schedule="predefined")
+    nn_dict = {"egnn": torch.nn.Linear(3, 3)}
+    assert isinstance(dma.define_optimizer(params, nn_dict, None, "RAdamScheduleFree"), dma.RAdamScheduleFree)
+    assert isinstance(dma.define_optimizer(params, nn_dict, None, "AdamW"), torch.optim.AdamW)

@@ -1,0 +1,108 @@
+"""GPU tests: device graph construction and evaluation statistics against the oracle restatements."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import diffusion_model_amd as dma
+from oracle import aux_ref, egnn_ref
+from tests._util import dims_for, golden_case, load_golden, max_rel
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_fully_connected_plan_matches_python_builder():
+    for sizes in ([5, 1, 9, 3], [64] * 7, [2, 2, 2, 2], [1]):
+        plan = dma.fully_connected_plan(sizes, DEV)
+        ei = egnn_ref.fully_connected_edge_index(sizes)
+        assert plan.E == ei.shape[1]
+        got = dma.plan_edge_index(plan).cpu()
+        assert torch.equal(got, ei)
+        ref = dma.GraphPlan(ei, sum(sizes), sizes=sizes)
+        assert torch.equal(plan.row_ptr.cpu(), ref.row_ptr) and torch.equal(plan.graph_ptr.cpu(), ref.graph_ptr)
+
+
+def test_radius_plan_matches_bruteforce_and_runs_through_the_kernels():
+    g = torch.Generator().manual_seed(0)
+    sizes = [40, 130, 7]
+    n = sum(sizes)
+    x = torch.rand(n, 3, generator=g) * 6.0
+    r = 2.2
+    plan = dma.radius_plan(x.to(DEV), sizes, r)
+    rows, cols, off = [], [], 0
+    for s in sizes:
+        d = torch.cdist(x[off:off + s], x[off:off + s])
+        m = (d < r) & ~torch.eye(s, dtype=torch.bool)
+        i, j = m.nonzero(as_tuple=True)
+        rows.append(i + off)
+        cols.append(j + off)
+        off += s
+    ei = torch.stack((torch.cat(rows), torch.cat(cols)))
+    got = dma.plan_edge_index(plan).cpu()
+    # identical up to pairs whose distance is within fp32 rounding of r
+    a = set(map(tuple, got.t().tolist()))
+    b = set(map(tuple, ei.t().tolist()))
+    assert len(a ^ b) <= 2
+    # the EGNN forward on the radius graph equals the oracle on the same edge list
+    G = load_golden("egnn_golden.npz")
+    sd, _, _, _, layers, d = golden_case(G, "g8_H36")
+    net = dma.EquivariantGNN(len(layers), **d)
+    net.load_state_dict(sd)
+    net.to(DEV).eval()
+    h = torch.randn(n, 36, generator=g)
+    with torch.no_grad():
+        ho, xo = net(got.to(DEV), h.to(DEV), x.to(DEV))
+    hr, xr = egnn_ref.egnn_forward(sd, got, h, x)
+    assert max_rel(ho.cpu(), hr) <= 1e-4 and max_rel(xo.cpu(), xr) <= 1e-4
+
+
+def test_rdf_matches_oracle():
+    g = torch.Generator().manual_seed(3)
+    sizes = [64, 17, 30]
+    pos = torch.randn(sum(sizes), 3, generator=g) * 2.0
+    out = dma.stats.rdf(pos.to(DEV), sizes).cpu().numpy()
+    assert out.shape == (3, 500)
+    off = 0
+    for k, s in enumerate(sizes):
+        ref = aux_ref.rdf_about_atom0(pos[off:off + s])
+        assert np.abs(out[k] - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+        off += s
+    one = dma.stats.rdf(pos[:64].to(DEV), Normalize=True).cpu().numpy()
+    refn = aux_ref.rdf_about_atom0(pos[:64], normalize=True)
+    assert np.abs(one - refn).max() <= 1e-5
+    assert abs(dma.stats.cos_similarity(out[0], out[0]) - 1.0) < 1e-12
+
+
+def test_si_o_si_matches_oracle():
+    sizes, poss, ohs, want = [], [], [], []
+    for ang in (180.0, 90.0, 144.0):
+        a = math.radians(ang)
+        poss.append(torch.tensor([[0.0, 0, 0], [1.62, 0, 0], [1.6 * math.cos(a), 1.6 * math.sin(a), 0], [4.0, 4.0, 4.0]]))
+        ohs.append(torch.tensor([[1, 0], [0, 1], [0, 1], [1, 0]]))
+        sizes.append(4)
+        want.append((True, ang, 1.61))
+    # three neighbours -> rejected; an O neighbour -> rejected
+    poss.append(torch.tensor([[0.0, 0, 0], [1.6, 0, 0], [0, 1.6, 0], [0, 0, 1.6]]))
+    ohs.append(torch.tensor([[1, 0], [0, 1], [0, 1], [0, 1]]))
+    sizes.append(4)
+    want.append((False, 0, 0))
+    poss.append(torch.tensor([[0.0, 0, 0], [1.6, 0, 0], [0, 1.6, 0]]))
+    ohs.append(torch.tensor([[1, 0], [0, 1], [1, 0]]))
+    sizes.append(3)
+    want.append((False, 0, 0))
+    pos, oh = torch.cat(poss), torch.cat(ohs)
+    valid, ang, ln = dma.stats.si_o_si(pos.to(DEV), oh.to(DEV), sizes)
+    off = 0
+    for k, (v, a, l) in enumerate(want):
+        assert bool(valid[k]) == v
+        sel = aux_ref.select_si_o_si(pos[off:off + sizes[k]], oh[off:off + sizes[k]])
+        assert (sel is not None) == v
+        if v:
+            assert abs(float(ang[k]) - aux_ref.angle_cn2(sel)) < 1e-2
+            l1, l2 = aux_ref.bond_lengths_cn2(sel)
+            assert abs(float(ln[k]) - 0.5 * (l1 + l2)) < 1e-5
+        off += sizes[k]
+    res = dma.stats.compare_si_o_si(pos.to(DEV), oh.to(DEV), pos.to(DEV), oh.to(DEV), sizes)
+    assert res["n_selected"] == 3 and abs(res["r2_angle"] - 1.0) < 1e-9
