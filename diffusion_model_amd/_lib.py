@@ -24,6 +24,8 @@ SIGNATURES = {
     "egnn_pack_layer": (_i, [_vp, _vp, _i] + [_vp] * 16),
     "egnn_set_graph": (_i, [_vp, _i, _i, _i] + [_vp] * 5),
     "egcl_forward": (_i, [_vp, _vp, _i, _i, _i] + [_vp] * 4),
+    "egcl_forward_begin": (_i, [_vp, _vp, _i, _i, _i] + [_vp] * 3),
+    "egcl_forward_end": (_i, [_vp, _vp, _i, _i, _i] + [_vp] * 5),
     "egnn_forward": (_i, [_vp, _vp, _i, _i] + [_vp] * 4),
     "egnn_eps": (_i, [_vp, _i, _i, _i, _vp, _i] + [_vp] * 5),
     "egnn_remove_mean": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),

@@ -94,7 +94,8 @@ struct egnn_ctx {
   float* part_m = nullptr;   // [tiles][2][MP]
   float* part_x = nullptr;   // [tiles][2][4]
   float* node_d2 = nullptr;  // [N]
-  float* gscale = nullptr;   // [B] 1/(G+1)
+  float* gscale = nullptr;   // [B] sum of d^2 per graph (G^2); node_post applies 1/(G+1)
+  int last_R = 64, last_nsplit_x = 1;   // edge path chosen by the last launch_layer_begin
   unsigned long long* stamps = nullptr;  // [2 kernels][8 waves][32 chunks][4] diagnostic time stamps
   float* h_tmp[2] = {nullptr, nullptr};  // [N][H] ping-pong between layers
   float* x_tmp[2] = {nullptr, nullptr};  // [N][3]

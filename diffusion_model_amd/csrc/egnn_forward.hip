@@ -137,8 +137,9 @@ __global__ void node_d2_kernel(const float* __restrict__ x, const int* __restric
   }
   node_d2[n] = s;
 }
-// gscale[g] = 1 / (sqrt(sum_{n in g} node_d2[n]) + 1); one workgroup per graph (or one in 'call' scope)
-__global__ __launch_bounds__(kThreads) void graph_scale_kernel(const float* __restrict__ node_d2,
+// gsum[g] = sum_{n in g} node_d2[n] (= G^2 of the graph, or of the whole call in 'call' scope); node_post turns
+// it into 1 / (G + 1).  One workgroup per graph, fixed summation order.
+__global__ __launch_bounds__(kThreads) void graph_sum_kernel(const float* __restrict__ node_d2,
                                                                const int* __restrict__ graph_ptr, int N,
                                                                int per_graph, float* __restrict__ gscale) {
   __shared__ float red[kThreads];
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(kThreads) void graph_scale_kernel(const float* __re
     if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
     __syncthreads();
   }
-  if (threadIdx.x == 0) gscale[blockIdx.x] = 1.0f / (sqrtf(red[0]) + 1.0f);
+  if (threadIdx.x == 0) gscale[blockIdx.x] = red[0];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(kThreads, 1) void node_post_kernel(const PostParams
           }
         }
       }
-      const float g = p.gscale[p.per_graph ? p.node_graph[n] : 0];
+      const float g = 1.0f / (sqrtf(p.gscale[p.per_graph ? p.node_graph[n] : 0]) + 1.0f);
       p.x_out[3 * n + d] = p.x[3 * n + d] + v * g;
     }
   }
@@ -721,8 +722,10 @@ static int launch_edge(const EdgeParams& p, int tiles, size_t smem, hipStream_t 
   return EGNN_OK;
 }
 
-int launch_layer(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_scope, const float* h,
-                 const float* x, float* h_out, float* x_out) {
+// Stage 1 of a layer: node_pre, squared-distance sums and the fused edge pass.  gsum (c->gscale) then holds the
+// sum of d^2 over the edges THIS context received, per graph (or per call).
+int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_scope, const float* h,
+                       const float* x) {
   const LayerPack& lp = c->layers[layer];
   if (!lp.packed) { set_error("layer %d has no packed parameters", layer); return EGNN_ESTATE; }
   const int N = c->N, E = c->E;
@@ -773,7 +776,7 @@ int launch_layer(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_scop
                        c->H, w1catT, b1cat, c->TC, c->table);
     hipLaunchKernelGGL(node_d2_kernel, dim3((N + 255) / 256), dim3(256), 0, st, x, c->row_ptr, c->edge_src, N,
                        c->node_d2);
-    hipLaunchKernelGGL(graph_scale_kernel, dim3(per_graph ? c->B : 1), dim3(kThreads), 0, st, c->node_d2,
+    hipLaunchKernelGGL(graph_sum_kernel, dim3(per_graph ? c->B : 1), dim3(kThreads), 0, st, c->node_d2,
                        c->graph_ptr, N, per_graph, c->gscale);
   }
   prof_end(c, st);
@@ -795,6 +798,18 @@ int launch_layer(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_scop
     if (rc) return rc;
   }
 
+  c->last_R = R; c->last_nsplit_x = nsplit_x;
+  return EGNN_OK;
+}
+
+// Stage 2: node_post with the normaliser sums in c->gscale (possibly replaced by a cross-rank total).
+int launch_layer_end(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_scope, const float* h, const float* x,
+                     float* h_out, float* x_out) {
+  const LayerPack& lp = c->layers[layer];
+  const int N = c->N, R = c->last_R, nsplit_x = c->last_nsplit_x;
+  const size_t agg_x_stride = (size_t)c->cap_nodes * 4, part_x_stride = (c->cap_tiles + 1) * 2 * 4;
+  const int per_graph = norm_scope == EGNN_NORM_GRAPH;
+  (void)prec;
   {
     PostParams q;
     q.N = N; q.H = c->H; q.MP = c->MP; q.K1P = c->K1P; q.WhP = c->WhP; q.HP = c->HP; q.R = R;
@@ -811,6 +826,13 @@ int launch_layer(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_scop
     EGNN_HIP(hipGetLastError());
   }
   return EGNN_OK;
+}
+
+int launch_layer(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_scope, const float* h,
+                 const float* x, float* h_out, float* x_out) {
+  int rc = launch_layer_begin(c, st, layer, prec, norm_scope, h, x);
+  if (rc) return rc;
+  return launch_layer_end(c, st, layer, prec, norm_scope, h, x, h_out, x_out);
 }
 
 }  // namespace egnn
@@ -1010,6 +1032,34 @@ int egcl_forward(egnn_ctx* c, void* stream, int layer, int prec, int norm_scope,
     return EGNN_EINVAL;
   }
   return launch_layer(c, reinterpret_cast<hipStream_t>(stream), layer, prec, norm_scope, h, x, h_out, x_out);
+}
+
+int egcl_forward_begin(egnn_ctx* c, void* stream, int layer, int prec, int norm_scope, const float* h, const float* x,
+                       float* d_sq_sums) {
+  int rc = check_ready(c, prec, norm_scope);
+  if (rc) return rc;
+  if (layer < 0 || layer >= c->L || !h || !x) { set_error("bad egcl_forward_begin arguments"); return EGNN_EINVAL; }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if ((rc = launch_layer_begin(c, st, layer, prec, norm_scope, h, x))) return rc;
+  if (d_sq_sums)
+    EGNN_HIP(hipMemcpyAsync(d_sq_sums, c->gscale, sizeof(float) * (norm_scope == EGNN_NORM_GRAPH ? c->B : 1),
+                            hipMemcpyDeviceToDevice, st));
+  return EGNN_OK;
+}
+
+int egcl_forward_end(egnn_ctx* c, void* stream, int layer, int prec, int norm_scope, const float* h, const float* x,
+                     const float* d_sq_sums, float* h_out, float* x_out) {
+  int rc = check_ready(c, prec, norm_scope);
+  if (rc) return rc;
+  if (layer < 0 || layer >= c->L || !h || !x || !h_out || !x_out || h == h_out || x == x_out) {
+    set_error("bad egcl_forward_end arguments");
+    return EGNN_EINVAL;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (d_sq_sums)
+    EGNN_HIP(hipMemcpyAsync(c->gscale, d_sq_sums, sizeof(float) * (norm_scope == EGNN_NORM_GRAPH ? c->B : 1),
+                            hipMemcpyDeviceToDevice, st));
+  return launch_layer_end(c, st, layer, prec, norm_scope, h, x, h_out, x_out);
 }
 
 int egnn_forward(egnn_ctx* c, void* stream, int prec, int norm_scope, const float* h, const float* x, float* h_out,

@@ -85,6 +85,17 @@ int egnn_set_graph(egnn_ctx* ctx, int N, int E, int B,
 int egcl_forward(egnn_ctx* ctx, void* stream, int layer, int prec, int norm_scope,
                  const float* d_h, const float* d_x, float* d_h_out, float* d_x_out);
 
+/* The same layer in two stages, for one large graph whose receiving nodes are partitioned over ranks
+ * (BASELINE configs[4]): each rank sets a graph that holds only the edges its nodes receive.
+ * _begin runs node_pre + the fused edge pass and returns this rank's sums of d^2 (float[B], or [1] in 'call'
+ * scope); the caller all-reduces them (the coordinate normaliser of :64 spans all edges) and passes the
+ * totals to _end, which runs node_post; rows of nodes the rank does not own are meaningless and the caller
+ * all-gathers the owned rows.  d_sq_sums may be NULL (single rank: use the local sums). */
+int egcl_forward_begin(egnn_ctx* ctx, void* stream, int layer, int prec, int norm_scope,
+                       const float* d_h, const float* d_x, float* d_sq_sums);
+int egcl_forward_end(egnn_ctx* ctx, void* stream, int layer, int prec, int norm_scope,
+                     const float* d_h, const float* d_x, const float* d_sq_sums, float* d_h_out, float* d_x_out);
+
 /* EquivariantGNN.forward(edge_index, h, x) -> (h_L, x_L) (:85-88): all L layers. */
 int egnn_forward(egnn_ctx* ctx, void* stream, int prec, int norm_scope,
                  const float* d_h, const float* d_x, float* d_h_out, float* d_x_out);

@@ -119,3 +119,47 @@ def test_gradient_allreduce_world_size_2_gloo(tmp_path):
     res = torch.load(out, weights_only=True)
     assert res["n_global"] == 8
     assert max(res["errs"]) < 1e-6
+
+
+def _part_worker(rank, world, port, out):
+    """partitioned_forward's communication pattern with gloo on CPU: the two stage calls are replaced by an
+    oracle-based stand-in (no GPU here); checks that all-reduced sums + all-gathered rows reproduce the
+    unpartitioned layer stack."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import egnn_ref
+    from diffusion_model_amd import partition
+    torch.manual_seed(0)
+    n, H = 23, 5
+    d = dims_for(H, 8, 16, 16, 16)
+    sd = egnn_ref.init_state_dict(2, **d, seed=3)
+    g = torch.Generator().manual_seed(4)
+    h, x = torch.randn(n, H, generator=g), torch.randn(n, 3, generator=g)
+    ei = egnn_ref.fully_connected_edge_index(n)
+    ranges = partition.node_ranges(n, world)
+    lo, hi = ranges[rank]
+    keep = (ei[0] >= lo) & (ei[0] < hi)
+    ei_loc = ei[:, keep]
+    hc, xc = h, x
+    for l in range(2):
+        diff = xc[ei_loc[0]] - xc[ei_loc[1]]
+        S = (diff * diff).sum().reshape(1)
+        S = partition._allreduce_default(S, None)
+        # one layer with the GLOBAL normaliser: run the oracle on the local edges with G patched in
+        ho, xo = egnn_ref.egcl_forward(sd, l, ei_loc, hc, xc)
+        G_loc = torch.norm(diff)
+        xo = xc + (xo - xc) * (G_loc + 1) / (torch.sqrt(S[0]) + 1)
+        hc = partition._allgather_default(ho[lo:hi], ranges, None)
+        xc = partition._allgather_default(xo[lo:hi], ranges, None)
+    if rank == 0:
+        h_ref, x_ref = egnn_ref.egnn_forward(sd, ei, h, x)
+        torch.save({"eh": float((hc - h_ref).abs().max()), "ex": float((xc - x_ref).abs().max())}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_partitioned_exchange_world_size_2_gloo(tmp_path):
+    out = str(tmp_path / "p.pt")
+    mp.spawn(_part_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    res = torch.load(out, weights_only=True)
+    assert res["eh"] < 1e-4 and res["ex"] < 1e-4
