@@ -10,7 +10,8 @@ from .optim import RAdamScheduleFree, define_optimizer  # noqa: F401
 from .sampler import DeviceSampler, generate  # noqa: F401
 from .preprocessor import SpectrumCompressor  # noqa: F401
 from .snr import GammaNetwork, PositiveLinear  # noqa: F401
-from .training import GradAllReducer, diffuse_as_batch, train_step, training_loss  # noqa: F401
+from .training import GradAllReducer, diffuse_as_batch, eval_epoch, train_epoch, train_step, training_loss  # noqa: F401
+from .checkpoint import load_model_state, save_model_state  # noqa: F401
 
 __all__ = ["EGCL", "EquivariantGNN", "E3DiffusionProcess", "remove_mean", "GraphPlan",
            "fully_connected_edge_index", "DeviceSampler", "generate", "SpectrumCompressor",

@@ -129,3 +129,45 @@ def train_step(nn_dict, data, params, diffusion_process, optimizer, reducer: Opt
         reducer.reduce()
     optimizer.step()
     return loss.detach()
+
+
+def _epoch(nn_dict, loader, params, diffusion_process, optimizer, train: bool, reducer=None):
+    egnn = nn_dict["egnn"]
+    egnn.train(train)
+    if params.get("optimizer") == "RAdamScheduleFree":
+        (optimizer.train if train else optimizer.eval)()
+    if params.get("to_compress_spectrum"):
+        nn_dict["spectrum_compressor"].train(train)
+    total, nodes = 0.0, 0
+    for data in loader:
+        nb = int(data.batch.max().item()) + 1
+        nodes += data.pos.shape[0]
+        if train:
+            loss = train_step(nn_dict, data, params, diffusion_process, optimizer, reducer)
+        else:
+            with torch.no_grad():
+                noised = diffuse_as_batch(data.pos, data.x, data.batch, diffusion_process)
+                cols = []
+                if params["conditional"]:
+                    spec = data.spectrum.float()
+                    if params["to_compress_spectrum"]:
+                        spec = nn_dict["spectrum_compressor"](spec)
+                    cols.append(spec)
+                if params["give_exO"]:
+                    cols.append(data.exO.float())
+                cond = torch.cat(cols, dim=1) if cols else None
+                loss, _, _ = training_loss(egnn, data.edge_index, data.batch, noised, cond, params["atom_type_size"])
+        total += float(loss) * nb                     # the reference re-multiplies by num_graph (:178)
+    return total / max(nodes, 1)                      # average per node (:181)
+
+
+def train_epoch(nn_dict, train_loader, params, diffusion_process, optimizer, reducer=None):
+    """train_epoch(nn_dict, train_loader, params, diffusion_process, optimizer) -> average loss per node
+    (parts/train_per_iretation.py:99-183); ``train_loader`` yields collated batches with .pos .x .batch
+    .edge_index (.spectrum .exO)."""
+    return _epoch(nn_dict, train_loader, params, diffusion_process, optimizer, True, reducer)
+
+
+def eval_epoch(nn_dict, eval_loader, params, diffusion_process, optimizer):
+    """eval_epoch (parts/train_per_iretation.py:185-262)."""
+    return _epoch(nn_dict, eval_loader, params, diffusion_process, optimizer, False)

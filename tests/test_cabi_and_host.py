@@ -170,3 +170,26 @@ def test_radam_schedule_free_properties():
     nn_dict = {"egnn": torch.nn.Linear(3, 3)}
     assert isinstance(dma.define_optimizer(params, nn_dict, None, "RAdamScheduleFree"), dma.RAdamScheduleFree)
     assert isinstance(dma.define_optimizer(params, nn_dict, None, "AdamW"), torch.optim.AdamW)
+
+
+def test_checkpoint_contract(tmp_path):
+    """the reference's checkpoint dict ('egnn', 'spectrum_compressor', 'gamma' / legacy 'GammaNetwork') loads"""
+    d = dims_for(36, 128, 256, 256, 256)
+    params = dict(to_compress_spectrum=True, noise_schedule="learned")
+    torch.manual_seed(1)
+    src = {"egnn": dma.EquivariantGNN(2, **d), "spectrum_compressor": dma.SpectrumCompressor(200, [150, 100, 50], 32),
+           "gamma": dma.GammaNetwork()}
+    path = str(tmp_path / "model.pth")
+    dma.save_model_state(src, path, params)
+    raw = torch.load(path, weights_only=True)
+    assert sorted(raw) == ["egnn", "gamma", "spectrum_compressor"]
+    torch.manual_seed(2)
+    dst = {"egnn": dma.EquivariantGNN(2, **d), "spectrum_compressor": dma.SpectrumCompressor(200, [150, 100, 50], 32),
+           "gamma": dma.GammaNetwork()}
+    dma.load_model_state(dst, path, params)
+    for k in src:
+        for (n1, a), (n2, b) in zip(src[k].state_dict().items(), dst[k].state_dict().items()):
+            assert n1 == n2 and torch.equal(a, b)
+    raw["GammaNetwork"] = raw.pop("gamma")                       # layout written by train.py:358-366
+    torch.save(raw, path)
+    dma.load_model_state(dst, path, params)

@@ -155,3 +155,32 @@ def test_node_partitioned_forward_equals_full_forward():
     h1, x1 = dma.partition.partitioned_forward(nets[0], full, h.to(DEV), x.to(DEV), 0, [(0, n)],
                                                allreduce=lambda t, g: t, allgather=lambda rows, rg, g: rows)
     assert max_rel(h1.cpu(), h_ref.cpu()) <= 1e-6 and max_rel(x1.cpu(), x_ref.cpu()) <= 1e-6
+
+
+def test_c3_size_512_atom_graphs():
+    """BASELINE configs[2] shape: 512-atom fully connected graphs (degree 511 spans several edge tiles, so
+    every node goes through the tile-partial path), small widths so the CPU oracle finishes in seconds."""
+    G = load_golden("egnn_golden.npz")
+    sd, _, _, _, layers, d = golden_case(G, "g8_H36")
+    g = torch.Generator().manual_seed(12)
+    sizes = [512, 512]
+    n = sum(sizes)
+    side = 8
+    grid = torch.stack(torch.meshgrid(*[torch.arange(side, dtype=torch.float32)] * 3, indexing="ij"), -1).reshape(-1, 3) * 1.6
+    x = grid.repeat(2, 1) + 0.1 * torch.randn(n, 3, generator=g)
+    h = torch.randn(n, 36, generator=g)
+    plan = dma.fully_connected_plan(sizes, DEV)
+    assert plan.E == 2 * 512 * 511
+    ei = dma.plan_edge_index(plan)
+    batch = plan.batch
+    ho, xo = egnn_ref.egnn_forward(sd, ei.cpu(), h, x, "graph", torch.tensor([0, 512, 1024]))
+    for prec, tol in (("fp32", 1e-4), ("bf16", 5e-2)):
+        net = dma.EquivariantGNN(len(layers), **d)
+        net.load_state_dict(sd)
+        net.to(DEV).eval()
+        net.precision, net.norm_scope = prec, "graph"
+        with torch.no_grad():
+            hg, xg = net(ei, h.to(DEV), x.to(DEV), batch=batch)
+        eh = float((hg.cpu() - ho).norm() / ho.norm())
+        ex = float(((xg.cpu() - x) - (xo - x)).norm() / (xo - x).norm())
+        assert eh <= tol and ex <= tol, (prec, eh, ex)
