@@ -53,6 +53,8 @@ struct LayerPack {
   float* sc = nullptr;       // [w1catT_s | b1cat_s | wdx_s | wdm_s | b2x_s | w3x_s | b2m_s | wa_s]
   void* w2x_bf16s = nullptr;
   void* w2m_bf16s = nullptr;
+  void* w1h_bf16 = nullptr;   // mlp_h.0 bf16 fragments (N = WhP, K = K1Q)
+  void* w2h_bf16p = nullptr;  // mlp_h.2 bf16 fragments, k in accumulator-row order
 };
 
 struct Sampler {
@@ -79,7 +81,7 @@ struct egnn_ctx {
   int device = 0;
   // model
   int L = 0, H = 0, M = 0, Wm = 0, Wx = 0, Wh = 0;
-  int WxP = 0, WmP = 0, MP = 0, WhP = 0, HP = 0, K1P = 0, TC = 0;
+  int WxP = 0, WmP = 0, MP = 0, WhP = 0, HP = 0, K1P = 0, K1Q = 0, TC = 0;
   int cbx = 0, cbm = 0;  // 32-column blocks per wave for the x / m second-layer GEMMs
   std::vector<egnn::LayerPack> layers;
   // graph

@@ -66,6 +66,21 @@ __global__ void pack_frags_bf16(const float* __restrict__ W, int Nout, int K, in
     out[i] = (__bf16)((n < Nout && k < K) ? W[(size_t)n * ldw + k] * scale : 0.f);
   }
 }
+// mlp_h.2 as the A operand of out^T = W2h . hidden^T where hidden^T comes straight from an accumulator tile:
+// element j of lane half hh in k-step ks is hidden unit 32*(ks/2) + 16*(ks%2) + 8*(j>>2) + 4*hh + (j&3).
+__global__ void pack_frags_bf16_accperm(const float* __restrict__ W, int Nout, int K, int ldw, int NP, int KP,
+                                        __bf16* __restrict__ out) {
+  const int KS = KP / 16;
+  const size_t total = (size_t)(NP / 32) * KS * 64 * 8;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int j = i & 7, lane = (i >> 3) & 63;
+    const size_t f = i >> 9;
+    const int ks = f % KS, nb = f / KS;
+    const int n = 32 * nb + (lane & 31);
+    const int k = 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
+    out[i] = (__bf16)((n < Nout && k < K) ? W[(size_t)n * ldw + k] : 0.f);
+  }
+}
 __global__ void scale_copy(const float* __restrict__ src, size_t n, float scale, float* __restrict__ dst) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i] * scale;
 }
@@ -121,6 +136,56 @@ __global__ __launch_bounds__(kThreads) void node_pre_kernel(const float* __restr
 #pragma unroll
   for (int i = 0; i < kPreNodes; ++i)
     if (n0 + i < N) table[(size_t)(n0 + i) * TC + col] = acc[i];
+}
+
+// The same table on the matrix cores: exact fp32 v_mfma_f32_32x32x2_f32 (K = H is tiny, the kernel is bound by
+// the 268 MB table write).  Workgroup = 32 nodes x 512 columns, wave w owns 4 column blocks; A = h tile from LDS,
+// B = w1catT rows straight from L2 (128 B per half-wave, coalesced), accumulator initialised with the bias.
+constexpr int kPre2Nodes = 32, kPre2Cols = 512;
+__global__ __launch_bounds__(kThreads) void node_pre_mfma_kernel(const float* __restrict__ h, int N, int H,
+                                                                 const float* __restrict__ w1catT,
+                                                                 const float* __restrict__ b1cat, int TC,
+                                                                 float* __restrict__ table) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* hs = reinterpret_cast<float*>(smem_raw);  // [HP2][33], HP2 = H rounded up to even
+  const int HP2 = (H + 1) & ~1;
+  const int n0 = blockIdx.x * kPre2Nodes;
+  for (int i = threadIdx.x; i < kPre2Nodes * HP2; i += kThreads) {
+    const int node = i / HP2, k = i % HP2, n = n0 + node;
+    hs[k * 33 + node] = (n < N && k < H) ? h[(size_t)n * H + k] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+  const int col0 = blockIdx.y * kPre2Cols + wave * 128;
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = col0 + 32 * j + r;
+    const float b = col < TC ? b1cat[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = b;
+  }
+  for (int k0 = 0; k0 < HP2; k0 += 2) {
+    const int k = k0 + hh;
+    const float a = hs[k * 33 + r];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = col0 + 32 * j + r;
+      const float b = (k < H && col < TC) ? w1catT[(size_t)k * TC + col] : 0.f;
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = col0 + 32 * j + r;
+    if (col < TC) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int n = n0 + acc_row(i, lane);
+        if (n < N) table[(size_t)n * TC + col] = acc[j][i];
+      }
+    }
+  }
 }
 
 // node_d2[n] = sum over the edges received by n of |x_n - x_src|^2 (fixed order -> deterministic)
@@ -481,21 +546,8 @@ __global__ __launch_bounds__(kThreads, 1) void edge_kernel(const EdgeParams p) {
 // ------------------------------------------------------------------------------------------------
 // node_post: h' = mlp_h([h | sum_m]) (:69), x' = x + sum_x / (G + 1) (:64, :70)
 // ------------------------------------------------------------------------------------------------
-struct PostParams {
-  int N, H, MP, K1P, WhP, HP, R;
-  const float *h, *x;
-  const int *row_ptr, *node_graph;
-  const float *agg_m, *agg_x, *part_m, *part_x, *gscale;
-  size_t agg_x_stride, part_x_stride;
-  int nsplit_x;   // column-split copies of the coordinate sums to add
-  int per_graph;
-  const f32x4 *w1h, *w2h;
-  const float *b1h, *b2h;
-  float *h_out, *x_out;
-};
 constexpr int kPostNodes = 32;
 constexpr int kPostHC = 512;   // hidden columns kept in LDS at a time
-constexpr int kPostMaxOB = 8;  // output column blocks (H <= 256)
 __host__ __device__ inline size_t post_smem_bytes(int K1P, int WhP) {
   const int hc = WhP < kPostHC ? WhP : kPostHC;
   size_t hs = (size_t)hc * 33 * 4, red = (size_t)4 * 16 * 64 * 4;
@@ -711,6 +763,7 @@ int init_kernel_attributes() {
   int rc = init_edge_bf16_v2_attributes();
   if (rc) return rc;
   if ((rc = init_edge_bf16_v3_attributes())) return rc;
+  if ((rc = init_node_bf16_attributes())) return rc;
   done = true;
   return EGNN_OK;
 }
@@ -771,9 +824,16 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
 
   prof_begin(c, st, 1);
   {
-    dim3 grid((N + kPreNodes - 1) / kPreNodes, (c->TC + kThreads - 1) / kThreads);
-    hipLaunchKernelGGL(node_pre_kernel, grid, dim3(kThreads), (size_t)kPreNodes * c->H * sizeof(float), st, h, N,
-                       c->H, w1catT, b1cat, c->TC, c->table);
+    static const int pre_sel = getenv("EGNN_PRE") ? atoi(getenv("EGNN_PRE")) : 2;   // A/B switch
+    if (pre_sel >= 2) {
+      dim3 grid((N + kPre2Nodes - 1) / kPre2Nodes, (c->TC + kPre2Cols - 1) / kPre2Cols);
+      hipLaunchKernelGGL(node_pre_mfma_kernel, grid, dim3(kThreads), (size_t)((c->H + 1) & ~1) * 33 * sizeof(float), st,
+                         h, N, c->H, w1catT, b1cat, c->TC, c->table);
+    } else {
+      dim3 grid((N + kPreNodes - 1) / kPreNodes, (c->TC + kThreads - 1) / kThreads);
+      hipLaunchKernelGGL(node_pre_kernel, grid, dim3(kThreads), (size_t)kPreNodes * c->H * sizeof(float), st, h, N,
+                         c->H, w1catT, b1cat, c->TC, c->table);
+    }
     hipLaunchKernelGGL(node_d2_kernel, dim3((N + 255) / 256), dim3(256), 0, st, x, c->row_ptr, c->edge_src, N,
                        c->node_d2);
     hipLaunchKernelGGL(graph_sum_kernel, dim3(per_graph ? c->B : 1), dim3(kThreads), 0, st, c->node_d2,
@@ -819,9 +879,16 @@ int launch_layer_end(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_
     q.agg_x_stride = agg_x_stride; q.part_x_stride = part_x_stride; q.nsplit_x = nsplit_x;
     q.w1h = reinterpret_cast<const f32x4*>(lp.w1h_f32); q.w2h = reinterpret_cast<const f32x4*>(lp.w2h_f32);
     q.b1h = lp.b1h; q.b2h = lp.b2h; q.h_out = h_out; q.x_out = x_out;
+    q.w1h_bf16 = lp.w1h_bf16; q.w2h_bf16p = lp.w2h_bf16p; q.K1Q = c->K1Q;
+    static const int post_sel = getenv("EGNN_POST") ? atoi(getenv("EGNN_POST")) : 2;   // A/B switch
     prof_begin(c, st, 1);
-    hipLaunchKernelGGL(node_post_kernel, dim3((N + kPostNodes - 1) / kPostNodes), dim3(kThreads),
-                       post_smem_bytes(c->K1P, c->WhP), st, q);
+    if (prec == EGNN_PREC_BF16 && post_sel >= 2 && node_post_bf16_supported(q)) {
+      int rc = launch_node_post_bf16(q, st);
+      if (rc) return rc;
+    } else {
+      hipLaunchKernelGGL(node_post_kernel, dim3((N + kPostNodes - 1) / kPostNodes), dim3(kThreads),
+                         post_smem_bytes(c->K1P, c->WhP), st, q);
+    }
     prof_end(c, st);
     EGNN_HIP(hipGetLastError());
   }
@@ -867,7 +934,7 @@ int egnn_create(egnn_ctx** out, int device) {
 
 static void free_layer(LayerPack& lp) {
   void* ptrs[] = {lp.w1catT, lp.b1cat, lp.wdx, lp.wdm, lp.w2x_f32, lp.w2x_bf16, lp.b2x, lp.w3x, lp.w2m_f32,
-                  lp.w2m_bf16, lp.b2m, lp.wa, lp.scal, lp.w1h_f32, lp.b1h, lp.w2h_f32, lp.b2h, lp.sc, lp.w2x_bf16s, lp.w2m_bf16s};
+                  lp.w2m_bf16, lp.b2m, lp.wa, lp.scal, lp.w1h_f32, lp.b1h, lp.w2h_f32, lp.b2h, lp.sc, lp.w2x_bf16s, lp.w2m_bf16s, lp.w1h_bf16, lp.w2h_bf16p};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   lp = LayerPack();
@@ -913,6 +980,7 @@ int egnn_set_model(egnn_ctx* c, int L, int H, int M, int Wm, int Wx, int Wh) {
   c->WhP = round_up(Wh, 128);
   c->HP = round_up(H, 32);
   c->K1P = round_up(H + c->MP, 8);
+  c->K1Q = round_up(H + c->MP, 16);
   c->TC = 2 * c->WxP + 2 * c->WmP;
   c->cap_nodes = c->cap_tiles = c->cap_graphs = 0;  // MP / TC may have changed
   if (post_smem_bytes(c->K1P, c->WhP) > 160 * 1024 || edge_smem_bytes(64, c->MP) > 160 * 1024) {
@@ -958,6 +1026,10 @@ int egnn_pack_layer(egnn_ctx* c, void* stream, int l, const float* m0_w, const f
     if ((rc = dev_alloc(&lp.b2h, (size_t)HP))) return rc;
     if ((rc = dev_alloc(&lp.sc, (size_t)(H + 1) * TC + 3 * (size_t)WxP + WmP + 2 * (size_t)MP))) return rc;
     tmp = nullptr;
+    if ((rc = dev_alloc(&tmp, (size_t)WhP * c->K1Q))) return rc;
+    lp.w1h_bf16 = tmp; tmp = nullptr;
+    if ((rc = dev_alloc(&tmp, (size_t)HP * WhP))) return rc;
+    lp.w2h_bf16p = tmp; tmp = nullptr;
     if ((rc = dev_alloc(&tmp, (size_t)WxP * WxP))) return rc;
     lp.w2x_bf16s = tmp; tmp = nullptr;
     if ((rc = dev_alloc(&tmp, (size_t)MP * WmP))) return rc;
@@ -995,6 +1067,8 @@ int egnn_pack_layer(egnn_ctx* c, void* stream, int l, const float* m0_w, const f
     hipLaunchKernelGGL(scale_copy, dim3(8), b, 0, st, lp.wa, (size_t)MP, s2, o);
     hipLaunchKernelGGL(pack_frags_bf16, g, b, 0, st, x2_w, Wx, Wx, Wx, WxP, WxP, reinterpret_cast<__bf16*>(lp.w2x_bf16s), s2);
     hipLaunchKernelGGL(pack_frags_bf16, g, b, 0, st, m2_w, M, Wm, Wm, MP, WmP, reinterpret_cast<__bf16*>(lp.w2m_bf16s), s2);
+    hipLaunchKernelGGL(pack_frags_bf16, g, b, 0, st, h0_w, Wh, H + M, H + M, WhP, c->K1Q, reinterpret_cast<__bf16*>(lp.w1h_bf16), 1.0f);
+    hipLaunchKernelGGL(pack_frags_bf16_accperm, g, b, 0, st, h2_w, H, Wh, Wh, HP, WhP, reinterpret_cast<__bf16*>(lp.w2h_bf16p));
   }
   EGNN_HIP(hipGetLastError());
   lp.packed = true;

@@ -142,6 +142,26 @@ __device__ __forceinline__ void unit_finish(const Unit& u, const float* wd, floa
 }
 
 
+constexpr int kPostMaxOB = 8;  // output column blocks of node_post (H <= 256)
+// node_post arguments (fp32 and bf16 variants)
+struct PostParams {
+  int N, H, MP, K1P, WhP, HP, R;
+  const float *h, *x;
+  const int *row_ptr, *node_graph;
+  const float *agg_m, *agg_x, *part_m, *part_x, *gscale;
+  size_t agg_x_stride, part_x_stride;
+  int nsplit_x;   // column-split copies of the coordinate sums to add
+  int per_graph;
+  const f32x4 *w1h, *w2h;
+  const void *w1h_bf16, *w2h_bf16p;   // bf16 node MLP (node_post_bf16_kernel)
+  int K1Q;                            // H + MP rounded up to 16
+  const float *b1h, *b2h;
+  float *h_out, *x_out;
+};
+int launch_node_post_bf16(const PostParams& q, hipStream_t st);
+bool node_post_bf16_supported(const PostParams& q);
+int init_node_bf16_attributes();
+
 int launch_edge_bf16_v2(const EdgeParams& p, int tiles, hipStream_t st);
 int launch_edge_bf16_v3(const EdgeParams& p, hipStream_t st);
 bool edge_bf16_v3_supported(const EdgeParams& p);

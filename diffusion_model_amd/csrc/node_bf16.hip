@@ -1,0 +1,177 @@
+// node_post on bf16 MFMA (throughput mode): h' = mlp_h([h | sum_m]) (EquivariantGraphNeuralNetwork.py:26-30, :69)
+// and x' = x + sum_x / (G + 1) (:64, :70) for 32 nodes per workgroup.
+//
+// Both GEMMs run TRANSPOSED (nodes on the MFMA lanes): hidden^T = W1h . X^T leaves the hidden units in the
+// accumulator registers and the node on the lane, which is exactly the B-operand layout of the second product
+// out^T = W2h . hidden^T, so the 1024-wide hidden activation never touches LDS or HBM: bias + SiLU + bf16 pack
+// happen on the accumulator registers (the k order inside a 16-deep step is the accumulator's row order; W2h is
+// packed with the same permutation).  Each wave owns a quarter of the hidden units; the four partial out^T
+// tiles are added through LDS in a fixed order.
+#include "kernels.h"
+
+namespace egnn {
+
+namespace {
+
+constexpr int kNodes = 32, kThreadsN = 256;
+constexpr int kMaxKS1 = 20;   // k-steps of the first product held in registers (H + MP <= 320)
+__host__ __device__ inline size_t nb_smem_bytes(int K1Q, int OB) {
+  const size_t xs = (size_t)(K1Q / 8) * 33 * 16;          // X^T image [k-group][33][8 bf16]
+  const size_t red = (size_t)4 * OB * 16 * 64 * 4;         // cross-wave partial out^T
+  return xs + red;
+}
+
+__global__ __launch_bounds__(kThreadsN) void node_post_bf16_kernel(const PostParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Xb = smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const int n0 = blockIdx.x * kNodes;
+  const int KS1 = p.K1Q / 16, OB = p.HP / 32;
+  float* red = reinterpret_cast<float*>(smem + (size_t)(p.K1Q / 8) * 33 * 16);
+
+  // gather [h | sum_m] (tile partials added in tile order), pack to bf16 in the fragment image
+  for (int i = tid; i < kNodes * (p.K1Q / 2); i += kThreadsN) {
+    const int node = i / (p.K1Q / 2), kp = i % (p.K1Q / 2), n = n0 + node;
+    float v[2] = {0.f, 0.f};
+    if (n < p.N) {
+      const int rp0 = p.row_ptr[n], rp1 = p.row_ptr[n + 1];
+      const int t0 = rp1 > rp0 ? rp0 / p.R : 0, t1 = rp1 > rp0 ? (rp1 - 1) / p.R : 0;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int k = 2 * kp + u;
+        if (k < p.H) v[u] = p.h[(size_t)n * p.H + k];
+        else if (k - p.H < p.MP && rp1 > rp0) {
+          const int c = k - p.H;
+          if (t0 == t1) v[u] = p.agg_m[(size_t)n * p.MP + c];
+          else {
+            float a = p.part_m[((size_t)t0 * 2 + 1) * p.MP + c];
+            for (int t = t0 + 1; t <= t1; ++t) a += p.part_m[((size_t)t * 2) * p.MP + c];
+            v[u] = a;
+          }
+        }
+      }
+    }
+    const int k = 2 * kp;
+    __bf16* dst = reinterpret_cast<__bf16*>(Xb + ((size_t)(k >> 3) * 33 + node) * 16) + (k & 7);
+    dst[0] = (__bf16)v[0];
+    dst[1] = (__bf16)v[1];
+  }
+  // coordinate update
+  if (tid < kNodes * 3) {
+    const int node = tid / 3, d = tid % 3, n = n0 + node;
+    if (n < p.N) {
+      const int rp0 = p.row_ptr[n], rp1 = p.row_ptr[n + 1];
+      float v = 0.f;
+      if (rp1 > rp0) {
+        const int t0 = rp0 / p.R, t1 = (rp1 - 1) / p.R;
+        for (int hs = 0; hs < p.nsplit_x; ++hs) {
+          const float* ax = p.agg_x + (size_t)hs * p.agg_x_stride;
+          const float* px = p.part_x + (size_t)hs * p.part_x_stride;
+          if (t0 == t1) v += ax[(size_t)n * 4 + d];
+          else {
+            v += px[((size_t)t0 * 2 + 1) * 4 + d];
+            for (int t = t0 + 1; t <= t1; ++t) v += px[((size_t)t * 2) * 4 + d];
+          }
+        }
+      }
+      const float g = 1.0f / (sqrtf(p.gscale[p.per_graph ? p.node_graph[n] : 0]) + 1.0f);
+      p.x_out[3 * n + d] = p.x[3 * n + d] + v * g;
+    }
+  }
+  __syncthreads();
+
+  const bf16x8* w1 = reinterpret_cast<const bf16x8*>(p.w1h_bf16);    // [WhP/32][KS1][64]
+  const bf16x8* w2 = reinterpret_cast<const bf16x8*>(p.w2h_bf16p);   // [OB][WhP/16][64], k permuted
+  const int KS2 = p.WhP / 16;
+  const int nhb = p.WhP / 32, hb_per_wave = nhb / 4;   // WhP is a multiple of 128
+  f32x16 oacc[kPostMaxOB];
+#pragma unroll
+  for (int ob = 0; ob < kPostMaxOB; ++ob)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) oacc[ob][i] = 0.f;
+
+  const char* xfrag = Xb + ((size_t)hh * 33 + r) * 16;   // B fragment of k-step s: + s*2*33*16
+  // The W1h fragments of a hidden block (KS1 <= kMaxKS1 k-steps, 1 KiB each) are all requested before the
+  // block's MFMA chain, and the next block's while this one is multiplied: one exposed L2 round trip per
+  // wave instead of one per k-step.
+  bf16x8 wf[kMaxKS1], wn[kMaxKS1];
+  {
+    const bf16x8* w1b = w1 + ((size_t)(wave * hb_per_wave) * KS1) * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < kMaxKS1; ++s) wf[s] = w1b[(size_t)(s < KS1 ? s : 0) * 64];
+  }
+  for (int q = 0; q < hb_per_wave; ++q) {
+    const int hb = wave * hb_per_wave + q;
+    {
+      const int hbn = q + 1 < hb_per_wave ? hb + 1 : hb;
+      const bf16x8* w1b = w1 + ((size_t)hbn * KS1) * 64 + lane;
+#pragma unroll
+      for (int s = 0; s < kMaxKS1; ++s) wn[s] = w1b[(size_t)(s < KS1 ? s : 0) * 64];
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < kMaxKS1; ++s)
+      if (s < KS1) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(xfrag + (size_t)s * 2 * 33 * 16);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s], b, acc, 0, 0, 0);
+      }
+    // bias + SiLU on the accumulator; registers 8s..8s+7 are the B fragment of k-step s of the second product
+    bf16x8 hf[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float bias = p.b1h[32 * hb + acc_row(i, lane)];
+      hf[i >> 3][i & 7] = (__bf16)silu_f(acc[i] + bias);
+    }
+#pragma unroll
+    for (int ob = 0; ob < kPostMaxOB; ++ob)
+      if (ob < OB) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const bf16x8 a = w2[((size_t)ob * KS2 + 2 * hb + s) * 64 + lane];
+          oacc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hf[s], oacc[ob], 0, 0, 0);
+        }
+      }
+#pragma unroll
+    for (int s = 0; s < kMaxKS1; ++s) wf[s] = wn[s];
+  }
+  // cross-wave sum (fixed order) and store: oacc[ob][i] = out^T[o = 32ob + acc_row(i), node = r]
+#pragma unroll
+  for (int ob = 0; ob < kPostMaxOB; ++ob)
+    if (ob < OB) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) red[((size_t)(wave * OB + ob) * 16 + i) * 64 + lane] = oacc[ob][i];
+    }
+  __syncthreads();
+  for (int e = tid; e < OB * 16 * 64; e += kThreadsN) {
+    const int l = e & 63, i = (e >> 6) & 15, ob = e >> 10;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) v += red[((size_t)(w * OB + ob) * 16 + i) * 64 + l];
+    const int o = 32 * ob + acc_row(i, l), n = n0 + (l & 31);
+    if (n < p.N && o < p.H) p.h_out[(size_t)n * p.H + o] = v + p.b2h[o];
+  }
+}
+
+}  // namespace
+
+int init_node_bf16_attributes() {
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&node_post_bf16_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  return EGNN_OK;
+}
+
+bool node_post_bf16_supported(const PostParams& q) {
+  return q.w1h_bf16 && q.w2h_bf16p && q.WhP % 128 == 0 && q.HP / 32 <= kPostMaxOB && q.K1Q / 16 <= kMaxKS1 &&
+         nb_smem_bytes(q.K1Q, q.HP / 32) <= 160 * 1024;
+}
+
+int launch_node_post_bf16(const PostParams& q, hipStream_t st) {
+  hipLaunchKernelGGL(node_post_bf16_kernel, dim3((q.N + kNodes - 1) / kNodes), dim3(kThreadsN),
+                     nb_smem_bytes(q.K1Q, q.HP / 32), st, q);
+  EGNN_HIP(hipGetLastError());
+  return EGNN_OK;
+}
+
+}  // namespace egnn

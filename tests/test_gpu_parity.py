@@ -186,7 +186,7 @@ def test_full_size_c2_properties(precision, tol):
     idx = (perm.repeat_interleave(n) * n + torch.arange(n).repeat(B))
     with torch.no_grad():
         h2, x2 = net(ei, h[idx].to(DEV), x[idx].to(DEV), batch=batch)
-    ptol = 1e-5 if precision == "fp32" else 1e-3   # bf16 re-rounding amplifies fp32 order differences
+    ptol = 1e-5 if precision == "fp32" else 5e-3   # bf16 re-rounding (eps 4e-3) amplifies fp32 order differences
     assert rel_err(h2.cpu(), h0.cpu()[idx]) <= ptol and rel_err(x2.cpu(), x0.cpu()[idx]) <= ptol
     # oracle spot check on graphs 0 and 137
     e1 = egnn_ref.fully_connected_edge_index(n)
