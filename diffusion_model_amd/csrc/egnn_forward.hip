@@ -165,16 +165,26 @@ __global__ __launch_bounds__(kThreads) void node_pre_mfma_kernel(const float* __
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[j][i] = b;
   }
-  for (int k0 = 0; k0 < HP2; k0 += 2) {
-    const int k = k0 + hh;
-    const float a = hs[k * 33 + r];
+  // all B values of this lane (KS k-steps x 4 column blocks) are requested up front: one L2 round trip
+  constexpr int kMaxKS = 32;   // H <= 64 (checked on the host)
+  const int KS = HP2 / 2;
+  float bw[4][kMaxKS];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int col = col0 + 32 * j + r;
-      const float b = (k < H && col < TC) ? w1catT[(size_t)k * TC + col] : 0.f;
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+  for (int j = 0; j < 4; ++j) {
+    const int col = col0 + 32 * j + r;
+#pragma unroll
+    for (int s = 0; s < kMaxKS; ++s) {
+      const int k = 2 * s + hh;
+      bw[j][s] = (s < KS && k < H && col < TC) ? w1catT[(size_t)k * TC + col] : 0.f;
     }
   }
+#pragma unroll
+  for (int s = 0; s < kMaxKS; ++s)
+    if (s < KS) {
+      const float a = hs[(2 * s + hh) * 33 + r];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[j][s], acc[j], 0, 0, 0);
+    }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int col = col0 + 32 * j + r;
@@ -825,7 +835,7 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
   prof_begin(c, st, 1);
   {
     static const int pre_sel = getenv("EGNN_PRE") ? atoi(getenv("EGNN_PRE")) : 2;   // A/B switch
-    if (pre_sel >= 2) {
+    if (pre_sel >= 2 && c->H <= 64) {
       dim3 grid((N + kPre2Nodes - 1) / kPre2Nodes, (c->TC + kPre2Cols - 1) / kPre2Cols);
       hipLaunchKernelGGL(node_pre_mfma_kernel, grid, dim3(kThreads), (size_t)((c->H + 1) & ~1) * 33 * sizeof(float), st,
                          h, N, c->H, w1catT, b1cat, c->TC, c->table);
