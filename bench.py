@@ -103,11 +103,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # BENCH_DEVICE / BENCH_BACKEND exist only to rehearse the N>1 code path on a one-GPU box
+    # (all ranks on one device, gloo for the timing collective); the driver's runs use one GPU per rank + RCCL.
+    dev_index = int(os.environ.get("BENCH_DEVICE", local_rank))
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import diffusion_model_amd as dma
     from diffusion_model_amd import _lib
@@ -155,7 +162,7 @@ def main():
     _lib.check(lib.egnn_profile_read(smp.ctx.handle, C.byref(edge_ms), C.byref(edge_n), C.byref(node_ms)))
     _lib.check(lib.egnn_profile_enable(smp.ctx.handle, 0))
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     # ---- extra: the same K steps replayed from the captured hipGraph (no events) ----
