@@ -181,6 +181,15 @@ def main():
         flops_per_launch = 2.0 * edge_macs(H, M, W, W) * E
         achieved = flops_per_launch / (edge_ms.value * 1e-3) / 1e12 if edge_ms.value > 0 else 0.0
         peak = PEAK_TFLOPS[args.precision]
+        # HBM bytes per launch come from separate rocprofv3 --pmc passes (profiles/traffic.json, same workload);
+        # they cannot be collected from inside this process
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if args.precision == "bf16" and B == 256 and n == 64 and L == 4:
+                traffic = tj["bytes_per_launch"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "atoms*denoise-steps/sec, 64-atom SiO2 T=1000",
             "value": world * B * n * K / elapsed,
@@ -193,7 +202,8 @@ def main():
                                    f"T=1000 reverse steps, fully connected (E={E}/GPU)",
                        "global_batch": world * B, "parallelism": f"replicas x{world} (no data-path collective)"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": None,
+                         "frac": achieved / peak, "traffic": traffic,
+                         "traffic_source": "profiles/traffic.json (rocprofv3 --pmc, separate pass)" if traffic else None,
                          "kernel": "fused edge pass of one EGCL layer (edge_kernel_bf16_v3 X+M launches, or "
                                    "edge_kernel_bf16_v2 / edge_kernel<F32>)",
                          "avg_launch_ms": edge_ms.value, "launches": edge_n.value,
