@@ -55,6 +55,7 @@ class _EGNNFunction(torch.autograd.Function):
                                       _lib.ptr(ho), _lib.ptr(xo)))
             hc, xc = ho, xo
         ctx.layers, ctx.plan, ctx.scope = layers, plan, scope
+        ctx.bf16 = prec == _lib.PREC_BF16
         ctx.save_for_backward(*saved)
         return hc, xc
 
@@ -70,6 +71,9 @@ class _EGNNFunction(torch.autograd.Function):
         gh = torch.zeros_like(saved[-2]) if gh is None else gh.contiguous().float()
         gx = torch.zeros_like(saved[-1]) if gx is None else gx.contiguous().float()
         grads = {}
+        # bf16 mode: the recomputed edge MLPs run under bf16 autocast (bf16 GEMM operands, fp32 accumulate and
+        # fp32 master gradients), matching the forward kernels' arithmetic; fp32 mode stays fp32 end to end
+        amp = lambda: torch.autocast("cuda", dtype=torch.bfloat16, enabled=ctx.bf16)
         for l in reversed(range(len(layers))):
             layer = layers[l]
             h_l, x_l = saved[2 * l], saved[2 * l + 1]
@@ -82,7 +86,9 @@ class _EGNNFunction(torch.autograd.Function):
                 S = torch.zeros(nseg, device=h_l.device)
                 for a in range(0, E, EDGE_CHUNK):
                     d_, s_ = dst[a:a + EDGE_CHUNK], src[a:a + EDGE_CHUNK]
-                    m, xm, d2 = _edge_terms(layer, h_l, x_l, d_, s_)
+                    with amp():
+                        m, xm, d2 = _edge_terms(layer, h_l, x_l, d_, s_)
+                    m, xm, d2 = m.float(), xm.float(), d2.float()
                     agg_m.index_add_(0, d_, m)
                     agg_x.index_add_(0, d_, xm)
                     S.index_add_(0, seg_of_node.index_select(0, d_), d2)
@@ -109,7 +115,9 @@ class _EGNNFunction(torch.autograd.Function):
                 with torch.enable_grad():
                     h_leaf = h_l.detach().requires_grad_(True)
                     x_leaf = x_l.detach().requires_grad_(True)
-                    m, xm, d2 = _edge_terms(layer, h_leaf, x_leaf, d_, s_)
+                    with amp():
+                        m, xm, d2 = _edge_terms(layer, h_leaf, x_leaf, d_, s_)
+                    m, xm, d2 = m.float(), xm.float(), d2.float()
                     up = [g_am.index_select(0, d_), g_ax.index_select(0, d_),
                           g_S.index_select(0, seg_of_node.index_select(0, d_))]
                     outs = torch.autograd.grad([m, xm, d2], [h_leaf, x_leaf] + edge_params, up, allow_unused=True)

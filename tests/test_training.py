@@ -163,3 +163,25 @@ def test_partitioned_exchange_world_size_2_gloo(tmp_path):
     mp.spawn(_part_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     res = torch.load(out, weights_only=True)
     assert res["eh"] < 1e-4 and res["ex"] < 1e-4
+
+
+@pytest.mark.gpu
+def test_bf16_training_gradients_close_to_fp32():
+    """bf16 mode: HIP bf16 forward + bf16-autocast recompute backward; gradients within bf16 accuracy of fp32."""
+    H, A, T = 36, 2, 50
+    d = dims_for(H, 128, 256, 256, 256)
+    pos0, x0, cond, batch, ei, npos, nh, times = _problem()
+    dev = "cuda"
+    proc = dma.E3DiffusionProcess(1e-5, 2.0, T)
+    grads = {}
+    for prec in ("fp32", "bf16"):
+        torch.manual_seed(5)
+        net = dma.EquivariantGNN(2, **d).to(dev).train()
+        net.precision, net.norm_scope = prec, "graph"
+        noised = dma.diffuse_as_batch(pos0.to(dev), x0.to(dev), batch.to(dev), proc, times=times,
+                                      noise_pos=npos.to(dev), noise_h=nh.to(dev))
+        loss, _, _ = dma.training_loss(net, ei.to(dev), batch.to(dev), noised, cond.to(dev), A)
+        loss.backward()
+        grads[prec] = {k: p.grad.detach().cpu() for k, p in net.named_parameters()}
+    for k in grads["fp32"]:
+        assert rel_err(grads["bf16"][k], grads["fp32"][k]) <= 8e-2, k
