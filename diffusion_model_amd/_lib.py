@@ -27,6 +27,10 @@ SIGNATURES = {
     "egcl_forward_begin": (_i, [_vp, _vp, _i, _i, _i] + [_vp] * 3),
     "egcl_forward_end": (_i, [_vp, _vp, _i, _i, _i] + [_vp] * 5),
     "egnn_forward": (_i, [_vp, _vp, _i, _i] + [_vp] * 4),
+    "egcl_read_aggregates": (_i, [_vp, _vp, _i] + [_vp] * 3),
+    "egcl_backward_l1_act": (_i, [_vp, _i, _i, _i] + [_vp] * 7),
+    "egcl_backward_heads": (_i, [_vp, _i, _i, _i, _i] + [_vp] * 20),
+    "egcl_backward_l1_grad": (_i, [_vp, _i, _i, _i] + [_vp] * 7),
     "egnn_eps": (_i, [_vp, _i, _i, _i, _vp, _i] + [_vp] * 5),
     "egnn_remove_mean": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
     "schedule_table_build": (_i, [_i, C.c_double, C.c_double, _fp, _fp, _fp]),

@@ -1,41 +1,126 @@
 """Differentiable EGNN forward for training.
 
-Forward: the fused HIP kernels (same call as inference).  Backward (round 1): per layer, in reverse
-order, the layer is recomputed from its saved inputs (h_l, x_l) and differentiated with library GEMMs
-(rocBLAS/hipBLASLt through torch.matmul -- dgrad/wgrad of the edge MLPs are plain large GEMMs) in edge
-chunks, so no [E, 1024] tensor outlives a chunk.  A fused HIP backward kernel that recomputes the hidden
-activations on chip is the planned replacement; the interface here does not change.
+Forward: the fused HIP kernels (same call as inference); per layer the inputs (h_l, x_l) and the three segment
+sums the edge pass produced (egcl_read_aggregates) are kept.  Backward, per layer in reverse order:
 
-Math (reference EquivariantGraphNeuralNetwork.py:55-71), per layer:
-  node part : h' = mlp_h([h | sum_m]);  x' = x + sum_x / (G + 1),  G = sqrt(S), S = sum of d^2
-  edge part : m_e = gate(mlp_m(in_e)) ; xm_e = (x_i - x_j) * mlp_x(in_e) ; d2_e = |x_i - x_j|^2
+  node part  (N rows, small): h' = mlp_h([h | sum_m]), x' = x + sum_x / (G + 1), G = sqrt(sum d^2) -- differentiated
+             with torch ops on the saved sums; yields the gradients of the three segment sums.
+  edge part  (E rows, the cost): recomputed in edge chunks as the chain
+             egcl_backward_l1_act -> GEMM -> egcl_backward_heads -> GEMM, GEMM -> egcl_backward_l1_grad -> GEMM, GEMM
+             where the stage functions are HIP kernels of the C ABI (gathers, SiLU and SiLU', scalar heads, gate,
+             row reductions, bias / w3 / wa column sums, in place on the GEMM buffers) and the GEMMs are the plain
+             dgrad / wgrad products of the four Linear layers, run by the BLAS library through torch.mm.
+             bf16 mode stores the [edges, W] buffers and runs the GEMMs in bf16 (fp32 accumulate, fp32 master
+             gradients); fp32 mode is fp32 end to end.
+
+Math (reference EquivariantGraphNeuralNetwork.py:55-71), per edge e = (i <- j):
+  in = [h_i | h_j | d2],  d2 = |x_i - x_j|^2
+  m branch : m = SiLU(W2m SiLU(W1m in + b1m) + b2m);  out = m * sigmoid(wa . m + ba)          -> sum_m[i]
+  x branch : s = w3 . SiLU(W2x SiLU(W1x in + b1x) + b2x) + b3;  xm = (x_i - x_j) * s          -> sum_x[i]
 """
 from __future__ import annotations
 
 import torch
-import torch.nn.functional as F
 
 from . import _lib
 
 EDGE_CHUNK = 1 << 18
 
 
-def _edge_terms(layer, h, x, dst, src):
-    """gated messages, raw coordinate messages and squared distances of a block of edges"""
-    h_i, h_j = h.index_select(0, dst), h.index_select(0, src)
-    diff = x.index_select(0, dst) - x.index_select(0, src)
-    d2 = torch.norm(diff, dim=1, keepdim=True) ** 2                    # :56 (sqrt then square)
-    inp = torch.cat((h_i, h_j, d2), dim=1)
-    m = layer.mlp_m(inp)
-    m = m * layer.attention(m)                                         # :59-60
-    xm = diff * layer.mlp_x(inp)                                       # :64 without the 1/(G+1) factor
-    return m, xm, d2.squeeze(1)
-
-
 def _segment_scale(S, scope_graph, node_graph):
     G = torch.sqrt(S.clamp_min(1e-30))   # graphs without edges: S = 0, zero gradient
     c = 1.0 / (G + 1.0)
     return c.index_select(0, node_graph).unsqueeze(1) if scope_graph else c
+
+
+class _Workspace:
+    """[chunk, width] buffers of the edge part, allocated once per backward call"""
+
+    def __init__(self, rows, Wx, Wm, M, dtype, device):
+        e = lambda *shape, dt=dtype: torch.empty(*shape, dtype=dt, device=device)
+        self.s1x, self.s1m = e(rows, Wx), e(rows, Wm)
+        self.a2x, self.a2m = e(rows, Wx), e(rows, M)
+        self.g1x, self.g1m = e(rows, Wx), e(rows, Wm)
+        self.g_diff = e(rows, 3, dt=torch.float32)
+
+
+def _edge_backward(layer, prec, ws, h, x, dst32, src32, seg_of_node, g_am, g_ax, g_S, g_h, g_x, grads):
+    """adds the edge part's contributions to g_h, g_x and to the parameter gradients in `grads`"""
+    L = _lib.lib()
+    st = _lib.stream_ptr()
+    dt = ws.s1x.dtype
+    H = h.shape[1]
+    lin_x0, lin_x2, lin_x4 = layer.mlp_x[0], layer.mlp_x[2], layer.mlp_x[4]
+    lin_m0, lin_m2, att = layer.mlp_m[0], layer.mlp_m[2], layer.attention[0]
+    Wx, Wm, M = lin_x0.out_features, lin_m0.out_features, lin_m2.out_features
+    f32 = dict(dtype=torch.float32, device=h.device)
+
+    def tables(lin):   # per-node halves of the first Linear layer (:56's concatenation factorised)
+        w = lin.weight.detach()
+        P = torch.addmm(lin.bias.detach(), h, w[:, :H].t()).contiguous()
+        Q = torch.mm(h, w[:, H:2 * H].t()).contiguous()
+        return P, Q, w[:, 2 * H].contiguous()
+
+    Px, Qx, wdx = tables(lin_x0)
+    Pm, Qm, wdm = tables(lin_m0)
+    w2x, w2m = lin_x2.weight.detach().to(dt), lin_m2.weight.detach().to(dt)
+    w1x, w1m = lin_x0.weight.detach().to(dt), lin_m0.weight.detach().to(dt)
+    b2x, b2m = lin_x2.bias.detach().contiguous(), lin_m2.bias.detach().contiguous()
+    w3, b3 = lin_x4.weight.detach().reshape(-1).contiguous(), lin_x4.bias.detach().contiguous()
+    wa, ba = att.weight.detach().reshape(-1).contiguous(), att.bias.detach().contiguous()
+    # fp32 accumulators; the first Linear layers carry their bias gradient in an extra column (ones column of `in`)
+    g_w1x, g_w1m = torch.zeros(Wx, 2 * H + 2, **f32), torch.zeros(Wm, 2 * H + 2, **f32)
+    g_w2x, g_w2m = torch.zeros(Wx, Wx, **f32), torch.zeros(M, Wm, **f32)
+    g_b2x, g_w3, g_b3 = torch.zeros(Wx, **f32), torch.zeros(Wx, **f32), torch.zeros(1, **f32)
+    g_b2m, g_wa, g_ba = torch.zeros(M, **f32), torch.zeros(M, **f32), torch.zeros(1, **f32)
+    g_am, g_ax = g_am.contiguous(), g_ax.contiguous()
+    E = dst32.numel()
+    rows = ws.s1x.shape[0]
+    for a in range(0, E, rows):
+        n = min(rows, E - a)
+        d32, s32 = dst32[a:a + n], src32[a:a + n]
+        d_, s_ = d32.long(), s32.long()
+        diff = x.index_select(0, d_) - x.index_select(0, s_)
+        d2 = (diff * diff).sum(1).contiguous()
+        s1x, s1m, a2x, a2m, g1x, g1m = ws.s1x[:n], ws.s1m[:n], ws.a2x[:n], ws.a2m[:n], ws.g1x[:n], ws.g1m[:n]
+        g_diff = ws.g_diff[:n]
+        P = _lib.ptr
+        _lib.check(L.egcl_backward_l1_act(st, prec, n, Wx, P(d32), P(s32), P(Px), P(Qx), P(wdx), P(d2), P(s1x)))
+        _lib.check(L.egcl_backward_l1_act(st, prec, n, Wm, P(d32), P(s32), P(Pm), P(Qm), P(wdm), P(d2), P(s1m)))
+        torch.mm(s1x, w2x.t(), out=a2x)
+        torch.mm(s1m, w2m.t(), out=a2m)
+        _lib.check(L.egcl_backward_heads(st, prec, n, Wx, M, P(d32), P(s32), P(x), P(g_ax), P(g_am), P(a2x), P(a2m),
+                                         P(b2x), P(w3), P(b3), P(b2m), P(wa), P(ba), P(g_diff), P(g_b2x), P(g_w3),
+                                         P(g_b3), P(g_b2m), P(g_wa), P(g_ba)))
+        # a2x / a2m now hold dL/da2: wgrad and dgrad of the second Linear layers
+        g_w2x += torch.mm(a2x.t(), s1x)
+        g_w2m += torch.mm(a2m.t(), s1m)
+        torch.mm(a2x, w2x, out=g1x)
+        torch.mm(a2m, w2m, out=g1m)
+        _lib.check(L.egcl_backward_l1_grad(st, prec, n, Wx, P(d32), P(s32), P(Px), P(Qx), P(wdx), P(d2), P(g1x)))
+        _lib.check(L.egcl_backward_l1_grad(st, prec, n, Wm, P(d32), P(s32), P(Pm), P(Qm), P(wdm), P(d2), P(g1m)))
+        # first Linear layers: wgrad against in = [h_i | h_j | d2 | 1], dgrad back to the gathered inputs
+        inp = torch.cat((h.index_select(0, d_), h.index_select(0, s_), d2.unsqueeze(1), torch.ones_like(d2).unsqueeze(1)),
+                        dim=1).to(dt)
+        g_w1x += torch.mm(g1x.t(), inp)
+        g_w1m += torch.mm(g1m.t(), inp)
+        g_in = (torch.mm(g1x, w1x) + torch.mm(g1m, w1m)).float()
+        g_h.index_add_(0, d_, g_in[:, :H])
+        g_h.index_add_(0, s_, g_in[:, H:2 * H])
+        g_d2 = g_in[:, 2 * H] + g_S.index_select(0, seg_of_node.index_select(0, d_))
+        g_dd = g_diff + (2.0 * g_d2).unsqueeze(1) * diff
+        g_x.index_add_(0, d_, g_dd)
+        g_x.index_add_(0, s_, -g_dd)
+
+    def acc(p, g):
+        grads[p] = grads.get(p, 0) + g.reshape(p.shape)
+
+    acc(lin_x0.weight, g_w1x[:, :2 * H + 1]); acc(lin_x0.bias, g_w1x[:, 2 * H + 1])
+    acc(lin_m0.weight, g_w1m[:, :2 * H + 1]); acc(lin_m0.bias, g_w1m[:, 2 * H + 1])
+    acc(lin_x2.weight, g_w2x); acc(lin_x2.bias, g_b2x)
+    acc(lin_m2.weight, g_w2m); acc(lin_m2.bias, g_b2m)
+    acc(lin_x4.weight, g_w3); acc(lin_x4.bias, g_b3)
+    acc(att.weight, g_wa); acc(att.bias, g_ba)
 
 
 class _EGNNFunction(torch.autograd.Function):
@@ -46,88 +131,64 @@ class _EGNNFunction(torch.autograd.Function):
         c.set_graph(plan)
         c.pack(layers)
         L = _lib.lib()
+        nseg = plan.B if scope == _lib.NORM_GRAPH else 1
         saved = []
         hc, xc = h.detach().float().contiguous(), x.detach().float().contiguous()
         for l in range(len(layers)):
-            saved += [hc, xc]
             ho, xo = torch.empty_like(hc), torch.empty_like(xc)
             _lib.check(L.egcl_forward(c.handle, _lib.stream_ptr(), l, prec, scope, _lib.ptr(hc), _lib.ptr(xc),
                                       _lib.ptr(ho), _lib.ptr(xo)))
+            sum_m = torch.empty(hc.shape[0], layers[l].dims["M"], device=hc.device)
+            sum_x = torch.empty(hc.shape[0], 3, device=hc.device)
+            S = torch.empty(nseg, device=hc.device)
+            _lib.check(L.egcl_read_aggregates(c.handle, _lib.stream_ptr(), scope, _lib.ptr(sum_m), _lib.ptr(sum_x),
+                                              _lib.ptr(S)))
+            saved += [hc, xc, sum_m, sum_x, S]
             hc, xc = ho, xo
-        ctx.layers, ctx.plan, ctx.scope = layers, plan, scope
-        ctx.bf16 = prec == _lib.PREC_BF16
+        ctx.layers, ctx.plan, ctx.scope, ctx.prec = layers, plan, scope, prec
         ctx.save_for_backward(*saved)
         return hc, xc
 
     @staticmethod
     def backward(ctx, gh, gx):
-        layers, plan = ctx.layers, ctx.plan
+        layers, plan, prec = ctx.layers, ctx.plan, ctx.prec
         scope_graph = ctx.scope == _lib.NORM_GRAPH
         saved = ctx.saved_tensors
-        dst, src = plan.edge_dst.long(), plan.edge_src.long()
+        dst32, src32 = plan.edge_dst, plan.edge_src
         node_graph = plan.node_graph.long()
-        nseg = plan.B if scope_graph else 1
         seg_of_node = node_graph if scope_graph else torch.zeros_like(node_graph)
-        gh = torch.zeros_like(saved[-2]) if gh is None else gh.contiguous().float()
-        gx = torch.zeros_like(saved[-1]) if gx is None else gx.contiguous().float()
+        gh = torch.zeros_like(saved[0]) if gh is None else gh.contiguous().float()
+        gx = torch.zeros_like(saved[1]) if gx is None else gx.contiguous().float()
         grads = {}
-        # bf16 mode: the recomputed edge MLPs run under bf16 autocast (bf16 GEMM operands, fp32 accumulate and
-        # fp32 master gradients), matching the forward kernels' arithmetic; fp32 mode stays fp32 end to end
-        amp = lambda: torch.autocast("cuda", dtype=torch.bfloat16, enabled=ctx.bf16)
+        d0 = layers[0].dims
+        E = dst32.numel()
+        ws = None
+        if E > 0:
+            ws = _Workspace(min(EDGE_CHUNK, E), layers[0].mlp_x[0].out_features, layers[0].mlp_m[0].out_features, d0["M"],
+                            torch.bfloat16 if prec == _lib.PREC_BF16 else torch.float32, gh.device)
         for l in reversed(range(len(layers))):
             layer = layers[l]
-            h_l, x_l = saved[2 * l], saved[2 * l + 1]
-            n, E = h_l.shape[0], dst.numel()
-            M = layer.dims["M"]
-            # pass A (no grad): segment sums of the layer, in edge chunks
-            with torch.no_grad():
-                agg_m = torch.zeros(n, M, device=h_l.device)
-                agg_x = torch.zeros(n, 3, device=h_l.device)
-                S = torch.zeros(nseg, device=h_l.device)
-                for a in range(0, E, EDGE_CHUNK):
-                    d_, s_ = dst[a:a + EDGE_CHUNK], src[a:a + EDGE_CHUNK]
-                    with amp():
-                        m, xm, d2 = _edge_terms(layer, h_l, x_l, d_, s_)
-                    m, xm, d2 = m.float(), xm.float(), d2.float()
-                    agg_m.index_add_(0, d_, m)
-                    agg_x.index_add_(0, d_, xm)
-                    S.index_add_(0, seg_of_node.index_select(0, d_), d2)
-            # pass B: node part
-            params = [p for p in layer.parameters()]
+            h_l, x_l, sum_m, sum_x, S = saved[5 * l:5 * l + 5]
+            # node part
+            node_params = list(layer.mlp_h.parameters())
             with torch.enable_grad():
                 h_leaf = h_l.detach().requires_grad_(True)
                 x_leaf = x_l.detach().requires_grad_(True)
-                am, ax, S_leaf = agg_m.requires_grad_(True), agg_x.requires_grad_(True), S.requires_grad_(True)
+                am, ax = sum_m.detach().requires_grad_(True), sum_x.detach().requires_grad_(True)
+                S_leaf = S.detach().requires_grad_(True)
                 h_new = layer.mlp_h(torch.cat((h_leaf, am), dim=1))
                 x_new = x_leaf + ax * _segment_scale(S_leaf, scope_graph, node_graph)
-                node_params = list(layer.mlp_h.parameters())
                 outs = torch.autograd.grad([h_new, x_new], [h_leaf, x_leaf, am, ax, S_leaf] + node_params, [gh, gx],
                                            allow_unused=True)
-            g_h, g_x, g_am, g_ax, g_S = [o if o is not None else 0 for o in outs[:5]]
+            zero = lambda o, like: o.clone() if o is not None else torch.zeros_like(like)
+            g_h, g_x = zero(outs[0], h_l), zero(outs[1], x_l)
+            g_am, g_ax, g_S = zero(outs[2], sum_m), zero(outs[3], sum_x), zero(outs[4], S)
             for p, g in zip(node_params, outs[5:]):
-                grads[p] = grads.get(p, 0) + (g if g is not None else 0)
-            g_h = g_h.clone() if torch.is_tensor(g_h) else torch.zeros_like(h_l)
-            g_x = g_x.clone() if torch.is_tensor(g_x) else torch.zeros_like(x_l)
-            # pass C: edge part, chunked, with the upstream gradients of the three segment sums
-            edge_params = [p for p in params if all(p is not q for q in node_params)]
-            for a in range(0, E, EDGE_CHUNK):
-                d_, s_ = dst[a:a + EDGE_CHUNK], src[a:a + EDGE_CHUNK]
-                with torch.enable_grad():
-                    h_leaf = h_l.detach().requires_grad_(True)
-                    x_leaf = x_l.detach().requires_grad_(True)
-                    with amp():
-                        m, xm, d2 = _edge_terms(layer, h_leaf, x_leaf, d_, s_)
-                    m, xm, d2 = m.float(), xm.float(), d2.float()
-                    up = [g_am.index_select(0, d_), g_ax.index_select(0, d_),
-                          g_S.index_select(0, seg_of_node.index_select(0, d_))]
-                    outs = torch.autograd.grad([m, xm, d2], [h_leaf, x_leaf] + edge_params, up, allow_unused=True)
-                if outs[0] is not None:
-                    g_h += outs[0]
-                if outs[1] is not None:
-                    g_x += outs[1]
-                for p, g in zip(edge_params, outs[2:]):
-                    if g is not None:
-                        grads[p] = grads.get(p, 0) + g
+                if g is not None:
+                    grads[p] = grads.get(p, 0) + g
+            # edge part
+            if E > 0:
+                _edge_backward(layer, prec, ws, h_l, x_l, dst32, src32, seg_of_node, g_am, g_ax, g_S, g_h, g_x, grads)
             gh, gx = g_h, g_x
         flat = []
         for layer in layers:

@@ -144,6 +144,8 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
   char* slot0 = s_a1 + ((size_t)kg * kRPAD3 + brow) * 16;
   char* slot1 = slot0 + 64 * 16;
   const unsigned lane16 = lane * 16u;
+  // 32-bit LDS byte address of this lane's A-fragment slot in activation buffer 0
+  const unsigned lds_a1_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(s_a1 + ((size_t)hh * kRPAD3 + r) * 16);
   const int colblk0 = half * 8 * CB + wave * CB;   // first 32-column block of this wave
   const unsigned w0 = (unsigned)colblk0 * KS * 1024u;
 
@@ -174,6 +176,43 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
   // after the MFMAs of k-step s of chunk c were issued (a whole chunk = 4 k-steps of distance, enough to cover
   // an L2 round trip under load), the LDS A fragments one k-step ahead.
   auto mphase = [&](const int c, const bool last) {
+#ifndef EGNN_EXP_NO_MFMA
+    // A fragments by inline-asm ds_read_b128 so that hipcc cannot sink them to their use: a[rb] is refilled in
+    // place for k-step s+1 right after the MFMAs of (s, rb) were issued and flies under the next 3 row blocks'
+    // MFMAs.  LDS operations of a wave return in order, so lgkmcnt(3) before a use means "all but the 3
+    // younger reads have landed" (a scalar load in flight only makes the wait conservative).
+    const unsigned abase = lds_a1_base + (unsigned)(c & 1) * (unsigned)kA1_3;
+    bf16x8 a[kRB3];
+#define LDS_RD(dst, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(abase), "n"(off))
+#define LDS_WAIT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
+    LDS_RD(a[0], 0); LDS_RD(a[1], 512); LDS_RD(a[2], 1024); LDS_RD(a[3], 1536);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int rb = 0; rb < kRB3; ++rb) {
+        // LDS returns in order: at most 3 younger reads may still be in flight when a[rb] is consumed
+        if (s < 3 || rb == 0) LDS_WAIT(3);
+        else if (rb == 1) LDS_WAIT(2);
+        else if (rb == 2) LDS_WAIT(1);
+        else LDS_WAIT(0);
+        asm volatile("" : "+v"(a[rb]));   // uses of a[rb] stay below the wait
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+          acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rb], bq[s][cb], acc[rb][cb], 0, 0, 0);
+        // refill a[rb] in place for the next k-step (the MFMAs above have read it at issue)
+        if (s == 0) { if (rb == 0) LDS_RD(a[0], 4128); if (rb == 1) LDS_RD(a[1], 4128 + 512); if (rb == 2) LDS_RD(a[2], 4128 + 1024); if (rb == 3) LDS_RD(a[3], 4128 + 1536); }
+        if (s == 1) { if (rb == 0) LDS_RD(a[0], 8256); if (rb == 1) LDS_RD(a[1], 8256 + 512); if (rb == 2) LDS_RD(a[2], 8256 + 1024); if (rb == 3) LDS_RD(a[3], 8256 + 1536); }
+        if (s == 2) { if (rb == 0) LDS_RD(a[0], 12384); if (rb == 1) LDS_RD(a[1], 12384 + 512); if (rb == 2) LDS_RD(a[2], 12384 + 1024); if (rb == 3) LDS_RD(a[3], 12384 + 1536); }
+      }
+      if (!last) {
+        const unsigned ksn = (unsigned)((c + 1) * 4 + s) * 1024u;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) bq[s][cb] = ldbuf_bf16x8(rs_w, lane16, w0 + (unsigned)cb * KS * 1024u + ksn);
+      }
+    }
+#undef LDS_WAIT
+#undef LDS_RD
+#else   // timing experiment without MFMAs: compiler-visible LDS reads
     const char* cur = s_a1 + (size_t)(c & 1) * kA1_3 + ((size_t)hh * kRPAD3 + r) * 16;
     bf16x8 a[kRB3], an[kRB3];
 #pragma unroll
@@ -189,11 +228,7 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
       for (int rb = 0; rb < kRB3; ++rb)
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
-#ifndef EGNN_EXP_NO_MFMA
-          acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rb], bq[s][cb], acc[rb][cb], 0, 0, 0);
-#else
-          acc[rb][cb][0] += (float)a[rb][0] * (float)bq[s][cb][0];   // timing experiment: no MFMA
-#endif
+          acc[rb][cb][0] += (float)a[rb][0] * (float)bq[s][cb][0];
       if (!last) {
         const unsigned ksn = (unsigned)((c + 1) * 4 + s) * 1024u;
 #pragma unroll
@@ -204,6 +239,7 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
         for (int rb = 0; rb < kRB3; ++rb) a[rb] = an[rb];
       }
     }
+#endif
   };
   Unit u0, u1;
   auto vload = [&](const int c) {   // table rows for the activations of chunk c

@@ -96,6 +96,40 @@ int egcl_forward_begin(egnn_ctx* ctx, void* stream, int layer, int prec, int nor
 int egcl_forward_end(egnn_ctx* ctx, void* stream, int layer, int prec, int norm_scope,
                      const float* d_h, const float* d_x, const float* d_sq_sums, float* d_h_out, float* d_x_out);
 
+/* ---- backward of one EGCL layer (training: EquivariantGNN.forward must be differentiable w.r.t. h, x and all
+ * parameters; the reference gets this from torch autograd over :55-71) -------------------------
+ * The layer's backward is   l1_act -> GEMM -> heads -> GEMM,GEMM -> l1_grad -> GEMM,GEMM   where the GEMMs are
+ * the plain dgrad / wgrad products of the Linear layers (run by the caller's BLAS on the buffers below) and the
+ * three stage functions fuse everything in between, one pass over HBM each.  prec selects the storage type of
+ * the [edges, width] buffers (EGNN_PREC_F32: float, EGNN_PREC_BF16: bf16); arithmetic is fp32.  dst/src are
+ * the int32 edge arrays of egnn_set_graph (any contiguous slice of edges); all pointers are device memory.
+ *
+ * egcl_read_aggregates: the three segment sums of the layer that was just run on ctx by egcl_forward
+ *   (sum_m [N,M] = sum of gated messages :68, sum_x [N,3] = sum of (x_i-x_j)*s before the 1/(G+1) factor :64/:70,
+ *   sq_sums [B] or [1] = sum of d^2 per graph / per call), so that the backward need not recompute them. */
+int egcl_read_aggregates(egnn_ctx* ctx, void* stream, int norm_scope, float* d_sum_m, float* d_sum_x,
+                         float* d_sq_sums);
+/* s1[e][c] = SiLU(P[dst e][c] + Q[src e][c] + wd[c]*d2[e]) for C table columns: the first Linear+SiLU of mlp_x
+ * and mlp_m (:13-14, :19-20) on in = [h_i | h_j | d2] (:56), with P = h.W1[:, :H]^T + b1 and Q = h.W1[:, H:2H]^T
+ * tabulated per node by the caller and wd = W1[:, 2H]. */
+int egcl_backward_l1_act(void* stream, int prec, int n_edges, int C, const int32_t* d_dst, const int32_t* d_src,
+                         const float* d_P, const float* d_Q, const float* d_wd, const float* d_d2, void* d_s1_out);
+/* In place: a2x [n_edges,W] (= s1x.W2x^T) -> dL/da2x and a2m [n_edges,M] (= s1m.W2m^T) -> dL/da2m, through
+ * SiLU, the scalar head mlp_x.4 and xm = (x_i-x_j)*s (:62-65), and SiLU, the attention gate and m*gate (:57-60),
+ * given the gradients of the segment sums g_sum_x [N,3] (already multiplied by 1/(G+1)) and g_sum_m [N,M].
+ * Also writes g_diff [n_edges,3] = dL/d(x_i-x_j) through s, and ADDS the column sums to g_b2x [W], g_w3 [W],
+ * g_b3 [1], g_b2m [M], g_wa [M], g_ba [1] (gradients of mlp_x.2.bias, mlp_x.4.weight/.bias, mlp_m.2.bias,
+ * attention.0.weight/.bias).  b3 and ba are device pointers to the two scalar biases. */
+int egcl_backward_heads(void* stream, int prec, int n_edges, int W, int M, const int32_t* d_dst, const int32_t* d_src,
+                        const float* d_x, const float* d_g_sum_x, const float* d_g_sum_m, void* d_a2x_inout,
+                        void* d_a2m_inout, const float* d_b2x, const float* d_w3, const float* d_b3,
+                        const float* d_b2m, const float* d_wa, const float* d_ba, float* d_g_diff, float* d_g_b2x,
+                        float* d_g_w3, float* d_g_b3, float* d_g_b2m, float* d_g_wa, float* d_g_ba);
+/* In place: g_s1[e][c] *= SiLU'(P[dst e][c] + Q[src e][c] + wd[c]*d2[e])  (dL/ds1 -> dL/da1). */
+int egcl_backward_l1_grad(void* stream, int prec, int n_edges, int C, const int32_t* d_dst, const int32_t* d_src,
+                          const float* d_P, const float* d_Q, const float* d_wd, const float* d_d2,
+                          void* d_g_s1_inout);
+
 /* EquivariantGNN.forward(edge_index, h, x) -> (h_L, x_L) (:85-88): all L layers. */
 int egnn_forward(egnn_ctx* ctx, void* stream, int prec, int norm_scope,
                  const float* d_h, const float* d_x, float* d_h_out, float* d_x_out);
