@@ -31,6 +31,8 @@ SIGNATURES = {
     "egcl_backward_l1_act": (_i, [_vp, _i, _i, _i] + [_vp] * 7),
     "egcl_backward_heads": (_i, [_vp, _i, _i, _i, _i] + [_vp] * 20),
     "egcl_backward_l1_grad": (_i, [_vp, _i, _i, _i] + [_vp] * 7),
+    "egcl_backward_gather_in": (_i, [_vp, _i, _i, _i, _i] + [_vp] * 6),
+    "egcl_backward_scatter": (_i, [_vp, _i, _i, _i, _i] + [_vp] * 9),
     "egnn_eps": (_i, [_vp, _i, _i, _i, _vp, _i] + [_vp] * 5),
     "egnn_remove_mean": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
     "schedule_table_build": (_i, [_i, C.c_double, C.c_double, _fp, _fp, _fp]),

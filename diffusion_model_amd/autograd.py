@@ -6,7 +6,8 @@ sums the edge pass produced (egcl_read_aggregates) are kept.  Backward, per laye
   node part  (N rows, small): h' = mlp_h([h | sum_m]), x' = x + sum_x / (G + 1), G = sqrt(sum d^2) -- differentiated
              with torch ops on the saved sums; yields the gradients of the three segment sums.
   edge part  (E rows, the cost): recomputed in edge chunks as the chain
-             egcl_backward_l1_act -> GEMM -> egcl_backward_heads -> GEMM, GEMM -> egcl_backward_l1_grad -> GEMM, GEMM
+             egcl_backward_gather_in, egcl_backward_l1_act -> GEMM -> egcl_backward_heads -> GEMM, GEMM ->
+             egcl_backward_l1_grad -> GEMM, GEMM -> egcl_backward_scatter
              where the stage functions are HIP kernels of the C ABI (gathers, SiLU and SiLU', scalar heads, gate,
              row reductions, bias / w3 / wa column sums, in place on the GEMM buffers) and the GEMMs are the plain
              dgrad / wgrad products of the four Linear layers, run by the BLAS library through torch.mm.
@@ -33,23 +34,44 @@ def _segment_scale(S, scope_graph, node_graph):
     return c.index_select(0, node_graph).unsqueeze(1) if scope_graph else c
 
 
+def _round_up(v, m):
+    return (v + m - 1) // m * m
+
+
 class _Workspace:
     """[chunk, width] buffers of the edge part, allocated once per backward call"""
 
-    def __init__(self, rows, Wx, Wm, M, dtype, device):
+    def __init__(self, rows, H, Wx, Wm, M, dtype, device):
+        rows = _round_up(rows, 64)
         e = lambda *shape, dt=dtype: torch.empty(*shape, dtype=dt, device=device)
+        self.K1P = _round_up(2 * H + 2, 8)
         self.s1x, self.s1m = e(rows, Wx), e(rows, Wm)
         self.a2x, self.a2m = e(rows, Wx), e(rows, M)
         self.g1x, self.g1m = e(rows, Wx), e(rows, Wm)
+        self.inp, self.g_in = e(rows, self.K1P), e(rows, self.K1P)
+        self.d2 = e(rows, dt=torch.float32)
         self.g_diff = e(rows, 3, dt=torch.float32)
 
 
-def _edge_backward(layer, prec, ws, h, x, dst32, src32, seg_of_node, g_am, g_ax, g_S, g_h, g_x, grads):
+def _wgrad(g, a, n_pad, splits):
+    """g[:n_pad]^T . a[:n_pad] with the long edge dimension cut into `splits` batched products (the BLAS library's
+    single-GEMM choice for K = 2^18 and a small output runs at a fraction of its batched rate); fp32 result"""
+    S = splits
+    while S > 1 and (n_pad % S or n_pad // S < 1024):
+        S //= 2
+    if S == 1:
+        return torch.mm(g[:n_pad].t(), a[:n_pad]).float()
+    gv, av = g[:n_pad].view(S, n_pad // S, -1), a[:n_pad].view(S, n_pad // S, -1)
+    return torch.bmm(gv.transpose(1, 2), av).float().sum(0)
+
+
+def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_S, g_h, g_x, grads):
     """adds the edge part's contributions to g_h, g_x and to the parameter gradients in `grads`"""
     L = _lib.lib()
     st = _lib.stream_ptr()
+    P = _lib.ptr
     dt = ws.s1x.dtype
-    H = h.shape[1]
+    H, K1P = h.shape[1], ws.K1P
     lin_x0, lin_x2, lin_x4 = layer.mlp_x[0], layer.mlp_x[2], layer.mlp_x[4]
     lin_m0, lin_m2, att = layer.mlp_m[0], layer.mlp_m[2], layer.attention[0]
     Wx, Wm, M = lin_x0.out_features, lin_m0.out_features, lin_m2.out_features
@@ -57,19 +79,20 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, seg_of_node, g_am, g_ax,
 
     def tables(lin):   # per-node halves of the first Linear layer (:56's concatenation factorised)
         w = lin.weight.detach()
-        P = torch.addmm(lin.bias.detach(), h, w[:, :H].t()).contiguous()
-        Q = torch.mm(h, w[:, H:2 * H].t()).contiguous()
-        return P, Q, w[:, 2 * H].contiguous()
+        Pn = torch.addmm(lin.bias.detach(), h, w[:, :H].t()).contiguous()
+        Qn = torch.mm(h, w[:, H:2 * H].t()).contiguous()
+        wpad = torch.zeros(w.shape[0], K1P, dtype=dt, device=h.device)
+        wpad[:, :2 * H + 1] = w
+        return Pn, Qn, w[:, 2 * H].contiguous(), wpad
 
-    Px, Qx, wdx = tables(lin_x0)
-    Pm, Qm, wdm = tables(lin_m0)
+    Px, Qx, wdx, w1x = tables(lin_x0)
+    Pm, Qm, wdm, w1m = tables(lin_m0)
     w2x, w2m = lin_x2.weight.detach().to(dt), lin_m2.weight.detach().to(dt)
-    w1x, w1m = lin_x0.weight.detach().to(dt), lin_m0.weight.detach().to(dt)
     b2x, b2m = lin_x2.bias.detach().contiguous(), lin_m2.bias.detach().contiguous()
     w3, b3 = lin_x4.weight.detach().reshape(-1).contiguous(), lin_x4.bias.detach().contiguous()
     wa, ba = att.weight.detach().reshape(-1).contiguous(), att.bias.detach().contiguous()
-    # fp32 accumulators; the first Linear layers carry their bias gradient in an extra column (ones column of `in`)
-    g_w1x, g_w1m = torch.zeros(Wx, 2 * H + 2, **f32), torch.zeros(Wm, 2 * H + 2, **f32)
+    # fp32 accumulators; the first Linear layers carry their bias gradient in column 2H+1 (ones column of `in`)
+    g_w1x, g_w1m = torch.zeros(Wx, K1P, **f32), torch.zeros(Wm, K1P, **f32)
     g_w2x, g_w2m = torch.zeros(Wx, Wx, **f32), torch.zeros(M, Wm, **f32)
     g_b2x, g_w3, g_b3 = torch.zeros(Wx, **f32), torch.zeros(Wx, **f32), torch.zeros(1, **f32)
     g_b2m, g_wa, g_ba = torch.zeros(M, **f32), torch.zeros(M, **f32), torch.zeros(1, **f32)
@@ -78,13 +101,14 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, seg_of_node, g_am, g_ax,
     rows = ws.s1x.shape[0]
     for a in range(0, E, rows):
         n = min(rows, E - a)
+        n_pad = _round_up(n, 64)
         d32, s32 = dst32[a:a + n], src32[a:a + n]
-        d_, s_ = d32.long(), s32.long()
-        diff = x.index_select(0, d_) - x.index_select(0, s_)
-        d2 = (diff * diff).sum(1).contiguous()
         s1x, s1m, a2x, a2m, g1x, g1m = ws.s1x[:n], ws.s1m[:n], ws.a2x[:n], ws.a2m[:n], ws.g1x[:n], ws.g1m[:n]
-        g_diff = ws.g_diff[:n]
-        P = _lib.ptr
+        inp, g_in, d2, g_diff = ws.inp[:n], ws.g_in[:n], ws.d2[:n], ws.g_diff[:n]
+        if n_pad > n:   # rows the split wgrad products read beyond the chunk
+            for t in (ws.s1x, ws.s1m, ws.a2x, ws.a2m, ws.g1x, ws.g1m, ws.inp):
+                t[n:n_pad].zero_()
+        _lib.check(L.egcl_backward_gather_in(st, prec, n, H, K1P, P(d32), P(s32), P(h), P(x), P(inp), P(d2)))
         _lib.check(L.egcl_backward_l1_act(st, prec, n, Wx, P(d32), P(s32), P(Px), P(Qx), P(wdx), P(d2), P(s1x)))
         _lib.check(L.egcl_backward_l1_act(st, prec, n, Wm, P(d32), P(s32), P(Pm), P(Qm), P(wdm), P(d2), P(s1m)))
         torch.mm(s1x, w2x.t(), out=a2x)
@@ -93,24 +117,19 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, seg_of_node, g_am, g_ax,
                                          P(b2x), P(w3), P(b3), P(b2m), P(wa), P(ba), P(g_diff), P(g_b2x), P(g_w3),
                                          P(g_b3), P(g_b2m), P(g_wa), P(g_ba)))
         # a2x / a2m now hold dL/da2: wgrad and dgrad of the second Linear layers
-        g_w2x += torch.mm(a2x.t(), s1x)
-        g_w2m += torch.mm(a2m.t(), s1m)
+        g_w2x += _wgrad(ws.a2x, ws.s1x, n_pad, 16)
+        g_w2m += _wgrad(ws.a2m, ws.s1m, n_pad, 32)
         torch.mm(a2x, w2x, out=g1x)
         torch.mm(a2m, w2m, out=g1m)
         _lib.check(L.egcl_backward_l1_grad(st, prec, n, Wx, P(d32), P(s32), P(Px), P(Qx), P(wdx), P(d2), P(g1x)))
         _lib.check(L.egcl_backward_l1_grad(st, prec, n, Wm, P(d32), P(s32), P(Pm), P(Qm), P(wdm), P(d2), P(g1m)))
         # first Linear layers: wgrad against in = [h_i | h_j | d2 | 1], dgrad back to the gathered inputs
-        inp = torch.cat((h.index_select(0, d_), h.index_select(0, s_), d2.unsqueeze(1), torch.ones_like(d2).unsqueeze(1)),
-                        dim=1).to(dt)
-        g_w1x += torch.mm(g1x.t(), inp)
-        g_w1m += torch.mm(g1m.t(), inp)
-        g_in = (torch.mm(g1x, w1x) + torch.mm(g1m, w1m)).float()
-        g_h.index_add_(0, d_, g_in[:, :H])
-        g_h.index_add_(0, s_, g_in[:, H:2 * H])
-        g_d2 = g_in[:, 2 * H] + g_S.index_select(0, seg_of_node.index_select(0, d_))
-        g_dd = g_diff + (2.0 * g_d2).unsqueeze(1) * diff
-        g_x.index_add_(0, d_, g_dd)
-        g_x.index_add_(0, s_, -g_dd)
+        g_w1x += _wgrad(ws.g1x, ws.inp, n_pad, 32)
+        g_w1m += _wgrad(ws.g1m, ws.inp, n_pad, 32)
+        torch.mm(g1x, w1x, out=g_in)
+        g_in.addmm_(g1m, w1m)
+        _lib.check(L.egcl_backward_scatter(st, prec, n, H, K1P, P(d32), P(s32), P(x), P(g_in), P(g_diff), P(g_S),
+                                           P(node_seg), P(g_h), P(g_x)))
 
     def acc(p, g):
         grads[p] = grads.get(p, 0) + g.reshape(p.shape)
@@ -156,7 +175,7 @@ class _EGNNFunction(torch.autograd.Function):
         saved = ctx.saved_tensors
         dst32, src32 = plan.edge_dst, plan.edge_src
         node_graph = plan.node_graph.long()
-        seg_of_node = node_graph if scope_graph else torch.zeros_like(node_graph)
+        node_seg = plan.node_graph if scope_graph else None   # int32 segment of the d^2 sum each node belongs to
         gh = torch.zeros_like(saved[0]) if gh is None else gh.contiguous().float()
         gx = torch.zeros_like(saved[1]) if gx is None else gx.contiguous().float()
         grads = {}
@@ -164,7 +183,7 @@ class _EGNNFunction(torch.autograd.Function):
         E = dst32.numel()
         ws = None
         if E > 0:
-            ws = _Workspace(min(EDGE_CHUNK, E), layers[0].mlp_x[0].out_features, layers[0].mlp_m[0].out_features, d0["M"],
+            ws = _Workspace(min(EDGE_CHUNK, E), d0["H"], layers[0].mlp_x[0].out_features, layers[0].mlp_m[0].out_features, d0["M"],
                             torch.bfloat16 if prec == _lib.PREC_BF16 else torch.float32, gh.device)
         for l in reversed(range(len(layers))):
             layer = layers[l]
@@ -188,7 +207,7 @@ class _EGNNFunction(torch.autograd.Function):
                     grads[p] = grads.get(p, 0) + g
             # edge part
             if E > 0:
-                _edge_backward(layer, prec, ws, h_l, x_l, dst32, src32, seg_of_node, g_am, g_ax, g_S, g_h, g_x, grads)
+                _edge_backward(layer, prec, ws, h_l, x_l, dst32, src32, node_seg, g_am, g_ax, g_S.contiguous(), g_h, g_x, grads)
             gh, gx = g_h, g_x
         flat = []
         for layer in layers:

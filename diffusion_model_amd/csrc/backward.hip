@@ -21,6 +21,40 @@ template <> struct Io<__bf16> {
   static __device__ __forceinline__ void st(__bf16* p, float v) { *p = (__bf16)v; }
 };
 
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+// V consecutive elements (V = 1 or 4; 4 = one 16-byte float or 8-byte bf16 access)
+template <typename T, int V> struct VecIo;
+template <typename T> struct VecIo<T, 1> {
+  static __device__ __forceinline__ void ld(const T* p, float (&o)[1]) { o[0] = Io<T>::ld(p); }
+  static __device__ __forceinline__ void st(T* p, const float (&v)[1]) { Io<T>::st(p, v[0]); }
+};
+template <> struct VecIo<float, 4> {
+  static __device__ __forceinline__ void ld(const float* p, float (&o)[4]) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = v[j];
+  }
+  static __device__ __forceinline__ void st(float* p, const float (&v)[4]) {
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = v[j];
+    *reinterpret_cast<f32x4*>(p) = o;
+  }
+};
+template <> struct VecIo<__bf16, 4> {
+  static __device__ __forceinline__ void ld(const __bf16* p, float (&o)[4]) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (float)v[j];
+  }
+  static __device__ __forceinline__ void st(__bf16* p, const float (&v)[4]) {
+    bf16x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (__bf16)v[j];
+    *reinterpret_cast<bf16x4*>(p) = o;
+  }
+};
+
 // s = SiLU(a), ds = dSiLU/da = sig * (1 + a * (1 - sig))
 __device__ __forceinline__ void silu_and_grad(float a, float& s, float& ds) {
   const float sg = sigmoid_f(a);
@@ -32,42 +66,33 @@ constexpr int kBwdRows = 32;   // edge rows per tile of the elementwise kernels
 
 // ---- first-layer activations: out[e][c] = SiLU(P[dst e][c] + Q[src e][c] + wd[c] * d2[e]) ---------------------
 // P = h . W1[:, :H]^T + b1 and Q = h . W1[:, H:2H]^T are per-NODE tables (:56's concatenation factorised);
-// C = columns of the table (mlp_x.0 and mlp_m.0 side by side).  GRAD = false writes the activation, GRAD = true
-// multiplies the buffer in place by SiLU'(pre-activation)  (dL/da1 = dL/ds1 * SiLU'(a1)).
-template <typename T, bool GRAD>
+// C = columns of the table.  GRAD = false writes the activation, GRAD = true multiplies the buffer in place by
+// SiLU'(pre-activation)  (dL/da1 = dL/ds1 * SiLU'(a1)).  Work items = (row, group of V columns), flat over the
+// tile so that any C keeps all threads busy.
+template <typename T, bool GRAD, int V>
 __global__ __launch_bounds__(kThreads) void bwd_l1_kernel(int n_edges, int C, const int* __restrict__ dst,
                                                            const int* __restrict__ src, const float* __restrict__ P,
                                                            const float* __restrict__ Q, const float* __restrict__ wd,
                                                            const float* __restrict__ d2, T* __restrict__ buf) {
-  const int e0 = blockIdx.x * kBwdRows, e1 = min(e0 + kBwdRows, n_edges);
-  if ((C & 3) == 0) {
-    for (int c = 4 * threadIdx.x; c < C; c += 4 * kThreads) {
-      const f32x4 w = *reinterpret_cast<const f32x4*>(wd + c);
-      for (int e = e0; e < e1; ++e) {
-        const f32x4 p = *reinterpret_cast<const f32x4*>(P + (size_t)dst[e] * C + c);
-        const f32x4 q = *reinterpret_cast<const f32x4*>(Q + (size_t)src[e] * C + c);
-        const float d = d2[e];
-        T* o = buf + (size_t)e * C + c;
+  const int e0 = blockIdx.x * kBwdRows, rows = min(kBwdRows, n_edges - e0);
+  const int G = C / V, items = rows * G;
+#pragma unroll 2
+  for (int it = threadIdx.x; it < items; it += kThreads) {
+    const int r = it / G, c = (it - r * G) * V, e = e0 + r;
+    float p[V], q[V], w[V], o[V];
+    VecIo<float, V>::ld(P + (size_t)dst[e] * C + c, p);
+    VecIo<float, V>::ld(Q + (size_t)src[e] * C + c, q);
+    VecIo<float, V>::ld(wd + c, w);
+    const float d = d2[e];
+    T* optr = buf + (size_t)e * C + c;
+    if (GRAD) VecIo<T, V>::ld(optr, o);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float s, ds;
-          silu_and_grad(fmaf(w[j], d, p[j] + q[j]), s, ds);
-          if (GRAD) Io<T>::st(o + j, Io<T>::ld(o + j) * ds);
-          else Io<T>::st(o + j, s);
-        }
-      }
+    for (int j = 0; j < V; ++j) {
+      float sv, ds;
+      silu_and_grad(fmaf(w[j], d, p[j] + q[j]), sv, ds);
+      o[j] = GRAD ? o[j] * ds : sv;
     }
-  } else {
-    for (int c = threadIdx.x; c < C; c += kThreads) {
-      const float w = wd[c];
-      for (int e = e0; e < e1; ++e) {
-        float s, ds;
-        silu_and_grad(fmaf(w, d2[e], P[(size_t)dst[e] * C + c] + Q[(size_t)src[e] * C + c]), s, ds);
-        T* o = buf + (size_t)e * C + c;
-        if (GRAD) Io<T>::st(o, Io<T>::ld(o) * ds);
-        else Io<T>::st(o, s);
-      }
-    }
+    VecIo<T, V>::st(optr, o);
   }
 }
 
@@ -92,7 +117,7 @@ struct HeadsParams {
   float *g_diff, *g_b2x, *g_w3, *g_b3, *g_b2m, *g_wa, *g_ba;
 };
 
-template <typename T>
+template <typename T, int V>
 __global__ __launch_bounds__(kThreads) void bwd_heads_kernel(const HeadsParams p) {
   extern __shared__ float cs[];   // column sums kept across the tiles of this workgroup: [b2x | w3 | b2m | wa]
   __shared__ float s_gsc[kBwdRows], s_gate[kBwdRows], s_coef[kBwdRows];
@@ -112,15 +137,27 @@ __global__ __launch_bounds__(kThreads) void bwd_heads_kernel(const HeadsParams p
     for (int r = wave; r < rows; r += kWaves) {
       const int e = e0 + r, i = p.dst[e], j = p.src[e];
       float acc = 0.f;
-      for (int c = lane; c < W; c += 64) {
-        const float a = Io<T>::ld(a2x + (size_t)e * W + c) + p.b2x[c];
-        acc = fmaf(p.w3[c], silu_f(a), acc);
+      for (int c = V * lane; c < W; c += V * 64) {
+        float a[V], b[V], w[V];
+        VecIo<T, V>::ld(a2x + (size_t)e * W + c, a);
+        VecIo<float, V>::ld(p.b2x + c, b);
+        VecIo<float, V>::ld(p.w3 + c, w);
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc = fmaf(w[k], silu_f(a[k] + b[k]), acc);
       }
       float z = 0.f, dot = 0.f;
-      for (int c = lane; c < M; c += 64) {
-        const float m = silu_f(Io<T>::ld(a2m + (size_t)e * M + c) + p.b2m[c]);
-        z = fmaf(p.wa[c], m, z);
-        dot = fmaf(p.g_agg_m[(size_t)i * M + c], m, dot);
+      for (int c = V * lane; c < M; c += V * 64) {
+        float a[V], b[V], w[V], g[V];
+        VecIo<T, V>::ld(a2m + (size_t)e * M + c, a);
+        VecIo<float, V>::ld(p.b2m + c, b);
+        VecIo<float, V>::ld(p.wa + c, w);
+        VecIo<float, V>::ld(p.g_agg_m + (size_t)i * M + c, g);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+          const float m = silu_f(a[k] + b[k]);
+          z = fmaf(w[k], m, z);
+          dot = fmaf(g[k], m, dot);
+        }
       }
       acc = wave_sum(acc); z = wave_sum(z); dot = wave_sum(dot);
       if (lane == 0) {
@@ -136,35 +173,57 @@ __global__ __launch_bounds__(kThreads) void bwd_heads_kernel(const HeadsParams p
       }
     }
     __syncthreads();
-    // phase 2: one thread per column, rows in sequence; column sums stay with the owning thread
-    for (int c = tid; c < W; c += kThreads) {
-      const float b = p.b2x[c], w = p.w3[c];
-      float cb = 0.f, cw = 0.f;
+    // phase 2: one thread per group of V columns, rows in sequence; column sums stay with the owning thread
+    for (int c = V * tid; c < W; c += V * kThreads) {
+      float b[V], w[V], cb[V], cw[V];
+      VecIo<float, V>::ld(p.b2x + c, b);
+      VecIo<float, V>::ld(p.w3 + c, w);
+#pragma unroll
+      for (int k = 0; k < V; ++k) cb[k] = cw[k] = 0.f;
+#pragma unroll 4
       for (int r = 0; r < rows; ++r) {
-        T* a = a2x + (size_t)(e0 + r) * W + c;
-        float s, ds;
-        silu_and_grad(Io<T>::ld(a) + b, s, ds);
-        const float g = s_gsc[r] * w * ds;
-        Io<T>::st(a, g);
-        cb += g;
-        cw = fmaf(s_gsc[r], s, cw);
+        T* ap = a2x + (size_t)(e0 + r) * W + c;
+        float a[V];
+        VecIo<T, V>::ld(ap, a);
+        const float gsc = s_gsc[r];
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+          float sv, ds;
+          silu_and_grad(a[k] + b[k], sv, ds);
+          a[k] = gsc * w[k] * ds;
+          cb[k] += a[k];
+          cw[k] = fmaf(gsc, sv, cw[k]);
+        }
+        VecIo<T, V>::st(ap, a);
       }
-      cs[c] += cb; cs[W + c] += cw;
+#pragma unroll
+      for (int k = 0; k < V; ++k) { cs[c + k] += cb[k]; cs[W + c + k] += cw[k]; }
     }
-    for (int c = tid; c < M; c += kThreads) {
-      const float b = p.b2m[c], w = p.wa[c];
-      float cb = 0.f, cw = 0.f;
+    for (int c = V * tid; c < M; c += V * kThreads) {
+      float b[V], w[V], cb[V], cw[V];
+      VecIo<float, V>::ld(p.b2m + c, b);
+      VecIo<float, V>::ld(p.wa + c, w);
+#pragma unroll
+      for (int k = 0; k < V; ++k) cb[k] = cw[k] = 0.f;
+#pragma unroll 4
       for (int r = 0; r < rows; ++r) {
-        T* a = a2m + (size_t)(e0 + r) * M + c;
-        float m, ds;
-        silu_and_grad(Io<T>::ld(a) + b, m, ds);
-        const float gm = fmaf(p.g_agg_m[(size_t)s_dst[r] * M + c], s_gate[r], s_coef[r] * w);
-        const float g = gm * ds;
-        Io<T>::st(a, g);
-        cb += g;
-        cw = fmaf(s_coef[r], m, cw);
+        T* ap = a2m + (size_t)(e0 + r) * M + c;
+        float a[V], g[V];
+        VecIo<T, V>::ld(ap, a);
+        VecIo<float, V>::ld(p.g_agg_m + (size_t)s_dst[r] * M + c, g);
+        const float gate = s_gate[r], coef = s_coef[r];
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+          float m, ds;
+          silu_and_grad(a[k] + b[k], m, ds);
+          a[k] = fmaf(g[k], gate, coef * w[k]) * ds;
+          cb[k] += a[k];
+          cw[k] = fmaf(coef, m, cw[k]);
+        }
+        VecIo<T, V>::st(ap, a);
       }
-      cs[2 * W + c] += cb; cs[2 * W + M + c] += cw;
+#pragma unroll
+      for (int k = 0; k < V; ++k) { cs[2 * W + c + k] += cb[k]; cs[2 * W + M + c + k] += cw[k]; }
     }
     if (tid == 0)
       for (int r = 0; r < rows; ++r) { sum_gsc += s_gsc[r]; sum_coef += s_coef[r]; }
@@ -173,6 +232,56 @@ __global__ __launch_bounds__(kThreads) void bwd_heads_kernel(const HeadsParams p
   for (int c = tid; c < W; c += kThreads) { atomicAdd(p.g_b2x + c, cs[c]); atomicAdd(p.g_w3 + c, cs[W + c]); }
   for (int c = tid; c < M; c += kThreads) { atomicAdd(p.g_b2m + c, cs[2 * W + c]); atomicAdd(p.g_wa + c, cs[2 * W + M + c]); }
   if (tid == 0) { atomicAdd(p.g_b3, sum_gsc); atomicAdd(p.g_ba, sum_coef); }
+}
+
+// ---- gather of the first Linear layers' input: in[e] = [h_i | h_j | d2 | 1 | 0...] (:56) ------------------------
+// K1P >= 2H + 2 columns (the ones column carries the bias gradient through the wgrad GEMM); also writes d2[e].
+template <typename T>
+__global__ __launch_bounds__(kThreads) void bwd_gather_kernel(int n_edges, int H, int K1P, const int* __restrict__ dst,
+                                                               const int* __restrict__ src, const float* __restrict__ h,
+                                                               const float* __restrict__ x, T* __restrict__ inp,
+                                                               float* __restrict__ d2) {
+  const size_t total = (size_t)n_edges * K1P;
+  for (size_t t = (size_t)blockIdx.x * kThreads + threadIdx.x; t < total; t += (size_t)gridDim.x * kThreads) {
+    const int e = (int)(t / K1P), c = (int)(t - (size_t)e * K1P);
+    float v = 0.f;
+    if (c < H) v = h[(size_t)dst[e] * H + c];
+    else if (c < 2 * H) v = h[(size_t)src[e] * H + c - H];
+    else if (c == 2 * H) {
+      const int i = dst[e], j = src[e];
+      const float dx = x[3 * i] - x[3 * j], dy = x[3 * i + 1] - x[3 * j + 1], dz = x[3 * i + 2] - x[3 * j + 2];
+      v = dx * dx + dy * dy + dz * dz;
+      d2[e] = v;
+    } else if (c == 2 * H + 1) v = 1.f;
+    Io<T>::st(inp + t, v);
+  }
+}
+
+// ---- scatter of dL/d(in) back to the nodes ------------------------------------------------------------------------
+// g_in[e] = dL/d[h_i | h_j | d2] (K1P columns, the rest ignored).  g_h[i] += g_in[:H], g_h[j] += g_in[H:2H];
+// dL/d(x_i - x_j) = g_diff[e] + 2 (g_in[2H] + g_S[segment of i]) (x_i - x_j)  goes to g_x[i] and, negated, g_x[j].
+template <typename T>
+__global__ __launch_bounds__(kThreads) void bwd_scatter_kernel(int n_edges, int H, int K1P, const int* __restrict__ dst,
+                                                                const int* __restrict__ src, const float* __restrict__ x,
+                                                                const T* __restrict__ g_in, const float* __restrict__ g_diff,
+                                                                const float* __restrict__ g_S, const int* __restrict__ node_seg,
+                                                                float* __restrict__ g_h, float* __restrict__ g_x) {
+  const int cols = 2 * H + 3;
+  const size_t total = (size_t)n_edges * cols;
+  for (size_t t = (size_t)blockIdx.x * kThreads + threadIdx.x; t < total; t += (size_t)gridDim.x * kThreads) {
+    const int e = (int)(t / cols), c = (int)(t - (size_t)e * cols);
+    const int i = dst[e], j = src[e];
+    const T* row = g_in + (size_t)e * K1P;
+    if (c < H) atomicAdd(g_h + (size_t)i * H + c, Io<T>::ld(row + c));
+    else if (c < 2 * H) atomicAdd(g_h + (size_t)j * H + c - H, Io<T>::ld(row + c));
+    else {
+      const int d = c - 2 * H;
+      const float gd2 = Io<T>::ld(row + 2 * H) + g_S[node_seg ? node_seg[i] : 0];
+      const float g = fmaf(2.0f * gd2, x[3 * i + d] - x[3 * j + d], g_diff[3 * (size_t)e + d]);
+      atomicAdd(g_x + 3 * (size_t)i + d, g);
+      atomicAdd(g_x + 3 * (size_t)j + d, -g);
+    }
+  }
 }
 
 // ---- segment sums of the last edge pass, as dense per-node arrays --------------------------------------------
@@ -245,13 +354,17 @@ static int bwd_l1(void* stream, int prec, int grad, int n_edges, int C, const in
   if (n_edges == 0) return EGNN_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const dim3 grid((n_edges + kBwdRows - 1) / kBwdRows), block(kThreads);
+  const bool v4 = (C & 3) == 0;
+#define L1_LAUNCH(T, G, V) \
+  hipLaunchKernelGGL((bwd_l1_kernel<T, G, V>), grid, block, 0, st, n_edges, C, dst, src, P, Q, wd, d2, static_cast<T*>(buf))
   if (prec == EGNN_PREC_BF16) {
-    if (grad) hipLaunchKernelGGL((bwd_l1_kernel<__bf16, true>), grid, block, 0, st, n_edges, C, dst, src, P, Q, wd, d2, static_cast<__bf16*>(buf));
-    else hipLaunchKernelGGL((bwd_l1_kernel<__bf16, false>), grid, block, 0, st, n_edges, C, dst, src, P, Q, wd, d2, static_cast<__bf16*>(buf));
+    if (grad) { if (v4) L1_LAUNCH(__bf16, true, 4); else L1_LAUNCH(__bf16, true, 1); }
+    else { if (v4) L1_LAUNCH(__bf16, false, 4); else L1_LAUNCH(__bf16, false, 1); }
   } else {
-    if (grad) hipLaunchKernelGGL((bwd_l1_kernel<float, true>), grid, block, 0, st, n_edges, C, dst, src, P, Q, wd, d2, static_cast<float*>(buf));
-    else hipLaunchKernelGGL((bwd_l1_kernel<float, false>), grid, block, 0, st, n_edges, C, dst, src, P, Q, wd, d2, static_cast<float*>(buf));
+    if (grad) { if (v4) L1_LAUNCH(float, true, 4); else L1_LAUNCH(float, true, 1); }
+    else { if (v4) L1_LAUNCH(float, false, 4); else L1_LAUNCH(float, false, 1); }
   }
+#undef L1_LAUNCH
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }
@@ -288,8 +401,49 @@ int egcl_backward_heads(void* stream, int prec, int n_edges, int W, int M, const
   const int tiles = (n_edges + kBwdRows - 1) / kBwdRows;
   const dim3 grid(tiles < 2048 ? tiles : 2048), block(kThreads);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (prec == EGNN_PREC_BF16) hipLaunchKernelGGL(bwd_heads_kernel<__bf16>, grid, block, smem, st, p);
-  else hipLaunchKernelGGL(bwd_heads_kernel<float>, grid, block, smem, st, p);
+  const bool v4 = (W & 3) == 0 && (M & 3) == 0;
+  if (prec == EGNN_PREC_BF16) {
+    if (v4) hipLaunchKernelGGL((bwd_heads_kernel<__bf16, 4>), grid, block, smem, st, p);
+    else hipLaunchKernelGGL((bwd_heads_kernel<__bf16, 1>), grid, block, smem, st, p);
+  } else {
+    if (v4) hipLaunchKernelGGL((bwd_heads_kernel<float, 4>), grid, block, smem, st, p);
+    else hipLaunchKernelGGL((bwd_heads_kernel<float, 1>), grid, block, smem, st, p);
+  }
+  EGNN_HIP(hipGetLastError());
+  return EGNN_OK;
+}
+
+int egcl_backward_gather_in(void* stream, int prec, int n_edges, int H, int K1P, const int32_t* dst, const int32_t* src,
+                            const float* h, const float* x, void* in_out, float* d2_out) {
+  if (n_edges < 0 || H <= 0 || K1P < 2 * H + 2) { set_error("bad egcl_backward_gather_in sizes"); return EGNN_EINVAL; }
+  if (prec != EGNN_PREC_F32 && prec != EGNN_PREC_BF16) { set_error("bad precision %d", prec); return EGNN_EINVAL; }
+  if (n_edges == 0) return EGNN_OK;
+  if (!dst || !src || !h || !x || !in_out || !d2_out) { set_error("bad egcl_backward_gather_in arguments"); return EGNN_EINVAL; }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const size_t total = (size_t)n_edges * K1P;
+  const dim3 grid((unsigned)((total + kThreads - 1) / kThreads < 65536 ? (total + kThreads - 1) / kThreads : 65536)), block(kThreads);
+  if (prec == EGNN_PREC_BF16)
+    hipLaunchKernelGGL(bwd_gather_kernel<__bf16>, grid, block, 0, st, n_edges, H, K1P, dst, src, h, x, static_cast<__bf16*>(in_out), d2_out);
+  else
+    hipLaunchKernelGGL(bwd_gather_kernel<float>, grid, block, 0, st, n_edges, H, K1P, dst, src, h, x, static_cast<float*>(in_out), d2_out);
+  EGNN_HIP(hipGetLastError());
+  return EGNN_OK;
+}
+
+int egcl_backward_scatter(void* stream, int prec, int n_edges, int H, int K1P, const int32_t* dst, const int32_t* src,
+                          const float* x, const void* g_in, const float* g_diff, const float* g_sq_sums,
+                          const int32_t* node_segment, float* g_h, float* g_x) {
+  if (n_edges < 0 || H <= 0 || K1P < 2 * H + 1) { set_error("bad egcl_backward_scatter sizes"); return EGNN_EINVAL; }
+  if (prec != EGNN_PREC_F32 && prec != EGNN_PREC_BF16) { set_error("bad precision %d", prec); return EGNN_EINVAL; }
+  if (n_edges == 0) return EGNN_OK;
+  if (!dst || !src || !x || !g_in || !g_diff || !g_sq_sums || !g_h || !g_x) { set_error("bad egcl_backward_scatter arguments"); return EGNN_EINVAL; }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const size_t total = (size_t)n_edges * (2 * H + 3);
+  const dim3 grid((unsigned)((total + kThreads - 1) / kThreads < 65536 ? (total + kThreads - 1) / kThreads : 65536)), block(kThreads);
+  if (prec == EGNN_PREC_BF16)
+    hipLaunchKernelGGL(bwd_scatter_kernel<__bf16>, grid, block, 0, st, n_edges, H, K1P, dst, src, x, static_cast<const __bf16*>(g_in), g_diff, g_sq_sums, node_segment, g_h, g_x);
+  else
+    hipLaunchKernelGGL(bwd_scatter_kernel<float>, grid, block, 0, st, n_edges, H, K1P, dst, src, x, static_cast<const float*>(g_in), g_diff, g_sq_sums, node_segment, g_h, g_x);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }

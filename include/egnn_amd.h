@@ -130,6 +130,18 @@ int egcl_backward_l1_grad(void* stream, int prec, int n_edges, int C, const int3
                           const float* d_P, const float* d_Q, const float* d_wd, const float* d_d2,
                           void* d_g_s1_inout);
 
+/* in[e] = [h_i | h_j | d2 | 1 | 0 ...] (:56; K1P >= 2H+2 columns, the ones column carries the bias gradient through
+ * the wgrad GEMM) in the storage type of prec, and d2[e] = |x_i - x_j|^2 as float. */
+int egcl_backward_gather_in(void* stream, int prec, int n_edges, int H, int K1P, const int32_t* d_dst,
+                            const int32_t* d_src, const float* d_h, const float* d_x, void* d_in_out, float* d_d2_out);
+/* Adjoint of the gather: g_in [n_edges,K1P] = dL/d[h_i | h_j | d2 | ...] (storage type of prec).
+ * g_h[i] += g_in[:H], g_h[j] += g_in[H:2H]; dL/d(x_i-x_j) = g_diff[e] + 2 (g_in[2H] + g_sq_sums[segment of i]) (x_i-x_j)
+ * is added to g_x[i] and subtracted from g_x[j] (fp32 atomic adds).  node_segment [N] maps a node to its entry of
+ * g_sq_sums (the gradient of egcl_read_aggregates' sq_sums); NULL = one sum for the whole call. */
+int egcl_backward_scatter(void* stream, int prec, int n_edges, int H, int K1P, const int32_t* d_dst,
+                          const int32_t* d_src, const float* d_x, const void* d_g_in, const float* d_g_diff,
+                          const float* d_g_sq_sums, const int32_t* d_node_segment, float* d_g_h, float* d_g_x);
+
 /* EquivariantGNN.forward(edge_index, h, x) -> (h_L, x_L) (:85-88): all L layers. */
 int egnn_forward(egnn_ctx* ctx, void* stream, int prec, int norm_scope,
                  const float* d_h, const float* d_x, float* d_h_out, float* d_x_out);
