@@ -79,8 +79,12 @@ def num_layers(sd: StateDict) -> int:
 
 def egcl_forward(sd: StateDict, l: int, edge_index: torch.Tensor, h: torch.Tensor,
                  x: torch.Tensor, norm_scope: str = "call",
-                 graph_ptr: Optional[torch.Tensor] = None):
+                 graph_ptr: Optional[torch.Tensor] = None, return_aggregates: bool = False):
     """One EGCL layer (EquivariantGraphNeuralNetwork.py:55-71).
+
+    return_aggregates: also return the three segment sums of the layer -- sum of gated messages [N,M],
+    sum of (x_i - x_j) * s before the 1/(G+1) factor [N,3], and the sum(s) of d^2 the normaliser G is the
+    root of ([1] or [B]) -- the quantities egcl_read_aggregates hands to the backward.
 
     norm_scope='call'  : literal reference -- the coordinate normaliser
                          ``torch.norm(coords_i - coords_j)`` (:64, no dim) is ONE
@@ -112,7 +116,9 @@ def egcl_forward(sd: StateDict, l: int, edge_index: torch.Tensor, h: torch.Tenso
     s = F.silu(F.linear(inp, W("mlp_x.0"), B("mlp_x.0")))
     s = F.silu(F.linear(s, W("mlp_x.2"), B("mlp_x.2")))
     s = F.linear(s, W("mlp_x.4"), B("mlp_x.4"))
+    raw_x = torch.zeros_like(x).index_add_(0, row, diff * s)
     if norm_scope == "call":
+        sq = (diff * diff).sum().reshape(1)
         msg_x = diff * s / (torch.norm(diff) + 1)
     elif norm_scope == "graph":
         assert graph_ptr is not None
@@ -121,10 +127,13 @@ def egcl_forward(sd: StateDict, l: int, edge_index: torch.Tensor, h: torch.Tenso
         eg = node_graph.index_select(0, row)
         ss = torch.zeros(nb, dtype=h.dtype).index_add_(0, eg, (diff * diff).sum(1))
         G = torch.sqrt(ss)
+        sq = ss
         msg_x = diff * s / (G.index_select(0, eg).unsqueeze(1) + 1)
     else:
         raise ValueError(norm_scope)
     agg_x = torch.zeros_like(x).index_add_(0, row, msg_x)
+    if return_aggregates:
+        return h_new, x + agg_x, (agg_m, raw_x, sq)
     return h_new, x + agg_x
 
 
