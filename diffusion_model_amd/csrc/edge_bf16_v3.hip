@@ -133,14 +133,14 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
   // ---- K-loop ----
   const int NC = KP / kKC3, KS = KP / 16;
   const int brow = tid >> 3, kg = tid & 7;   // this thread builds rows brow and brow + 64
-  const rsrc_t rs_tab = make_rsrc(p.table, (p.dbg & 2) ? 0u : (unsigned)((size_t)p.N * p.TC * 4));
+  const rsrc_t rs_tab = make_rsrc(p.table, (p.dbg & 2) ? 0u : (unsigned)((size_t)p.N * p.TC * 2));
   const rsrc_t rs_w = make_rsrc(IS_M ? p.w2m : p.w2x, (p.dbg & 1) ? 0u : (unsigned)((size_t)(IS_M ? p.MP : p.WxP) * KP * 2));
-  const unsigned vdst0 = (unsigned)s_dst[brow] * (unsigned)p.TC * 4u + (unsigned)kg * 32u;
-  const unsigned vsrc0 = (unsigned)s_src[brow] * (unsigned)p.TC * 4u + (unsigned)kg * 32u;
-  const unsigned vdst1 = (unsigned)s_dst[brow + 64] * (unsigned)p.TC * 4u + (unsigned)kg * 32u;
-  const unsigned vsrc1 = (unsigned)s_src[brow + 64] * (unsigned)p.TC * 4u + (unsigned)kg * 32u;
+  const unsigned vdst0 = (unsigned)s_dst[brow] * (unsigned)p.TC * 2u + (unsigned)kg * 16u;
+  const unsigned vsrc0 = (unsigned)s_src[brow] * (unsigned)p.TC * 2u + (unsigned)kg * 16u;
+  const unsigned vdst1 = (unsigned)s_dst[brow + 64] * (unsigned)p.TC * 2u + (unsigned)kg * 16u;
+  const unsigned vsrc1 = (unsigned)s_src[brow + 64] * (unsigned)p.TC * 2u + (unsigned)kg * 16u;
   const float d2r0 = s_d2[brow], d2r1 = s_d2[brow + 64];
-  const unsigned offP = (IS_M ? 2u * p.WxP : 0u) * 4u, offQ = (IS_M ? 2u * p.WxP + p.WmP : (unsigned)p.WxP) * 4u;
+  const unsigned offP = (IS_M ? 2u * p.WxP : 0u) * 2u, offQ = (IS_M ? 2u * p.WxP + p.WmP : (unsigned)p.WxP) * 2u;   // fp16 table
   char* slot0 = s_a1 + ((size_t)kg * kRPAD3 + brow) * 16;
   char* slot1 = slot0 + 64 * 16;
   const unsigned lane16 = lane * 16u;
@@ -158,11 +158,11 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
       for (int i = 0; i < 16; ++i) acc[rb][cb][i] = 0.f;
 
   {  // chunk 0
-    Unit u;
-    unit_load(u, rs_tab, vdst0, vsrc0, offP, offQ);
-    unit_finish(u, s_wd + kg * 8, d2r0, slot0);
-    unit_load(u, rs_tab, vdst1, vsrc1, offP, offQ);
-    unit_finish(u, s_wd + kg * 8, d2r1, slot1);
+    UnitH u;
+    unith_load(u, rs_tab, vdst0, vsrc0, offP, offQ);
+    unith_finish(u, s_wd + kg * 8, d2r0, slot0);
+    unith_load(u, rs_tab, vdst1, vsrc1, offP, offQ);
+    unith_finish(u, s_wd + kg * 8, d2r1, slot1);
   }
   bf16x8 bq[4][CB];   // weight fragments of the 4 k-steps of the current chunk
 #pragma unroll
@@ -171,6 +171,27 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
     for (int cb = 0; cb < CB; ++cb) bq[s][cb] = ldbuf_bf16x8(rs_w, lane16, w0 + ((unsigned)cb * KS + s) * 1024u);
   __syncthreads();
 
+#ifdef EGNN_EXP_STAMP
+  const bool stamp_wg = blockIdx.x == gridDim.x / 2;
+  unsigned long long* st_base = p.stamps + ((size_t)(IS_M ? 1 : 0) * 8 + wave) * 32 * 4;
+#define STAMP(c, k)                                                                               \
+  do {                                                                                            \
+    unsigned long long t_;                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    if (stamp_wg && lane == 0 && (c) < 32) st_base[(c) * 4 + (k)] = t_;                           \
+  } while (0)
+#else
+#define STAMP(c, k)
+#endif
+#ifdef EGNN_EXP_STAMP2   // finer stamps inside the first half of a chunk (replaces the meaning of slots 1..3)
+#define STAMP2(c, k, cond) do { if (cond) STAMP(c, k); } while (0)
+#define STAMP1(c, k)
+#else
+#define STAMP2(c, k, cond)
+#define STAMP1(c, k) STAMP(c, k)
+#endif
   // matrix phase of chunk c: 4 k-steps x (4 row blocks x CB column blocks)
   // Operand pipeline of the matrix phase: the weight fragments of k-step s of chunk c+1 are requested right
   // after the MFMAs of k-step s of chunk c were issued (a whole chunk = 4 k-steps of distance, enough to cover
@@ -209,6 +230,7 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) bq[s][cb] = ldbuf_bf16x8(rs_w, lane16, w0 + (unsigned)cb * KS * 1024u + ksn);
       }
+      if (s == 0) STAMP2(c, 2, wave < 4);
     }
 #undef LDS_WAIT
 #undef LDS_RD
@@ -241,54 +263,47 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
     }
 #endif
   };
-  Unit u0, u1;
+  UnitH u0, u1;
   auto vload = [&](const int c) {   // table rows for the activations of chunk c
-    const unsigned kb = (unsigned)c * kKC3 * 4u;
-    unit_load(u0, rs_tab, vdst0, vsrc0, offP + kb, offQ + kb);
-    unit_load(u1, rs_tab, vdst1, vsrc1, offP + kb, offQ + kb);
+    const unsigned kb = (unsigned)c * kKC3 * 2u;
+    unith_load(u0, rs_tab, vdst0, vsrc0, offP + kb, offQ + kb);
+    unith_load(u1, rs_tab, vdst1, vsrc1, offP + kb, offQ + kb);
   };
   auto vfinish = [&](const int c) {  // SiLU + bf16 pack of chunk c into its LDS buffer
     const size_t nbuf = (size_t)(c & 1) * kA1_3;
     // vector work wins issue arbitration over the partner wave's MFMAs (which only need 1 slot in 4)
     __builtin_amdgcn_s_setprio(3);
-    unit_finish(u0, s_wd + c * kKC3 + kg * 8, d2r0, slot0 + nbuf);
-    unit_finish(u1, s_wd + c * kKC3 + kg * 8, d2r1, slot1 + nbuf);
+    unith_finish(u0, s_wd + c * kKC3 + kg * 8, d2r0, slot0 + nbuf);
+    STAMP2(c - 1, 1, wave >= 4);
+    unith_finish(u1, s_wd + c * kKC3 + kg * 8, d2r1, slot1 + nbuf);
+    STAMP2(c - 1, 2, wave >= 4);
     __builtin_amdgcn_s_setprio(0);
   };
   // The two waves that share a SIMD (w and w+4) run the chunk in opposite phase: waves 0-3 multiply chunk c
   // and then build chunk c+1, waves 4-7 build chunk c+1 first (from table rows requested one chunk earlier)
   // and then multiply chunk c -- one wave's vector work runs under its partner's matrix work instead of
   // both alternating in lockstep.  One barrier per chunk either way.
-#ifdef EGNN_EXP_STAMP
-  const bool stamp_wg = blockIdx.x == gridDim.x / 2;
-  unsigned long long* st_base = p.stamps + ((size_t)(IS_M ? 1 : 0) * 8 + wave) * 32 * 4;
-#define STAMP(c, k)                                                                               \
-  do {                                                                                            \
-    unsigned long long t_;                                                                        \
-    __builtin_amdgcn_sched_barrier(0);                                                            \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
-    __builtin_amdgcn_sched_barrier(0);                                                            \
-    if (stamp_wg && lane == 0 && (c) < 32) st_base[(c) * 4 + (k)] = t_;                           \
-  } while (0)
-#else
-#define STAMP(c, k)
-#endif
 #ifdef EGNN_EXP_NO_BUILD
   for (int c = 0; c < NC; ++c) { mphase(c, c == NC - 1); __syncthreads(); }
 #else
   // (the steady-state loop bodies are branch-free so that hipcc's waitcnt insertion can keep counted
   // vmcnt waits across the back edge instead of draining the queue at every control-flow join)
   if (wave < 4) {
+    // table rows of chunk c+2 are requested as soon as the units of chunk c+1 are consumed, ahead of the barrier:
+    // the vector-memory issue time (1 KiB per instruction through a 64 B/clk path) then overlaps this group's
+    // barrier wait instead of delaying its matrix phase.  (Clamped index: the last request is a harmless repeat.)
+    if (NC > 1) vload(1);
     for (int c = 0; c < NC - 1; ++c) {
       STAMP(c, 0);
-      vload(c + 1);
-      __builtin_amdgcn_sched_barrier(0);   // keep the table-row requests ahead of the matrix phase
+      STAMP2(c, 1, true);
       mphase(c, false);
-      STAMP(c, 1);
+      STAMP1(c, 1);
+      STAMP2(c, 3, true);
       vfinish(c + 1);
-      STAMP(c, 2);
+      vload(c + 2 < NC ? c + 2 : NC - 1);
+      STAMP1(c, 2);
       __syncthreads();
-      STAMP(c, 3);
+      STAMP1(c, 3);
     }
     mphase(NC - 1, true);
     __syncthreads();
@@ -299,11 +314,12 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
       vfinish(c + 1);
       vload(c + 2);
       __builtin_amdgcn_sched_barrier(0);
-      STAMP(c, 1);
+      STAMP1(c, 1);
+      STAMP2(c, 3, true);
       mphase(c, false);
-      STAMP(c, 2);
+      STAMP1(c, 2);
       __syncthreads();
-      STAMP(c, 3);
+      STAMP1(c, 3);
     }
     if (NC > 1) {
       vfinish(NC - 1);

@@ -110,10 +110,16 @@ __global__ void pack_first(const float* __restrict__ x0_w, const float* __restri
 // node_pre: table[n][col] = b1cat[col] + sum_h h[n][h] * w1catT[h][col]
 // ------------------------------------------------------------------------------------------------
 constexpr int kPreNodes = 16;
+// fp16 table entries saturate instead of overflowing to inf (pre-activations of that size are far in SiLU's
+// linear / zero tails either way)
+__device__ __forceinline__ void table_store(float* p, float v) { *p = v; }
+__device__ __forceinline__ void table_store(_Float16* p, float v) { *p = (_Float16)fminf(fmaxf(v, -60000.f), 60000.f); }
+
+template <typename TT>
 __global__ __launch_bounds__(kThreads) void node_pre_kernel(const float* __restrict__ h, int N, int H,
                                                             const float* __restrict__ w1catT,
                                                             const float* __restrict__ b1cat, int TC,
-                                                            float* __restrict__ table) {
+                                                            TT* __restrict__ table) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* hs = reinterpret_cast<float*>(smem_raw);  // [kPreNodes][H]
   const int n0 = blockIdx.x * kPreNodes;
@@ -135,17 +141,18 @@ __global__ __launch_bounds__(kThreads) void node_pre_kernel(const float* __restr
   }
 #pragma unroll
   for (int i = 0; i < kPreNodes; ++i)
-    if (n0 + i < N) table[(size_t)(n0 + i) * TC + col] = acc[i];
+    if (n0 + i < N) table_store(table + (size_t)(n0 + i) * TC + col, acc[i]);
 }
 
 // The same table on the matrix cores: exact fp32 v_mfma_f32_32x32x2_f32 (K = H is tiny, the kernel is bound by
 // the 268 MB table write).  Workgroup = 32 nodes x 512 columns, wave w owns 4 column blocks; A = h tile from LDS,
 // B = w1catT rows straight from L2 (128 B per half-wave, coalesced), accumulator initialised with the bias.
 constexpr int kPre2Nodes = 32, kPre2Cols = 512;
+template <typename TT>
 __global__ __launch_bounds__(kThreads) void node_pre_mfma_kernel(const float* __restrict__ h, int N, int H,
                                                                  const float* __restrict__ w1catT,
                                                                  const float* __restrict__ b1cat, int TC,
-                                                                 float* __restrict__ table) {
+                                                                 TT* __restrict__ table) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* hs = reinterpret_cast<float*>(smem_raw);  // [HP2][33], HP2 = H rounded up to even
   const int HP2 = (H + 1) & ~1;
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(kThreads) void node_pre_mfma_kernel(const float* __
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int n = n0 + acc_row(i, lane);
-        if (n < N) table[(size_t)n * TC + col] = acc[j][i];
+        if (n < N) table_store(table + (size_t)n * TC + col, acc[j][i]);
       }
     }
   }
@@ -837,12 +844,22 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
     static const int pre_sel = getenv("EGNN_PRE") ? atoi(getenv("EGNN_PRE")) : 2;   // A/B switch
     if (pre_sel >= 2 && c->H <= 64) {
       dim3 grid((N + kPre2Nodes - 1) / kPre2Nodes, (c->TC + kPre2Cols - 1) / kPre2Cols);
-      hipLaunchKernelGGL(node_pre_mfma_kernel, grid, dim3(kThreads), (size_t)((c->H + 1) & ~1) * 33 * sizeof(float), st,
-                         h, N, c->H, w1catT, b1cat, c->TC, c->table);
+      const size_t sm = (size_t)((c->H + 1) & ~1) * 33 * sizeof(float);
+      if (path == 3)   // the v3 edge kernels read a half-precision table
+        hipLaunchKernelGGL(node_pre_mfma_kernel<_Float16>, grid, dim3(kThreads), sm, st, h, N, c->H, w1catT, b1cat,
+                           c->TC, reinterpret_cast<_Float16*>(c->table));
+      else
+        hipLaunchKernelGGL(node_pre_mfma_kernel<float>, grid, dim3(kThreads), sm, st, h, N, c->H, w1catT, b1cat, c->TC,
+                           c->table);
     } else {
       dim3 grid((N + kPreNodes - 1) / kPreNodes, (c->TC + kThreads - 1) / kThreads);
-      hipLaunchKernelGGL(node_pre_kernel, grid, dim3(kThreads), (size_t)kPreNodes * c->H * sizeof(float), st, h, N,
-                         c->H, w1catT, b1cat, c->TC, c->table);
+      const size_t sm = (size_t)kPreNodes * c->H * sizeof(float);
+      if (path == 3)
+        hipLaunchKernelGGL(node_pre_kernel<_Float16>, grid, dim3(kThreads), sm, st, h, N, c->H, w1catT, b1cat, c->TC,
+                           reinterpret_cast<_Float16*>(c->table));
+      else
+        hipLaunchKernelGGL(node_pre_kernel<float>, grid, dim3(kThreads), sm, st, h, N, c->H, w1catT, b1cat, c->TC,
+                           c->table);
     }
     hipLaunchKernelGGL(node_d2_kernel, dim3((N + 255) / 256), dim3(256), 0, st, x, c->row_ptr, c->edge_src, N,
                        c->node_d2);

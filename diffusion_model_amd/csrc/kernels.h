@@ -36,7 +36,7 @@ struct EdgeParams {
   const int* edge_src;
   const int* row_ptr;
   const float* x;      // [N][3]
-  const float* table;  // [N][TC]
+  const float* table;  // [N][TC]  (fp16 [N][TC] for the v3 path)
   int TC, WxP, WmP, MP, cbx, cbm;
   const float *wdx, *wdm, *b2x, *w3x, *b2m, *wa, *scal;
   const void *w2x, *w2m;
@@ -141,6 +141,30 @@ __device__ __forceinline__ void unit_finish(const Unit& u, const float* wd, floa
   *reinterpret_cast<bf16x8*>(slot) = o;
 }
 
+
+// ---- half-precision table units (edge_bf16_v3) ---------------------------------------------------------------
+// The first-layer table of the v3 path is stored as fp16 (11 significant bits: finer than the bf16 the activation
+// is rounded to afterwards): half the bytes through the vector-memory path, P + Q as packed-half adds and the
+// fp16 -> fp32 conversion folded into the fma (v_fma_mix_f32).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+struct UnitH {  // one build unit in flight: 8 columns of one row of one MLP
+  f16x8 p, q;
+};
+__device__ __forceinline__ void unith_load(UnitH& u, rsrc_t tab, unsigned vdst, unsigned vsrc, unsigned sP, unsigned sQ) {
+  u.p = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(tab, vdst, __builtin_amdgcn_readfirstlane(sP), 0));
+  u.q = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(tab, vsrc, __builtin_amdgcn_readfirstlane(sQ), 0));
+}
+__device__ __forceinline__ void unith_finish(const UnitH& u, const float* wd, float d2, char* slot) {
+  const f32x4 w0 = *reinterpret_cast<const f32x4*>(wd), w1 = *reinterpret_cast<const f32x4*>(wd + 4);
+  const f16x8 t = u.p + u.q;
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    o[j] = (__bf16)silu_s(fmaf(w0[j], d2, (float)t[j]));   // table, wd pre-scaled by -log2(e)
+    o[j + 4] = (__bf16)silu_s(fmaf(w1[j], d2, (float)t[j + 4]));
+  }
+  *reinterpret_cast<bf16x8*>(slot) = o;
+}
 
 constexpr int kPostMaxOB = 8;  // output column blocks of node_post (H <= 256)
 // node_post arguments (fp32 and bf16 variants)
