@@ -263,68 +263,83 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
     }
 #endif
   };
-  UnitH u0, u1;
-  auto vload = [&](const int c) {   // table rows for the activations of chunk c
+  // Table-row units: set A serves every chunk (depth 1) or the odd chunks (depth 2), set B the even chunks of
+  // the depth-2 pipeline.  Depth 2 = rows requested two chunks ahead; the message kernel has the registers for
+  // it (and a chunk period shorter than an L2 round trip under load), the coordinate kernel does not.
+  constexpr bool DEPTH2 = (CB == 1);   // the message kernel and narrow coordinate MLPs
+  UnitH ua0, ua1, ub0, ub1;
+  auto vload = [&](UnitH& x0, UnitH& x1, const int cq) {   // table rows for the activations of chunk cq (clamped)
+    const int c = cq < NC ? cq : NC - 1;                    // past the end: a harmless repeat of the last chunk
     const unsigned kb = (unsigned)c * kKC3 * 2u;
-    unith_load(u0, rs_tab, vdst0, vsrc0, offP + kb, offQ + kb);
-    unith_load(u1, rs_tab, vdst1, vsrc1, offP + kb, offQ + kb);
+    unith_load(x0, rs_tab, vdst0, vsrc0, offP + kb, offQ + kb);
+    unith_load(x1, rs_tab, vdst1, vsrc1, offP + kb, offQ + kb);
   };
-  auto vfinish = [&](const int c) {  // SiLU + bf16 pack of chunk c into its LDS buffer
+  auto vfinish = [&](const UnitH& x0, const UnitH& x1, const int c) {  // SiLU + bf16 pack of chunk c into its LDS buffer
     const size_t nbuf = (size_t)(c & 1) * kA1_3;
     // vector work wins issue arbitration over the partner wave's MFMAs (which only need 1 slot in 4)
     __builtin_amdgcn_s_setprio(3);
-    unith_finish(u0, s_wd + c * kKC3 + kg * 8, d2r0, slot0 + nbuf);
+    unith_finish(x0, s_wd + c * kKC3 + kg * 8, d2r0, slot0 + nbuf);
     STAMP2(c - 1, 1, wave >= 4);
-    unith_finish(u1, s_wd + c * kKC3 + kg * 8, d2r1, slot1 + nbuf);
+    unith_finish(x1, s_wd + c * kKC3 + kg * 8, d2r1, slot1 + nbuf);
     STAMP2(c - 1, 2, wave >= 4);
     __builtin_amdgcn_s_setprio(0);
   };
   // The two waves that share a SIMD (w and w+4) run the chunk in opposite phase: waves 0-3 multiply chunk c
-  // and then build chunk c+1, waves 4-7 build chunk c+1 first (from table rows requested one chunk earlier)
-  // and then multiply chunk c -- one wave's vector work runs under its partner's matrix work instead of
-  // both alternating in lockstep.  One barrier per chunk either way.
+  // and then build chunk c+1, waves 4-7 build chunk c+1 first and then multiply chunk c -- one wave's vector
+  // work runs under its partner's matrix work instead of both alternating in lockstep.  One barrier per chunk
+  // either way.  A unit set is reloaded as soon as it has been consumed (for waves 0-3 that is ahead of the
+  // barrier: the vector-memory issue time -- 1 KiB per instruction through a 64 B/clk path -- then overlaps
+  // the group's barrier wait instead of delaying its matrix phase).
+  // (the steady-state loop bodies are branch-free so that hipcc's waitcnt insertion can keep counted
+  // vmcnt waits across the back edge instead of draining the queue at every control-flow join)
 #ifdef EGNN_EXP_NO_BUILD
   for (int c = 0; c < NC; ++c) { mphase(c, c == NC - 1); __syncthreads(); }
 #else
-  // (the steady-state loop bodies are branch-free so that hipcc's waitcnt insertion can keep counted
-  // vmcnt waits across the back edge instead of draining the queue at every control-flow join)
   if (wave < 4) {
-    // table rows of chunk c+2 are requested as soon as the units of chunk c+1 are consumed, ahead of the barrier:
-    // the vector-memory issue time (1 KiB per instruction through a 64 B/clk path) then overlaps this group's
-    // barrier wait instead of delaying its matrix phase.  (Clamped index: the last request is a harmless repeat.)
-    if (NC > 1) vload(1);
-    for (int c = 0; c < NC - 1; ++c) {
-      STAMP(c, 0);
-      STAMP2(c, 1, true);
-      mphase(c, false);
-      STAMP1(c, 1);
-      STAMP2(c, 3, true);
-      vfinish(c + 1);
-      vload(c + 2 < NC ? c + 2 : NC - 1);
-      STAMP1(c, 2);
+    auto step = [&](UnitH& x0, UnitH& x1, const int i) {   // chunk i: multiply, build i+1, request the set's next chunk
+      STAMP(i, 0);
+      STAMP2(i, 1, true);
+      mphase(i, false);
+      STAMP1(i, 1);
+      STAMP2(i, 3, true);
+      vfinish(x0, x1, i + 1);
+      vload(x0, x1, i + (DEPTH2 ? 3 : 2));
+      STAMP1(i, 2);
       __syncthreads();
-      STAMP1(c, 3);
+      STAMP1(i, 3);
+    };
+    vload(ua0, ua1, 1);
+    if constexpr (DEPTH2) {
+      vload(ub0, ub1, 2);
+      int i = 0;
+      for (; i + 1 <= NC - 2; i += 2) { step(ua0, ua1, i); step(ub0, ub1, i + 1); }
+      if (i <= NC - 2) step(ua0, ua1, i);
+    } else {
+      for (int i = 0; i < NC - 1; ++i) step(ua0, ua1, i);
     }
     mphase(NC - 1, true);
     __syncthreads();
   } else {
-    if (NC > 1) vload(1);
-    for (int c = 0; c < NC - 2; ++c) {
-      STAMP(c, 0);
-      vfinish(c + 1);
-      vload(c + 2);
+    auto step = [&](UnitH& x0, UnitH& x1, const int i) {   // build i+1, request the set's next chunk, multiply chunk i
+      STAMP(i, 0);
+      vfinish(x0, x1, i + 1);
+      vload(x0, x1, i + (DEPTH2 ? 3 : 2));
       __builtin_amdgcn_sched_barrier(0);
-      STAMP1(c, 1);
-      STAMP2(c, 3, true);
-      mphase(c, false);
-      STAMP1(c, 2);
+      STAMP1(i, 1);
+      STAMP2(i, 3, true);
+      mphase(i, false);
+      STAMP1(i, 2);
       __syncthreads();
-      STAMP1(c, 3);
-    }
-    if (NC > 1) {
-      vfinish(NC - 1);
-      mphase(NC - 2, false);
-      __syncthreads();
+      STAMP1(i, 3);
+    };
+    vload(ua0, ua1, 1);
+    if constexpr (DEPTH2) {
+      vload(ub0, ub1, 2);
+      int i = 0;
+      for (; i + 1 <= NC - 2; i += 2) { step(ua0, ua1, i); step(ub0, ub1, i + 1); }
+      if (i <= NC - 2) step(ua0, ua1, i);
+    } else {
+      for (int i = 0; i < NC - 1; ++i) step(ua0, ua1, i);
     }
     mphase(NC - 1, true);
     __syncthreads();
