@@ -81,6 +81,28 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
   const int e0 = tile * kR3;
   const int nvalid = min(kR3, p.E - e0);
 
+#ifdef EGNN_EXP_STAMP
+  const bool stamp_wg = blockIdx.x == gridDim.x / 2;
+  unsigned long long* st_base = p.stamps + ((size_t)(IS_M ? 1 : 0) * 8 + wave) * 32 * 4;
+#define STAMP(c, k)                                                                               \
+  do {                                                                                            \
+    unsigned long long t_;                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    if (stamp_wg && lane == 0 && (c) < 32) st_base[(c) * 4 + (k)] = t_;                           \
+  } while (0)
+#else
+#define STAMP(c, k)
+#endif
+#ifdef EGNN_EXP_STAMP2   // finer stamps inside the first half of a chunk (replaces the meaning of slots 1..3)
+#define STAMP2(c, k, cond) do { if (cond) STAMP(c, k); } while (0)
+#define STAMP1(c, k)
+#else
+#define STAMP2(c, k, cond)
+#define STAMP1(c, k) STAMP(c, k)
+#endif
+  STAMP(30, 0);   // kernel entry
   // ---- prologue: edge rows, geometry, segment (= receiving node) structure ----
   if (tid < kR3) {
     int d = 0, s = 0;
@@ -130,6 +152,8 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
     s_seg_mode[tid] = (first && last) ? 2 : (first ? 1 : 0);
   }
 
+  STAMP(30, 1);   // tile structure ready
+
   // ---- K-loop ----
   const int NC = KP / kKC3, KS = KP / 16;
   const int brow = tid >> 3, kg = tid & 7;   // this thread builds rows brow and brow + 64
@@ -171,27 +195,6 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
     for (int cb = 0; cb < CB; ++cb) bq[s][cb] = ldbuf_bf16x8(rs_w, lane16, w0 + ((unsigned)cb * KS + s) * 1024u);
   __syncthreads();
 
-#ifdef EGNN_EXP_STAMP
-  const bool stamp_wg = blockIdx.x == gridDim.x / 2;
-  unsigned long long* st_base = p.stamps + ((size_t)(IS_M ? 1 : 0) * 8 + wave) * 32 * 4;
-#define STAMP(c, k)                                                                               \
-  do {                                                                                            \
-    unsigned long long t_;                                                                        \
-    __builtin_amdgcn_sched_barrier(0);                                                            \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
-    __builtin_amdgcn_sched_barrier(0);                                                            \
-    if (stamp_wg && lane == 0 && (c) < 32) st_base[(c) * 4 + (k)] = t_;                           \
-  } while (0)
-#else
-#define STAMP(c, k)
-#endif
-#ifdef EGNN_EXP_STAMP2   // finer stamps inside the first half of a chunk (replaces the meaning of slots 1..3)
-#define STAMP2(c, k, cond) do { if (cond) STAMP(c, k); } while (0)
-#define STAMP1(c, k)
-#else
-#define STAMP2(c, k, cond)
-#define STAMP1(c, k) STAMP(c, k)
-#endif
   // matrix phase of chunk c: 4 k-steps x (4 row blocks x CB column blocks)
   // Operand pipeline of the matrix phase: the weight fragments of k-step s of chunk c+1 are requested right
   // after the MFMAs of k-step s of chunk c were issued (a whole chunk = 4 k-steps of distance, enough to cover
@@ -284,6 +287,7 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
     STAMP2(c - 1, 2, wave >= 4);
     __builtin_amdgcn_s_setprio(0);
   };
+  STAMP(30, 2);   // chunk 0 built, first weights requested
   // The two waves that share a SIMD (w and w+4) run the chunk in opposite phase: waves 0-3 multiply chunk c
   // and then build chunk c+1, waves 4-7 build chunk c+1 first and then multiply chunk c -- one wave's vector
   // work runs under its partner's matrix work instead of both alternating in lockstep.  One barrier per chunk
@@ -345,6 +349,7 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
     __syncthreads();
   }
 #endif
+  STAMP(30, 3);   // K loop done
 #ifdef EGNN_EXP_NO_EPI
   {
     float keep = 0.f;
@@ -497,6 +502,7 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
       }
     }
   }
+  STAMP(31, 0);   // epilogue done
 }
 
 template <int CB, bool IS_M>

@@ -24,3 +24,8 @@ for k, name in enumerate(("X", "M")):
         p1, p2, bar = s[:, 1]-s[:, 0], s[:, 2]-s[:, 1], s[:, 3]-s[:, 2]
         tot = s[15, 3] - s[0, 0]
         print(f" wave {w}: phase1 {p1[1:15].mean():7.0f}  phase2 {p2[1:15].mean():7.0f}  barrier {bar[1:15].mean():7.0f}  chunk {np.diff(s[:,0])[1:14].mean():7.0f}  loop total {tot}")
+    t = st[k, :, 30:32]
+    for w in (0, 4):
+        if t[w, 0, 0] == 0: continue
+        print(f" wave {w} tile anatomy (cycles): prologue {t[w,0,1]-t[w,0,0]}  chunk 0 + first weights {t[w,0,2]-t[w,0,1]}  "
+              f"K loop {t[w,0,3]-t[w,0,2]}  epilogue {t[w,1,0]-t[w,0,3]}  total {t[w,1,0]-t[w,0,0]}")
