@@ -110,10 +110,11 @@ __global__ void pack_first(const float* __restrict__ x0_w, const float* __restri
 // node_pre: table[n][col] = b1cat[col] + sum_h h[n][h] * w1catT[h][col]
 // ------------------------------------------------------------------------------------------------
 constexpr int kPreNodes = 16;
-// fp16 table entries saturate instead of overflowing to inf (pre-activations of that size are far in SiLU's
-// linear / zero tails either way)
+// fp16 table entries saturate at +-32000 instead of overflowing: the edge kernel adds two of them in fp16, and an
+// infinite pre-activation would turn SiLU's t * rcp(1 + exp2(t)) into inf * 0.  (Scaled pre-activations of that
+// size only occur once a reverse chain has already diverged.)
 __device__ __forceinline__ void table_store(float* p, float v) { *p = v; }
-__device__ __forceinline__ void table_store(_Float16* p, float v) { *p = (_Float16)fminf(fmaxf(v, -60000.f), 60000.f); }
+__device__ __forceinline__ void table_store(_Float16* p, float v) { *p = (_Float16)fminf(fmaxf(v, -32000.f), 32000.f); }
 
 template <typename TT>
 __global__ __launch_bounds__(kThreads) void node_pre_kernel(const float* __restrict__ h, int N, int H,
