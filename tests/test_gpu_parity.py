@@ -392,3 +392,33 @@ def test_generate_interface():
         n = o.x.shape[0]
         assert g.pos.shape == (n, 3) and g.x.shape == (n, 2)
         assert torch.isfinite(g.pos).all() and bool((g.x.sum(1) == 1).all())
+
+
+# every bf16 edge-kernel variant: v3 <2,false> (x_hidden >= 512), v3 <1,false> (x_hidden = 256), v3 <1,true>,
+# and the generic fallbacks taken when the widths do not fit the v3 tiling (m_size != 256, odd widths)
+@pytest.mark.parametrize("H,m_size,wm,wx,wh", [
+    (36, 256, 1024, 1024, 256),   # reference widths: v3 X (two column blocks) + M
+    (36, 256, 128, 256, 64),      # v3 X with one column block, narrow message MLP
+    (3, 256, 64, 512, 128),       # unconditional variant (H = 3) on the v3 path
+    (36, 250, 192, 512, 96),      # m_size padded to 256
+    (36, 64, 128, 128, 64),       # m_size 64: fallback kernels
+    (5, 10, 30, 22, 18),          # nothing aligned
+])
+def test_width_sweep_all_edge_kernel_variants(H, m_size, wm, wx, wh):
+    d = dims_for(H, m_size, wm, wx, wh)
+    sd = egnn_ref.init_state_dict(2, **d, seed=123)
+    sizes = [33, 5, 70, 1, 12]   # ragged batch, a single-atom graph (no edges), segments across tile borders
+    n = sum(sizes)
+    g = torch.Generator().manual_seed(9)
+    h, x = torch.randn(n, H, generator=g), torch.randn(n, 3, generator=g)
+    ei_cpu = egnn_ref.fully_connected_edge_index(sizes)
+    ptr = torch.tensor([0] + list(np.cumsum(sizes)))
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes)).to(DEV)
+    for scope in ("call", "graph"):
+        h_ref, x_ref = egnn_ref.egnn_forward(sd, ei_cpu, h, x, norm_scope=scope, graph_ptr=ptr)
+        for precision, tol in (("fp32", 1e-4), ("bf16", 5e-2)):
+            net = build_net(sd, d, 2, precision=precision, norm_scope=scope)
+            with torch.no_grad():
+                h_o, x_o = net(ei_cpu.to(DEV), h.to(DEV), x.to(DEV), batch=batch)
+            assert rel_err(h_o.cpu(), h_ref) <= tol, (scope, precision, "h")
+            assert rel_err(x_o.cpu(), x_ref) <= tol, (scope, precision, "x")
