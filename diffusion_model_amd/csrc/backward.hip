@@ -55,6 +55,34 @@ template <> struct VecIo<__bf16, 4> {
   }
 };
 
+template <> struct VecIo<float, 8> {
+  static __device__ __forceinline__ void ld(const float* p, float (&o)[8]) {
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(p), v1 = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o[j] = v0[j]; o[j + 4] = v1[j]; }
+  }
+  static __device__ __forceinline__ void st(float* p, const float (&v)[8]) {
+    f32x4 o0, o1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o0[j] = v[j]; o1[j] = v[j + 4]; }
+    *reinterpret_cast<f32x4*>(p) = o0;
+    *reinterpret_cast<f32x4*>(p + 4) = o1;
+  }
+};
+template <> struct VecIo<__bf16, 8> {
+  static __device__ __forceinline__ void ld(const __bf16* p, float (&o)[8]) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (float)v[j];
+  }
+  static __device__ __forceinline__ void st(__bf16* p, const float (&v)[8]) {
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (__bf16)v[j];
+    *reinterpret_cast<bf16x8*>(p) = o;
+  }
+};
+
 // s = SiLU(a), ds = dSiLU/da = sig * (1 + a * (1 - sig))
 __device__ __forceinline__ void silu_and_grad(float a, float& s, float& ds) {
   const float sg = sigmoid_f(a);
@@ -76,7 +104,7 @@ __global__ __launch_bounds__(kThreads) void bwd_l1_kernel(int n_edges, int C, co
                                                            const float* __restrict__ d2, T* __restrict__ buf) {
   const int e0 = blockIdx.x * kBwdRows, rows = min(kBwdRows, n_edges - e0);
   const int G = C / V, items = rows * G;
-#pragma unroll 2
+#pragma unroll 4
   for (int it = threadIdx.x; it < items; it += kThreads) {
     const int r = it / G, c = (it - r * G) * V, e = e0 + r;
     float p[V], q[V], w[V], o[V];
@@ -260,27 +288,41 @@ __global__ __launch_bounds__(kThreads) void bwd_gather_kernel(int n_edges, int H
 // ---- scatter of dL/d(in) back to the nodes ------------------------------------------------------------------------
 // g_in[e] = dL/d[h_i | h_j | d2] (K1P columns, the rest ignored).  g_h[i] += g_in[:H], g_h[j] += g_in[H:2H];
 // dL/d(x_i - x_j) = g_diff[e] + 2 (g_in[2H] + g_S[segment of i]) (x_i - x_j)  goes to g_x[i] and, negated, g_x[j].
+// Edges arrive sorted by receiving node, so the dst side is summed over runs of equal dst in registers and added
+// once per run; the src side is one atomic add per edge.  One workgroup = kScatRows consecutive edges, one thread
+// per column of [g_h (dst) | g_h (src) | g_x].
+constexpr int kScatRows = 64;
 template <typename T>
 __global__ __launch_bounds__(kThreads) void bwd_scatter_kernel(int n_edges, int H, int K1P, const int* __restrict__ dst,
                                                                 const int* __restrict__ src, const float* __restrict__ x,
                                                                 const T* __restrict__ g_in, const float* __restrict__ g_diff,
                                                                 const float* __restrict__ g_S, const int* __restrict__ node_seg,
                                                                 float* __restrict__ g_h, float* __restrict__ g_x) {
-  const int cols = 2 * H + 3;
-  const size_t total = (size_t)n_edges * cols;
-  for (size_t t = (size_t)blockIdx.x * kThreads + threadIdx.x; t < total; t += (size_t)gridDim.x * kThreads) {
-    const int e = (int)(t / cols), c = (int)(t - (size_t)e * cols);
-    const int i = dst[e], j = src[e];
-    const T* row = g_in + (size_t)e * K1P;
-    if (c < H) atomicAdd(g_h + (size_t)i * H + c, Io<T>::ld(row + c));
-    else if (c < 2 * H) atomicAdd(g_h + (size_t)j * H + c - H, Io<T>::ld(row + c));
-    else {
-      const int d = c - 2 * H;
-      const float gd2 = Io<T>::ld(row + 2 * H) + g_S[node_seg ? node_seg[i] : 0];
-      const float g = fmaf(2.0f * gd2, x[3 * i + d] - x[3 * j + d], g_diff[3 * (size_t)e + d]);
-      atomicAdd(g_x + 3 * (size_t)i + d, g);
-      atomicAdd(g_x + 3 * (size_t)j + d, -g);
+  const int e0 = blockIdx.x * kScatRows, e1 = min(e0 + kScatRows, n_edges);
+  for (int c = threadIdx.x; c < 2 * H + 3; c += kThreads) {
+    if (c >= H && c < 2 * H) {   // sending side: scattered
+      for (int e = e0; e < e1; ++e) atomicAdd(g_h + (size_t)src[e] * H + c - H, Io<T>::ld(g_in + (size_t)e * K1P + c));
+      continue;
     }
+    const int d = c - 2 * H;     // coordinate component when c >= 2H
+    float run = 0.f;
+    int cur = dst[e0];
+    for (int e = e0; e < e1; ++e) {
+      const int i = dst[e];
+      if (i != cur) {
+        atomicAdd(c < H ? g_h + (size_t)cur * H + c : g_x + 3 * (size_t)cur + d, run);
+        run = 0.f; cur = i;
+      }
+      if (c < H) run += Io<T>::ld(g_in + (size_t)e * K1P + c);
+      else {
+        const int j = src[e];
+        const float gd2 = Io<T>::ld(g_in + (size_t)e * K1P + 2 * H) + g_S[node_seg ? node_seg[i] : 0];
+        const float g = fmaf(2.0f * gd2, x[3 * i + d] - x[3 * j + d], g_diff[3 * (size_t)e + d]);
+        run += g;
+        atomicAdd(g_x + 3 * (size_t)j + d, -g);
+      }
+    }
+    atomicAdd(c < H ? g_h + (size_t)cur * H + c : g_x + 3 * (size_t)cur + d, run);
   }
 }
 
@@ -354,12 +396,12 @@ static int bwd_l1(void* stream, int prec, int grad, int n_edges, int C, const in
   if (n_edges == 0) return EGNN_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const dim3 grid((n_edges + kBwdRows - 1) / kBwdRows), block(kThreads);
-  const bool v4 = (C & 3) == 0;
+  const bool v4 = (C & 3) == 0, v8 = (C & 7) == 0;
 #define L1_LAUNCH(T, G, V) \
   hipLaunchKernelGGL((bwd_l1_kernel<T, G, V>), grid, block, 0, st, n_edges, C, dst, src, P, Q, wd, d2, static_cast<T*>(buf))
   if (prec == EGNN_PREC_BF16) {
-    if (grad) { if (v4) L1_LAUNCH(__bf16, true, 4); else L1_LAUNCH(__bf16, true, 1); }
-    else { if (v4) L1_LAUNCH(__bf16, false, 4); else L1_LAUNCH(__bf16, false, 1); }
+    if (grad) { if (v8) L1_LAUNCH(__bf16, true, 8); else if (v4) L1_LAUNCH(__bf16, true, 4); else L1_LAUNCH(__bf16, true, 1); }
+    else { if (v8) L1_LAUNCH(__bf16, false, 8); else if (v4) L1_LAUNCH(__bf16, false, 4); else L1_LAUNCH(__bf16, false, 1); }
   } else {
     if (grad) { if (v4) L1_LAUNCH(float, true, 4); else L1_LAUNCH(float, true, 1); }
     else { if (v4) L1_LAUNCH(float, false, 4); else L1_LAUNCH(float, false, 1); }
@@ -438,8 +480,7 @@ int egcl_backward_scatter(void* stream, int prec, int n_edges, int H, int K1P, c
   if (n_edges == 0) return EGNN_OK;
   if (!dst || !src || !x || !g_in || !g_diff || !g_sq_sums || !g_h || !g_x) { set_error("bad egcl_backward_scatter arguments"); return EGNN_EINVAL; }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const size_t total = (size_t)n_edges * (2 * H + 3);
-  const dim3 grid((unsigned)((total + kThreads - 1) / kThreads < 65536 ? (total + kThreads - 1) / kThreads : 65536)), block(kThreads);
+  const dim3 grid((n_edges + kScatRows - 1) / kScatRows), block(2 * H + 3 <= 128 ? 128 : kThreads);
   if (prec == EGNN_PREC_BF16)
     hipLaunchKernelGGL(bwd_scatter_kernel<__bf16>, grid, block, 0, st, n_edges, H, K1P, dst, src, x, static_cast<const __bf16*>(g_in), g_diff, g_sq_sums, node_segment, g_h, g_x);
   else
