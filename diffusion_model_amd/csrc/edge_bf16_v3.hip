@@ -92,8 +92,18 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
     __builtin_amdgcn_sched_barrier(0);                                                            \
     if (stamp_wg && lane == 0 && (c) < 32) st_base[(c) * 4 + (k)] = t_;                           \
   } while (0)
+// 100 MHz wall counter next to a cycle stamp: in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz
+#define RSTAMP(c, k)                                                                              \
+  do {                                                                                            \
+    unsigned long long t_;                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    if (stamp_wg && lane == 0 && (c) < 32) st_base[(c) * 4 + (k)] = t_;                           \
+  } while (0)
 #else
 #define STAMP(c, k)
+#define RSTAMP(c, k)
 #endif
 #ifdef EGNN_EXP_STAMP2   // finer stamps inside the first half of a chunk (replaces the meaning of slots 1..3)
 #define STAMP2(c, k, cond) do { if (cond) STAMP(c, k); } while (0)
@@ -288,6 +298,7 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
     __builtin_amdgcn_s_setprio(0);
   };
   STAMP(30, 2);   // chunk 0 built, first weights requested
+  RSTAMP(31, 1);
   // The two waves that share a SIMD (w and w+4) run the chunk in opposite phase: waves 0-3 multiply chunk c
   // and then build chunk c+1, waves 4-7 build chunk c+1 first and then multiply chunk c -- one wave's vector
   // work runs under its partner's matrix work instead of both alternating in lockstep.  One barrier per chunk
@@ -350,6 +361,7 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
   }
 #endif
   STAMP(30, 3);   // K loop done
+  RSTAMP(31, 2);
 #ifdef EGNN_EXP_NO_EPI
   {
     float keep = 0.f;

@@ -12,7 +12,7 @@ for l in net.egcl_list:
     l.mlp_x[4].weight.data.mul_(1e-3)
 proc = dma.E3DiffusionProcess(1e-5, 2.0, T)
 smp = dma.DeviceSampler(net, proc, [n]*B, torch.randn(B*n, H-A-1), atom_type_size=A)
-smp.init(); smp.run(nsteps=3, use_graph=False)
+smp.init(); smp.run(nsteps=200, use_graph=False)
 buf = np.zeros(2*8*32*4, dtype=np.uint64)
 _lib.check(_lib.lib().egnn_debug_stamps(smp.ctx.handle, buf.ctypes.data_as(C.POINTER(C.c_uint64))))
 st = buf.reshape(2, 8, 32, 4).astype(np.int64)
@@ -29,3 +29,6 @@ for k, name in enumerate(("X", "M")):
         if t[w, 0, 0] == 0: continue
         print(f" wave {w} tile anatomy (cycles): prologue {t[w,0,1]-t[w,0,0]}  chunk 0 + first weights {t[w,0,2]-t[w,0,1]}  "
               f"K loop {t[w,0,3]-t[w,0,2]}  epilogue {t[w,1,0]-t[w,0,3]}  total {t[w,1,0]-t[w,0,0]}")
+        wall = t[w, 1, 2] - t[w, 1, 1]   # 100 MHz ticks over the K loop
+        if wall > 0:
+            print(f"   in-kernel clock over the K loop: {(t[w,0,3]-t[w,0,2]) / wall * 100:.0f} MHz")
