@@ -203,10 +203,15 @@ def main():
     # [1, 1024] vector without any range clamp) makes the reverse chain overflow within a
     # few steps; it is scaled by 1e-3 so the benchmark runs on finite, realistic magnitudes.  The
     # arithmetic performed per step is unchanged.
+    # Graphs larger than the 64-atom reference cell sum proportionally more messages per node; the message
+    # head is scaled by 64/atoms for them, again only to keep untrained weights in a finite regime.
     with torch.no_grad():
         for layer in net.egcl_list:
             layer.mlp_x[4].weight.mul_(1e-3)
             layer.mlp_x[4].bias.mul_(1e-3)
+            if n > 64:
+                layer.mlp_m[2].weight.mul_(64.0 / n)
+                layer.mlp_m[2].bias.mul_(64.0 / n)
     sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
     net.to(dev).eval()
     net.precision = args.precision
