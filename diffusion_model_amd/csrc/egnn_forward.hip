@@ -193,14 +193,33 @@ __global__ __launch_bounds__(kThreads) void node_pre_mfma_kernel(const float* __
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[j][s], acc[j], 0, 0, 0);
     }
+  if constexpr (sizeof(TT) == 2) {
+    // fp16 table: a lane's 2-byte column of 16 rows would touch 16 rows x 64 B per half-wave; stage the 32 x 512
+    // tile in LDS and store whole 16-byte pieces, 1 KiB contiguous per row
+    constexpr int kLd = kPre2Cols + 8;   // halves; the pad de-phases the two row groups of a wave
+    __syncthreads();                     // every wave is done reading the h tile
+    TT* stg = reinterpret_cast<TT*>(smem_raw);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int col = col0 + 32 * j + r;
-    if (col < TC) {
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int n = n0 + acc_row(i, lane);
-        if (n < N) table_store(table + (size_t)n * TC + col, acc[j][i]);
+      for (int i = 0; i < 16; ++i) table_store(stg + acc_row(i, lane) * kLd + wave * 128 + 32 * j + r, acc[j][i]);
+    __syncthreads();
+    const int cbase = blockIdx.y * kPre2Cols;
+    for (int q = threadIdx.x; q < kPre2Nodes * (kPre2Cols / 8); q += kThreads) {
+      const int row = q / (kPre2Cols / 8), piece = q % (kPre2Cols / 8), n = n0 + row, col = cbase + 8 * piece;
+      if (n < N && col < TC)
+        *reinterpret_cast<f32x4*>(table + (size_t)n * TC + col) = *reinterpret_cast<const f32x4*>(stg + row * kLd + 8 * piece);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = col0 + 32 * j + r;
+      if (col < TC) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int n = n0 + acc_row(i, lane);
+          if (n < N) table_store(table + (size_t)n * TC + col, acc[j][i]);
+        }
       }
     }
   }
@@ -846,9 +865,10 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
     if (pre_sel >= 2 && c->H <= 64) {
       dim3 grid((N + kPre2Nodes - 1) / kPre2Nodes, (c->TC + kPre2Cols - 1) / kPre2Cols);
       const size_t sm = (size_t)((c->H + 1) & ~1) * 33 * sizeof(float);
+      const size_t sm16 = (size_t)kPre2Nodes * (kPre2Cols + 8) * 2;   // output staging tile of the fp16 variant
       if (path == 3)   // the v3 edge kernels read a half-precision table
-        hipLaunchKernelGGL(node_pre_mfma_kernel<_Float16>, grid, dim3(kThreads), sm, st, h, N, c->H, w1catT, b1cat,
-                           c->TC, reinterpret_cast<_Float16*>(c->table));
+        hipLaunchKernelGGL(node_pre_mfma_kernel<_Float16>, grid, dim3(kThreads), sm > sm16 ? sm : sm16, st, h, N, c->H,
+                           w1catT, b1cat, c->TC, reinterpret_cast<_Float16*>(c->table));
       else
         hipLaunchKernelGGL(node_pre_mfma_kernel<float>, grid, dim3(kThreads), sm, st, h, N, c->H, w1catT, b1cat, c->TC,
                            c->table);
