@@ -146,7 +146,7 @@ __global__ __launch_bounds__(kThreads) void node_pre_kernel(const float* __restr
 }
 
 // The same table on the matrix cores: exact fp32 v_mfma_f32_32x32x2_f32 (K = H is tiny, the kernel is bound by
-// the 268 MB table write).  Workgroup = 32 nodes x 512 columns, wave w owns 4 column blocks; A = h tile from LDS,
+// the table write: 268 MB fp32 / 134 MB fp16 at C2).  Workgroup = 32 nodes x 512 columns, wave w owns 4 column blocks; A = h tile from LDS,
 // B = w1catT rows straight from L2 (128 B per half-wave, coalesced), accumulator initialised with the bias.
 constexpr int kPre2Nodes = 32, kPre2Cols = 512;
 template <typename TT>
