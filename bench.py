@@ -86,7 +86,7 @@ def cpu_baseline(sd, H, A, T, n_atoms, target_seconds=15.0):
 
 def train_bench(args, world, rank, dev, backend):
     """BASELINE configs[3]: 64-atom SiO2 training, `--batch` graphs per rank (256 -> global 2048 on 8 GPUs),
-    one step = diffuse_as_batch + EGNN forward (HIP) + recompute backward + gradient all-reduce (RCCL) + Adam."""
+    one step = diffuse_as_batch + EGNN forward (HIP) + backward (HIP stage kernels + library GEMMs) + gradient all-reduce (RCCL) + Adam."""
     from types import SimpleNamespace
     import torch.distributed as dist
     import diffusion_model_amd as dma
@@ -145,8 +145,8 @@ def train_bench(args, world, rank, dev, backend):
             "metric": "atoms*(fwd+bwd) steps/sec, 64-atom SiO2 training", "value": world * B * n * K / elapsed,
             "unit": "atoms*train-steps/s", "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": elapsed * 1e3 / K,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"{n}-atom SiO2 cells x {B} graphs/GPU, {L}-layer EGNN, forward HIP + recompute backward "
-                                   f"(library GEMMs) + per-layer RCCL gradient all-reduce + Adam",
+            "config": {"workload": f"{n}-atom SiO2 cells x {B} graphs/GPU, {L}-layer EGNN, HIP forward + HIP backward stage "
+                                   f"kernels around library GEMMs + per-layer RCCL gradient all-reduce + Adam",
                        "global_batch": world * B, "parallelism": f"dp{world}"},
             "final_loss": float(loss.detach())}), flush=True)
     if world > 1:
