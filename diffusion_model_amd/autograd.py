@@ -25,7 +25,9 @@ import torch
 
 from . import _lib
 
-EDGE_CHUNK = 1 << 18
+import os
+
+EDGE_CHUNK = int(os.environ.get("EGNN_BWD_CHUNK", 1 << 19))   # edges per backward chunk (workspace = 6 bf16 [chunk, W] buffers)
 
 
 def _segment_scale(S, scope_graph, node_graph):
