@@ -422,3 +422,41 @@ def test_width_sweep_all_edge_kernel_variants(H, m_size, wm, wx, wh):
                 h_o, x_o = net(ei_cpu.to(DEV), h.to(DEV), x.to(DEV), batch=batch)
             assert rel_err(h_o.cpu(), h_ref) <= tol, (scope, precision, "h")
             assert rel_err(x_o.cpu(), x_ref) <= tol, (scope, precision, "x")
+
+
+_FALLBACK_SNIPPET = r"""
+import sys, torch, numpy as np
+sys.path.insert(0, {root!r})
+import diffusion_model_amd as dma
+from oracle import egnn_ref
+from tests._util import dims_for, rel_err
+H = 36
+d = dims_for(H, 256, 1024, 1024, 256)
+sd = egnn_ref.init_state_dict(1, **d, seed=7)
+sizes = [40, 9, 70]
+n = sum(sizes)
+g = torch.Generator().manual_seed(1)
+h, x = torch.randn(n, H, generator=g), torch.randn(n, 3, generator=g)
+ei = egnn_ref.fully_connected_edge_index(sizes)
+h_ref, x_ref = egnn_ref.egnn_forward(sd, ei, h, x)
+net = dma.EquivariantGNN(1, d["m_input"], d["m_hidden"], d["m_output"], d["x_input"], d["x_hidden"], d["x_output"],
+                         d["h_input"], d["h_hidden"], d["h_output"])
+net.load_state_dict(sd); net.to("cuda").eval(); net.precision = "bf16"
+with torch.no_grad():
+    h_o, x_o = net(ei.cuda(), h.cuda(), x.cuda())
+eh, ex = rel_err(h_o.cpu(), h_ref), rel_err(x_o.cpu(), x_ref)
+print("ERR", eh, ex)
+assert eh <= 5e-2 and ex <= 5e-2
+"""
+
+
+@pytest.mark.parametrize("edge", ["1", "2"])
+def test_non_default_bf16_edge_kernels(edge):
+    """EGNN_EDGE=1 / 2 select the generic and the 64-row fused bf16 edge kernels that the default (3) falls back to
+    for shapes its tiling does not cover; the switch is read once per process, hence the child process."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EGNN_EDGE=edge)
+    out = subprocess.run([sys.executable, "-c", _FALLBACK_SNIPPET.format(root=root)], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
