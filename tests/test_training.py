@@ -74,8 +74,11 @@ def test_read_aggregates_matches_oracle():
 @pytest.mark.gpu
 @pytest.mark.parametrize("widths", [(128, 256, 256, 256), (10, 30, 22, 18)], ids=["vec4", "odd"])
 @pytest.mark.parametrize("norm_scope", ["graph", "call"])
-def test_gradients_match_oracle_autograd(norm_scope, widths):
+def test_gradients_match_oracle_autograd(norm_scope, widths, monkeypatch):
     # "odd": widths that are not multiples of 4 take the scalar-access variants of the backward stage kernels
+    # 100-edge chunks: several backward chunks per layer, alternating between the two side streams
+    from diffusion_model_amd import autograd as _ag
+    monkeypatch.setattr(_ag, "EDGE_CHUNK", 100)
     H, A, T = 36, 2, 50
     d = dims_for(H, *widths)
     torch.manual_seed(5)
