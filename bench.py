@@ -286,7 +286,10 @@ def main():
                          "kernel": "fused edge pass of one EGCL layer (edge_kernel_bf16_v3 X+M launches, or "
                                    "edge_kernel_bf16_v2 / edge_kernel<F32>)",
                          "avg_launch_ms": edge_ms.value, "launches": edge_n.value,
-                         "algorithmic_flop_per_launch": flops_per_launch},
+                         "algorithmic_flop_per_launch": flops_per_launch,
+                         # the first Linear layers are evaluated per node (factorised), so the matrix cores execute
+                         # only the second-layer products of the count above
+                         "mfma_executed_flop_per_launch": 2.0 * (W * M + W * W) * E},
             "graph_replay_ms_per_step": graph_ms,
             "node_kernels_ms_per_layer": node_ms.value * 2,
             "nonfinite_graphs": int(bad.sum()),
