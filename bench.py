@@ -6,15 +6,23 @@ A "step" is one reverse-diffusion step of the device-resident sampler over the w
 L-layer EGNN forward eps_theta(x_t, h_t, t) plus the fused eps -> mu -> noise -> state update kernel
 (parts/train_per_iretation.py:335-373).  Inputs (state, conditioning, weights, schedule table) are
 resident in HBM before the timed region.  With --gpus N every rank samples its own batch of graphs
-(independent replicas: no data-path collective, weak scaling); only the timing uses a collective.
+(independent replicas: no data-path collective, weak scaling); only the timing uses a collective.  The
+same JSON line carries a `ddp_train` sub-record (BASELINE configs[3] per-rank shape: forward + backward +
+per-layer RCCL gradient all-reduce + Adam), which is where the data-path collective of the N > 1 curve is.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-Prints ONE JSON line on rank 0.
+`--gpus N` from a plain shell starts the N ranks itself (a torch.distributed.run child process, before
+anything has touched the GPU); under torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE.
+Prints ONE JSON line on rank 0.  A state that went non-finite makes the line `"valid": false` with no value
+and the exit code 3.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -24,11 +32,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+H, M, W, A, T = 36, 256, 1024, 2, 1000
+
+
 # algorithmic work of the fused edge kernel: per edge per layer
 #   mlp_m 336,896 + gate 256 + mlp_x 1,124,352 = 1,461,504 MAC  (H=36, W=1024, M=256)
 def edge_macs(H, M, Wm, Wx):
     inp = 2 * H + 1
     return (inp * Wm + Wm * M) + M + (inp * Wx + Wx * Wx + Wx)
+
+
+def node_macs(H, M, Wh):
+    return (H + M) * Wh + Wh * H
 
 
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
@@ -43,7 +58,40 @@ def synthetic_cond(batch, n_atoms, ncond, seed):
     return cond
 
 
-def cpu_baseline(sd, H, A, T, n_atoms, target_seconds=15.0):
+def sio2_cells(batch, n_atoms, seed):
+    """jittered cubic grid, spacing 1.6 A, jitter N(0, 0.1^2); atom 0 = O, then Si : O = 21 : 42 per 64"""
+    g = torch.Generator().manual_seed(seed)
+    side = round(n_atoms ** (1 / 3))
+    grid = torch.stack(torch.meshgrid(*[torch.arange(side, dtype=torch.float32)] * 3, indexing="ij"), -1).reshape(-1, 3) * 1.6
+    pos = grid[:n_atoms].repeat(batch, 1) + 0.1 * torch.randn(batch * n_atoms, 3, generator=g)
+    types = torch.zeros(n_atoms, A)
+    n_si = max(1, round(n_atoms * 21 / 64))
+    types[0, 0] = 1
+    types[1:1 + n_si, 1] = 1
+    types[1 + n_si:, 0] = 1
+    return pos, types.repeat(batch, 1)
+
+
+def build_net(dma, L, n_atoms, finite_init=True):
+    """Random-init weights of the named architecture (seed 2024, default nn.Linear init).  The untrained coordinate
+    head (mlp_x.4, a [1, 1024] vector without any range clamp) makes the reverse chain overflow within a
+    few steps; it is scaled by 1e-3 so the benchmark runs on finite, realistic magnitudes.  Graphs larger than the
+    64-atom reference cell sum proportionally more messages per node; the message head is scaled by 64/atoms for
+    them, again only to keep untrained weights in a finite regime.  The arithmetic per step is unchanged."""
+    torch.manual_seed(2024)
+    net = dma.EquivariantGNN(L, 2 * H + 1, W, M, 2 * H + 1, W, 1, H + M, W, H)
+    if finite_init:
+        with torch.no_grad():
+            for layer in net.egcl_list:
+                layer.mlp_x[4].weight.mul_(1e-3)
+                layer.mlp_x[4].bias.mul_(1e-3)
+                if n_atoms > 64:
+                    layer.mlp_m[2].weight.mul_(64.0 / n_atoms)
+                    layer.mlp_m[2].bias.mul_(64.0 / n_atoms)
+    return net
+
+
+def cpu_baseline(sd, n_atoms, target_seconds=15.0):
     """The oracle (torch CPU fp32 restatement of the reference) on a bounded sample of the same
     workload: B=4 graphs of 64 atoms, a few reverse steps from t=T."""
     from oracle.diffusion_ref import DiffusionRef, remove_mean
@@ -84,166 +132,147 @@ def cpu_baseline(sd, H, A, T, n_atoms, target_seconds=15.0):
             "sample": f"{steps} reverse steps from t=T on {B} graphs x {n_atoms} atoms, fp32 torch-CPU oracle, {el:.1f} s"}
 
 
-def train_bench(args, world, rank, dev, backend):
-    """BASELINE configs[3]: 64-atom SiO2 training, `--batch` graphs per rank (256 -> global 2048 on 8 GPUs),
-    one step = diffuse_as_batch + EGNN forward (HIP) + backward (HIP stage kernels + library GEMMs) + gradient all-reduce (RCCL) + Adam."""
+class Ranks:
+    """process-group plumbing shared by the legs"""
+
+    def __init__(self, args):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        # BENCH_DEVICE / BENCH_BACKEND exist only to rehearse the N>1 code path on a one-GPU box
+        # (all ranks on one device, gloo for the collectives); the driver's runs use one GPU per rank + RCCL.
+        dev_index = int(os.environ.get("BENCH_DEVICE", local_rank))
+        self.backend = os.environ.get("BENCH_BACKEND", "nccl")
+        torch.cuda.set_device(dev_index)
+        self.dev = torch.device("cuda", dev_index)
+        if self.world > 1:
+            import torch.distributed as dist
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)
+            else:
+                dist.init_process_group(self.backend)
+
+    def barrier(self):
+        torch.cuda.synchronize(self.dev)
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize(self.dev)
+
+    def max_over_ranks(self, seconds):
+        if self.world == 1:
+            return seconds
+        import torch.distributed as dist
+        tt = torch.tensor([seconds], device=self.dev if self.backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    def timed(self, fn):
+        """barrier + synchronize on both sides; MAX over ranks"""
+        self.barrier()
+        t0 = time.perf_counter()
+        fn()
+        self.barrier()
+        return self.max_over_ranks(time.perf_counter() - t0)
+
+    def close(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def train_leg(args, rk, steps, warmup, batch):
+    """BASELINE configs[3] per-rank shape: 64-atom SiO2 training, `batch` graphs per rank (256 -> global 2048 on 8 GPUs);
+    one step = diffuse_as_batch + EGNN forward + backward (HIP) + per-layer gradient all-reduce (RCCL, issued from inside
+    the backward) + Adam.  Timed twice on N > 1: with the all-reduce and without it (what the same rank does alone)."""
     from types import SimpleNamespace
-    import torch.distributed as dist
     import diffusion_model_amd as dma
-    H, M, W, A, T = 36, 256, 1024, 2, 1000
-    L, B, n, K, Wm = args.layers, args.batch, args.atoms, args.steps, args.warmup
-    params = dict(conditional=False, to_compress_spectrum=False, give_exO=False, atom_type_size=A)
-    torch.manual_seed(2024)
-    net = dma.EquivariantGNN(L, 2 * H + 1, W, M, 2 * H + 1, W, 1, H + M, W, H).to(dev)
+    L, n = args.layers, args.atoms
+    dev, world, rank = rk.dev, rk.world, rk.rank
+    net = build_net(dma, L, n, finite_init=False).to(dev)
     net.precision, net.norm_scope = args.precision, "graph"
-    nn_dict = {"egnn": net}
     proc = dma.E3DiffusionProcess(1e-5, 2.0, T)
-    g = torch.Generator().manual_seed(1 + rank)
-    plan = dma.fully_connected_plan([n] * B, dev)
-    side = round(n ** (1 / 3))
-    grid = torch.stack(torch.meshgrid(*[torch.arange(side, dtype=torch.float32)] * 3, indexing="ij"), -1).reshape(-1, 3) * 1.6
-    pos = (grid.repeat(B, 1) + 0.1 * torch.randn(B * n, 3, generator=g)).to(dev)
-    types = torch.zeros(n, A)
-    types[0, 0] = 1; types[1:22, 1] = 1; types[22:, 0] = 1
-    cond = synthetic_cond(B, n, H - A - 1, 1 + rank).to(dev)
-    data = SimpleNamespace(pos=pos, x=types.repeat(B, 1).to(dev), batch=plan.batch, edge_index=dma.plan_edge_index(plan))
-    # conditioning columns enter through a fixed tensor here (the compressor is off the hot path)
+    plan = dma.fully_connected_plan([n] * batch, dev)
+    pos, types = sio2_cells(batch, n, seed=1 + rank)
+    cond = synthetic_cond(batch, n, H - A - 1, 1 + rank).to(dev)
+    data = SimpleNamespace(pos=pos.to(dev), x=types.to(dev), batch=plan.batch, edge_index=dma.plan_edge_index(plan))
     opt = torch.optim.Adam(net.parameters(), lr=1e-5)
     reducer = dma.GradAllReducer(list(net.egcl_list)) if world > 1 else None
+    losses = []
 
-    def step():
-        opt.zero_grad()
-        noised = dma.diffuse_as_batch(data.pos, data.x, data.batch, proc)
-        nb_glob = dma.training.global_graph_count(B, dev) if world > 1 and backend == "nccl" else B * world
-        loss, _, _ = dma.training_loss(net, data.edge_index, data.batch, noised, cond, A, num_graph_global=nb_glob)
+    def step(reduce_grads):
+        opt.zero_grad(set_to_none=True)
+        noised = dma.diffuse_as_batch(data.pos, data.x, data.batch, proc, num_graphs=batch)
+        if reducer is not None and reduce_grads:
+            reducer.arm()          # buckets are all-reduced from inside the backward, layer by layer
+        loss, _, _ = dma.training_loss(net, data.edge_index, data.batch, noised, cond, A, num_graph_global=batch * world,
+                                       num_graphs=batch)
         loss.backward()
-        if reducer is not None:
-            reducer.reduce()
+        if reducer is not None and reduce_grads:
+            reducer.finish()
         opt.step()
-        return loss
+        losses.append(loss.detach())
 
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+    def run(k, reduce_grads):
+        for _ in range(k):
+            step(reduce_grads)
 
-    for _ in range(Wm):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(K):
-        loss = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    run(warmup, True)
+    el = rk.timed(lambda: run(steps, True))
+    out = {"metric": "atoms*(fwd+bwd) steps/sec, 64-atom SiO2 training", "unit": "atoms*train-steps/s",
+           "value": world * batch * n * steps / el, "ms_per_step": el * 1e3 / steps, "steps": steps, "warmup": warmup,
+           "graphs_per_rank": batch, "global_batch": batch * world, "rccl_ranks": world if rk.backend == "nccl" else 0,
+           "collective_backend": rk.backend if world > 1 else None,
+           "allreduce_bytes_per_step": sum(p.numel() for p in net.parameters()) * 4 if world > 1 else 0,
+           "step": "diffuse_as_batch + HIP forward + HIP backward + per-layer gradient all-reduce + Adam"}
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    if rank == 0:
-        print(json.dumps({
-            "metric": "atoms*(fwd+bwd) steps/sec, 64-atom SiO2 training", "value": world * B * n * K / elapsed,
-            "unit": "atoms*train-steps/s", "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": elapsed * 1e3 / K,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"{n}-atom SiO2 cells x {B} graphs/GPU, {L}-layer EGNN, HIP forward + HIP backward stage "
-                                   f"kernels around library GEMMs + per-layer RCCL gradient all-reduce + Adam",
-                       "global_batch": world * B, "parallelism": f"dp{world}"},
-            "final_loss": float(loss.detach())}), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        el1 = rk.timed(lambda: run(steps, False))
+        out["ms_per_step_without_allreduce"] = el1 * 1e3 / steps
+        out["efficiency_vs_no_collective"] = el1 / el
+    final = torch.stack(losses[-steps:]).float()
+    out["final_loss"] = float(final[-1])
+    out["finite"] = bool(torch.isfinite(final).all())
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="graphs per GPU")
-    ap.add_argument("--atoms", type=int, default=64)
-    ap.add_argument("--layers", type=int, default=4)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--mode", default="sample", choices=["sample", "train"],
-                    help="sample = headline metric (default); train = BASELINE configs[3] shape, fwd+bwd+all-reduce+Adam")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    # BENCH_DEVICE / BENCH_BACKEND exist only to rehearse the N>1 code path on a one-GPU box
-    # (all ranks on one device, gloo for the timing collective); the driver's runs use one GPU per rank + RCCL.
-    dev_index = int(os.environ.get("BENCH_DEVICE", local_rank))
-    backend = os.environ.get("BENCH_BACKEND", "nccl")
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    if world > 1:
-        import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-
+def sample_leg(args, rk):
+    import ctypes as C
     import diffusion_model_amd as dma
     from diffusion_model_amd import _lib
-
-    if args.mode == "train":
-        return train_bench(args, world, rank, dev, backend)
-    H, M, W, A, T = 36, 256, 1024, 2, 1000
     L, B, n = args.layers, args.batch, args.atoms
     K, Wm = args.steps, args.warmup
-    assert K + Wm <= T
-    torch.manual_seed(2024)
-    net = dma.EquivariantGNN(L, 2 * H + 1, W, M, 2 * H + 1, W, 1, H + M, W, H)
-    # Random-init weights of the named architecture.  The untrained coordinate head (mlp_x.4, a
-    # [1, 1024] vector without any range clamp, SURVEY Q4) makes the reverse chain overflow within a
-    # few steps; it is scaled by 1e-3 so the benchmark runs on finite, realistic magnitudes.  The
-    # arithmetic performed per step is unchanged.
-    # Graphs larger than the 64-atom reference cell sum proportionally more messages per node; the message
-    # head is scaled by 64/atoms for them, again only to keep untrained weights in a finite regime.
-    with torch.no_grad():
-        for layer in net.egcl_list:
-            layer.mlp_x[4].weight.mul_(1e-3)
-            layer.mlp_x[4].bias.mul_(1e-3)
-            if n > 64:
-                layer.mlp_m[2].weight.mul_(64.0 / n)
-                layer.mlp_m[2].bias.mul_(64.0 / n)
+    dev, world, rank = rk.dev, rk.world, rk.rank
+    net = build_net(dma, L, n)
     sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
     net.to(dev).eval()
     net.precision = args.precision
     proc = dma.E3DiffusionProcess(1e-5, 2.0, T)
     cond = synthetic_cond(B, n, H - A - 1, seed=1 + rank)
     smp = dma.DeviceSampler(net, proc, [n] * B, cond, atom_type_size=A, seed=rank, norm_scope="graph", device=dev)
-    smp.init()
     lib = _lib.lib()
+    reps = max(1, args.reps)
+    if K + Wm > T:
+        raise SystemExit(f"--steps + --warmup must be <= T = {T}")
 
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    # warm-up (also instantiates the hipGraph used by the extra graph-replay measurement below)
+    # warm-up
+    smp.init()
     smp.run(nsteps=Wm, use_graph=False)
-    # ---- timed region: K steps, HIP events around every fused edge-kernel launch ----
+    # ---- timed region: `reps` repetitions of EXACTLY K steps from the same initial state (seeded x_T, h_T after the
+    # warm-up steps), each bracketed by barrier + synchronize, MAX over ranks; HIP events around every fused
+    # edge-kernel launch.  The median repetition is reported.
     _lib.check(lib.egnn_profile_enable(smp.ctx.handle, 1))
-    barrier()
-    t0 = time.perf_counter()
-    smp.run(nsteps=K, use_graph=False, sync=True)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    import ctypes as C
+    rep_s = []
+    bad_total = 0
+    for _ in range(reps):
+        smp.init()
+        smp.run(nsteps=Wm, use_graph=False)
+        rep_s.append(rk.timed(lambda: smp.run(nsteps=K, use_graph=False, sync=True)))
+        bad_total = max(bad_total, int(smp.state()[2].sum()))
     edge_ms, edge_n, node_ms = C.c_float(0), C.c_int(0), C.c_float(0)
     _lib.check(lib.egnn_profile_read(smp.ctx.handle, C.byref(edge_ms), C.byref(edge_n), C.byref(node_ms)))
     _lib.check(lib.egnn_profile_enable(smp.ctx.handle, 0))
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = statistics.median(rep_s)
     # ---- extra: the same K steps replayed from the captured hipGraph (no events) ----
     graph_ms = None
     if smp.t >= K + 2:
@@ -253,54 +282,125 @@ def main():
         smp.run(nsteps=K, use_graph=True, sync=True)
         torch.cuda.synchronize(dev)
         graph_ms = (time.perf_counter() - t1) * 1e3 / K
-    _, _, bad = smp.state()
+        bad_total = max(bad_total, int(smp.state()[2].sum()))
 
-    if rank == 0:
-        E = B * n * (n - 1)
-        flops_per_launch = 2.0 * edge_macs(H, M, W, W) * E
-        achieved = flops_per_launch / (edge_ms.value * 1e-3) / 1e12 if edge_ms.value > 0 else 0.0
-        peak = PEAK_TFLOPS[args.precision]
-        # HBM bytes per launch come from separate rocprofv3 --pmc passes (profiles/traffic.json, same workload);
-        # they cannot be collected from inside this process
+    E = B * n * (n - 1)
+    flops_per_launch = 2.0 * edge_macs(H, M, W, W) * E
+    achieved = flops_per_launch / (edge_ms.value * 1e-3) / 1e12 if edge_ms.value > 0 else 0.0
+    peak = PEAK_TFLOPS[args.precision]
+    # HBM bytes per launch come from separate rocprofv3 --pmc passes (profiles/traffic.json, same workload);
+    # they cannot be collected from inside this process
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if args.precision == "bf16" and B == 256 and n == 64 and L == 4:
+            traffic = tj["bytes_per_launch"]
+    except Exception:
         traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if args.precision == "bf16" and B == 256 and n == 64 and L == 4:
-                traffic = tj["bytes_per_launch"]
-        except Exception:
-            traffic = None
-        out = {
-            "metric": "atoms*denoise-steps/sec, 64-atom SiO2 T=1000",
-            "value": world * B * n * K / elapsed,
-            "unit": "atoms*denoise-steps/s",
-            "n_gpus": world, "steps": K, "warmup": Wm,
-            "ms_per_step": elapsed * 1e3 / K,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"{n}-atom SiO2 cells x {B} graphs/GPU, {L}-layer EGNN (H=36, W=1024, m=256), "
-                                   f"T=1000 reverse steps, fully connected (E={E}/GPU)",
-                       "global_batch": world * B, "parallelism": f"replicas x{world} (no data-path collective)"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic,
-                         "traffic_source": "profiles/traffic.json (rocprofv3 --pmc, separate pass)" if traffic else None,
-                         "kernel": "fused edge pass of one EGCL layer (edge_kernel_bf16_v3 X+M launches, or "
-                                   "edge_kernel_bf16_v2 / edge_kernel<F32>)",
-                         "avg_launch_ms": edge_ms.value, "launches": edge_n.value,
-                         "algorithmic_flop_per_launch": flops_per_launch,
-                         # the first Linear layers are evaluated per node (factorised), so the matrix cores execute
-                         # only the second-layer products of the count above
-                         "mfma_executed_flop_per_launch": 2.0 * (W * M + W * W) * E},
-            "graph_replay_ms_per_step": graph_ms,
-            "node_kernels_ms_per_layer": node_ms.value * 2,
-            "nonfinite_graphs": int(bad.sum()),
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sd, H, A, T, n, args.cpu_seconds)
+    out = {
+        "metric": "atoms*denoise-steps/sec, 64-atom SiO2 T=1000",
+        "value": world * B * n * K / elapsed,
+        "unit": "atoms*denoise-steps/s",
+        "n_gpus": world, "steps": K, "warmup": Wm,
+        "ms_per_step": elapsed * 1e3 / K,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": f"{n}-atom SiO2 cells x {B} graphs/GPU, {L}-layer EGNN (H=36, W=1024, m=256), "
+                               f"T=1000 reverse steps, fully connected (E={E}/GPU)",
+                   "global_batch": world * B, "parallelism": f"replicas x{world} (no data-path collective)"},
+        "timed_region": {"repetitions": reps, "steps_each": K, "ms_per_step_each": [s * 1e3 / K for s in rep_s],
+                         "reported": "median repetition"},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                     "frac": achieved / peak, "traffic": traffic,
+                     "traffic_source": "profiles/traffic.json (rocprofv3 --pmc, separate pass)" if traffic else None,
+                     "kernel": "fused edge pass of one EGCL layer (edge_kernel_bf16_v3 X+M launches, or "
+                               "edge_kernel_bf16_v2 / edge_kernel<F32>)",
+                     "avg_launch_ms": edge_ms.value, "launches": edge_n.value,
+                     "algorithmic_flop_per_launch": flops_per_launch,
+                     # the first Linear layers are evaluated per node (factorised), so the matrix cores execute
+                     # only the second-layer products of the count above
+                     "mfma_executed_flop_per_launch": 2.0 * (W * M + W * W) * E},
+        "graph_replay_ms_per_step": graph_ms,
+        "node_kernels_ms_per_layer": node_ms.value * 2,
+        "nonfinite_graphs": bad_total,
+    }
+    del smp
+    return out, sd
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` from a plain shell: start the N ranks as a child torch.distributed.run (nothing in
+    this process has touched the GPU; the child is a new process, not an exec of this one)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the K timed steps; the median is reported")
+    ap.add_argument("--batch", type=int, default=256, help="graphs per GPU")
+    ap.add_argument("--atoms", type=int, default=64)
+    ap.add_argument("--layers", type=int, default=4)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--mode", default="sample", choices=["sample", "train"],
+                    help="sample = headline metric (default, with the ddp_train sub-record); train = BASELINE configs[3] "
+                         "shape only (fwd+bwd+all-reduce+Adam) as the headline of the line")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-leg", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=8)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
+    rk = Ranks(args)
+    if rk.world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={rk.world}")
+    valid = True
+    if args.mode == "train":
+        tr = train_leg(args, rk, args.steps, args.warmup, args.batch)
+        out = dict(tr)
+        out.update({"n_gpus": rk.world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                    "dtype": args.precision, "data": "synthetic",
+                    "config": {"workload": f"{args.atoms}-atom SiO2 cells x {args.batch} graphs/GPU, {args.layers}-layer EGNN, "
+                                           f"{tr['step']}", "global_batch": rk.world * args.batch,
+                               "parallelism": f"dp{rk.world}"}})
+        valid = tr["finite"]
+    else:
+        out, sd = sample_leg(args, rk)
+        valid = out["nonfinite_graphs"] == 0
+        if not args.no_train_leg:
+            if args.atoms == 64:
+                tr = train_leg(args, rk, args.train_steps, 2, 256)
+                out["ddp_train"] = tr
+                valid = valid and tr["finite"]
+        if rk.world == 1 and rk.rank == 0 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd, args.atoms, args.cpu_seconds)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    if rk.world > 1:
+        # any rank with a non-finite state invalidates the line
+        import torch.distributed as dist
+        flag = torch.tensor([0 if valid else 1], device=rk.dev if rk.backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        valid = int(flag.item()) == 0
+    if rk.rank == 0:
+        out["valid"] = valid
+        if not valid:
+            out["invalid_value"] = out.pop("value", None)
+            out["value"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    rk.close()
+    if not valid:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -46,7 +46,7 @@ SIGNATURES = {
     "egnn_fc_graph_build": (_i, [_vp, _i, _i] + [_vp] * 6),
     "egnn_radius_graph_count": (_i, [_vp, _i, _vp, _vp, _vp, _f, _vp]),
     "egnn_radius_graph_fill": (_i, [_vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
-    "egnn_rdf": (_i, [_vp, _i, _vp, _vp, _f, _f, _f, _i, _i, _vp]),
+    "egnn_rdf": (_i, [_vp, _i, _vp, _vp, C.c_double, C.c_double, _f, _i, _i, _vp]),
     "egnn_si_o_si": (_i, [_vp, _i, _i, _vp, _vp, _vp, _f, _vp]),
     "egnn_debug_stamps": (_i, [_vp, C.POINTER(C.c_uint64)]),
     "egnn_profile_enable": (_i, [_vp, _i]),

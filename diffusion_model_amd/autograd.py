@@ -29,6 +29,10 @@ import os
 
 EDGE_CHUNK = int(os.environ.get("EGNN_BWD_CHUNK", 1 << 19))   # edges per backward chunk (workspace = 6 bf16 [chunk, W] buffers)
 
+# training.GradAllReducer.arm() puts itself here: the backward below hands it every layer's parameter gradients as soon
+# as they are final, so the bucket's all-reduce runs under the backward of the earlier layers
+ACTIVE_REDUCER = None
+
 
 def _segment_scale(S, scope_graph, node_graph):
     G = torch.sqrt(S.clamp_min(1e-30))   # graphs without edges: S = 0, zero gradient
@@ -211,6 +215,13 @@ class _EGNNFunction(torch.autograd.Function):
             if E > 0:
                 _edge_backward(layer, prec, ws, h_l, x_l, dst32, src32, node_seg, g_am, g_ax, g_S.contiguous(), g_h, g_x, grads)
             gh, gx = g_h, g_x
+            red = ACTIVE_REDUCER
+            if red is not None and id(layer) in red.bucket_of:
+                ps = red.buckets[red.bucket_of[id(layer)]]
+                for p_, g_ in zip(ps, red.layer_ready(layer, [grads.get(p_) for p_ in ps])):
+                    grads[p_] = g_
+        if ACTIVE_REDUCER is not None:
+            ACTIVE_REDUCER.sync()
         flat = []
         for layer in layers:
             for p in layer._ordered_params():

@@ -68,9 +68,14 @@ __global__ void radius_fill_kernel(const float* __restrict__ x, const int* __res
 // bins r_k = (k+1)*dR, k < nbins; count of distances with r_k < d < r_k + dR, divided by 4 pi rho r_k^2 dR with
 // rho = n / (4/3 pi R^3); Gaussian filter (sigma bins, truncate 4 sigma, 'reflect' boundary) as scipy's
 // gaussian_filter1d.  One workgroup per graph; fp64 accumulation like the numpy reference.
+// Bin membership follows the reference's mixed arithmetic exactly (pinned by tests/golden/stats_golden.npz): the
+// distance is a float32 torch.norm of a float32 difference, the bin edges are the float64 values
+// np.arange(dR, R + dR, dR)[k] = dR + k*dR and r + dR, and `r < d < r + dR` compares them AFTER rounding the edges to
+// float32 (a 0-dim float32 tensor against a Python float) -- so an atom sitting exactly on a float32 edge is in
+// no bin.
 constexpr int kMaxBins = 1024;
-__global__ __launch_bounds__(256) void rdf_kernel(const float* __restrict__ pos, const int* __restrict__ graph_ptr, float R,
-                                                  float dR, int nbins, float sigma, int normalize, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void rdf_kernel(const float* __restrict__ pos, const int* __restrict__ graph_ptr, double R,
+                                                  double dR, int nbins, float sigma, int normalize, float* __restrict__ out) {
   __shared__ int cnt[kMaxBins];
   __shared__ double raw[kMaxBins];
   __shared__ double red[256];
@@ -79,21 +84,20 @@ __global__ __launch_bounds__(256) void rdf_kernel(const float* __restrict__ pos,
   __syncthreads();
   const float x0 = pos[3 * lo], y0 = pos[3 * lo + 1], z0 = pos[3 * lo + 2];
   for (int i = lo + 1 + threadIdx.x; i < hi; i += blockDim.x) {
-    const double dx = (double)pos[3 * i] - x0, dy = (double)pos[3 * i + 1] - y0, dz = (double)pos[3 * i + 2] - z0;
-    const double d = sqrt(dx * dx + dy * dy + dz * dz);
-    // the bin edges are the fp64 values np.arange(dR, R + dR, dR)[k] = dR + k*dR
-    int k = (int)floor(d / (double)dR) - 1;
+    const float dx = pos[3 * i] - x0, dy = pos[3 * i + 1] - y0, dz = pos[3 * i + 2] - z0;
+    const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+    const int k = (int)floor((double)d / dR) - 1;
     for (int kk = k - 1; kk <= k + 1; ++kk) {
       if (kk < 0 || kk >= nbins) continue;
-      const double rk = (double)dR + (double)kk * (double)dR;
-      if (rk < d && d < rk + (double)dR) atomicAdd(&cnt[kk], 1);
+      const double rk = dR + (double)kk * dR;
+      if ((float)rk < d && d < (float)(rk + dR)) atomicAdd(&cnt[kk], 1);
     }
   }
   __syncthreads();
-  const double rho = (double)n / (4.0 / 3.0 * M_PI * (double)R * R * R);
+  const double rho = (double)n / (4.0 / 3.0 * M_PI * R * R * R);
   for (int k = threadIdx.x; k < nbins; k += blockDim.x) {
-    const double rk = (double)dR + (double)k * (double)dR;
-    raw[k] = (double)cnt[k] / (4.0 * M_PI * rho * rk * rk * (double)dR);
+    const double rk = dR + (double)k * dR;
+    raw[k] = (double)cnt[k] / (4.0 * M_PI * rho * rk * rk * dR);
   }
   __syncthreads();
   const int lw = (int)(4.0 * (double)sigma + 0.5);
@@ -194,9 +198,9 @@ int egnn_radius_graph_fill(void* stream, int N, const float* x, const int32_t* g
   return EGNN_OK;
 }
 
-int egnn_rdf(void* stream, int B, const float* pos, const int32_t* graph_ptr, float R, float dR, float sigma,
+int egnn_rdf(void* stream, int B, const float* pos, const int32_t* graph_ptr, double R, double dR, float sigma,
              int normalize, int nbins, float* out) {
-  if (B < 1 || !pos || !graph_ptr || !out || nbins < 1 || nbins > kMaxBins || !(dR > 0.f) || !(sigma > 0.f)) {
+  if (B < 1 || !pos || !graph_ptr || !out || nbins < 1 || nbins > kMaxBins || !(dR > 0.0) || !(sigma > 0.f)) {
     set_error("bad egnn_rdf arguments (nbins <= %d)", kMaxBins);
     return EGNN_EINVAL;
   }

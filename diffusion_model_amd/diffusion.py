@@ -16,20 +16,24 @@ from . import _lib
 from .snr import GammaNetwork
 
 
-def _graph_ptr_from_batch(batch_index: torch.Tensor):
+def _graph_ptr_from_batch(batch_index: torch.Tensor, num_graphs: Optional[int] = None):
     b = batch_index.long()
-    if b.numel() > 1 and bool((b[1:] < b[:-1]).any()):
-        raise ValueError("batch_index must be sorted (PyG collate order)")
-    nb = int(b.max().item()) + 1
-    cnt = torch.bincount(b, minlength=nb)
+    if num_graphs is None:   # the reference's own form (diffusion_x_h.py:10): one host sync
+        if b.numel() > 1 and bool((b[1:] < b[:-1]).any()):
+            raise ValueError("batch_index must be sorted (PyG collate order)")
+        nb = int(b.max().item()) + 1
+    else:                    # collated batches know their graph count: no host sync
+        nb = int(num_graphs)
+    cnt = torch.zeros(nb, dtype=torch.long, device=b.device).index_add_(0, b, torch.ones_like(b))
     ptr = torch.zeros(nb + 1, dtype=torch.int32, device=b.device)
     ptr[1:] = torch.cumsum(cnt, 0).to(torch.int32)
     return ptr, nb
 
 
-def remove_mean(x: torch.Tensor, batch_index: Optional[torch.Tensor] = None) -> torch.Tensor:
+def remove_mean(x: torch.Tensor, batch_index: Optional[torch.Tensor] = None, num_graphs: Optional[int] = None) -> torch.Tensor:
     """remove_mean(x, batch_index=None) (diffusion_x_h.py:5-14).  Like the reference, the
-    batch_index form updates ``x`` in place and returns it; the global form returns a new tensor."""
+    batch_index form updates ``x`` in place and returns it; the global form returns a new tensor.
+    ``num_graphs`` (extension) skips the host sync that finds the graph count."""
     if not x.is_cuda:
         raise RuntimeError("remove_mean needs a CUDA(ROCm) tensor; there is no CPU fallback")
     xc = x.detach().to(torch.float32).contiguous()
@@ -38,7 +42,7 @@ def remove_mean(x: torch.Tensor, batch_index: Optional[torch.Tensor] = None) -> 
     if batch_index is None:
         _lib.check(_lib.lib().egnn_remove_mean(_lib.stream_ptr(), n, d, None, 0, _lib.ptr(xc), _lib.ptr(out)))
         return out
-    ptr, nb = _graph_ptr_from_batch(batch_index.to(x.device))
+    ptr, nb = _graph_ptr_from_batch(batch_index.to(x.device), num_graphs)
     _lib.check(_lib.lib().egnn_remove_mean(_lib.stream_ptr(), n, d, _lib.ptr(ptr), nb, _lib.ptr(xc), _lib.ptr(out)))
     x.copy_(out)
     return x
@@ -112,6 +116,22 @@ class E3DiffusionProcess(nn.Module):
             self._learned_tables()
         return self.sigma_schedule[t]
 
+    def alpha_sigma_tables(self, device, with_grad: bool = False):
+        """(alpha [T+1], sigma [T+1]) on ``device`` for indexed gathers by a vector of times.  For the learned
+        schedule with ``with_grad`` the whole grid is evaluated through GammaNetwork under autograd
+        (alpha = sqrt(sigmoid(-gamma)), sigma = sqrt(sigmoid(gamma)), diffusion_x_h.py:36-46), so that what is built
+        from the gathered values is differentiable w.r.t. the schedule parameters as in the reference."""
+        if self.noise_schedule == "learned" and with_grad and any(p.requires_grad for p in self.gamma.parameters()):
+            g = self.gamma_schedule().reshape(-1).float().to(device)
+            return torch.sqrt(torch.sigmoid(-g)), torch.sqrt(torch.sigmoid(g))
+        if self.noise_schedule == "learned":
+            self._learned_tables()
+        key = "as:" + str(device)
+        if key not in self._table_dev:
+            self._table_dev[key] = (self.alpha_schedule.to(device).float().contiguous(),
+                                    self.sigma_schedule.to(device).float().contiguous())
+        return self._table_dev[key]
+
     def step_table(self, device=None) -> torch.Tensor:
         """[T+1, 4] per-step constants {1/alpha_ts, sigma2_ts/(alpha_ts sigma_t), std, t/T}."""
         if self.noise_schedule == "learned":
@@ -130,10 +150,11 @@ class E3DiffusionProcess(nn.Module):
             raise RuntimeError("E3DiffusionProcess steps need CUDA(ROCm) tensors; there is no CPU fallback")
         return z.detach().to(torch.float32).contiguous()
 
-    def diffuse_zero_to_t(self, z: torch.Tensor, t: int, mode="pos"):
-        """z_t = alpha_t z + sigma_t eps, eps ~ N(0,I) mean-removed iff mode == 'pos' (:51-59)."""
+    def diffuse_zero_to_t(self, z: torch.Tensor, t: int, mode="pos", noise: Optional[torch.Tensor] = None):
+        """z_t = alpha_t z + sigma_t eps, eps ~ N(0,I) mean-removed iff mode == 'pos' (:51-59); ``noise``
+        (extension, as in reverse_diffuse_one_step) replaces the N(0,I) draw BEFORE the mean removal."""
         zc = self._prep(z)
-        noise = torch.zeros_like(zc).normal_(mean=0, std=1)
+        noise = torch.zeros_like(zc).normal_(mean=0, std=1) if noise is None else self._prep(noise).clone()
         if mode == "pos":
             noise = remove_mean(noise)
         out = torch.empty_like(zc)
@@ -182,8 +203,8 @@ class E3DiffusionProcessXOnly(E3DiffusionProcess):
     test.py): diffuse_zero_to_t(pos, t), calculate_mu(pos, eps, t) in the x_hat form (algebraically the
     same mu as diffusion_x_h), reverse_diffuse_one_step(mu, t)."""
 
-    def diffuse_zero_to_t(self, pos, t):  # noqa: D102
-        return super().diffuse_zero_to_t(pos, t, mode="pos")
+    def diffuse_zero_to_t(self, pos, t, noise: Optional[torch.Tensor] = None):  # noqa: D102
+        return super().diffuse_zero_to_t(pos, t, mode="pos", noise=noise)
 
     def reverse_diffuse_one_step(self, mu, t, noise: Optional[torch.Tensor] = None):  # noqa: D102
         mc = self._prep(mu)

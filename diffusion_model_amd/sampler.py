@@ -21,6 +21,9 @@ class DeviceSampler:
     """Batched device-resident sampler for ``sizes`` fully connected graphs.
 
     cond: [N, H - A - 1] constant conditioning columns ([compressed spectrum | exO]) or None.
+
+    One live sampler per model: the sampler state lives in the model's egnn_ctx, so preparing a second
+    DeviceSampler on the same ``egnn`` invalidates the first (its next call raises EGNN_ESTATE).
     """
 
     def __init__(self, egnn, diffusion_process, sizes: Sequence[int], cond: Optional[torch.Tensor],
@@ -80,6 +83,9 @@ class DeviceSampler:
         self.stream.wait_stream(torch.cuda.current_stream())
         _lib.check(_lib.lib().egnn_sampler_run(self.ctx.handle, self._sp(), self.precision, self.norm_scope, int(nsteps),
                                                1 if use_graph else 0, _lib.ptr(keep[0]), _lib.ptr(keep[1])))
+        for x in keep:
+            if x is not None:
+                x.record_stream(self.stream)   # the caching allocator must not recycle them under the sampler stream
         if sync:
             self.stream.synchronize()
         else:
@@ -98,6 +104,7 @@ class DeviceSampler:
         xt = torch.empty(self.N, self.A, device=self.device)
         bad = torch.empty(len(self.sizes), dtype=torch.int32, device=self.device)
         th = C.c_int(0)
+        self.stream.wait_stream(torch.cuda.current_stream())   # the outputs were allocated on the caller's stream
         _lib.check(_lib.lib().egnn_sampler_state(self.ctx.handle, self._sp(), _lib.ptr(pos), _lib.ptr(xt), _lib.ptr(bad), C.byref(th)))
         self.stream.synchronize()
         return pos, xt, bad
@@ -108,6 +115,7 @@ class DeviceSampler:
         hc = torch.empty(self.N, self.A, device=self.device)
         oh = torch.empty(self.N, self.A, dtype=torch.int32, device=self.device)
         keep = [x.detach().to(self.device, torch.float32).contiguous() if x is not None else None for x in (noise_pos, noise_h)]
+        self.stream.wait_stream(torch.cuda.current_stream())   # noise conversions / output allocations of the caller's stream
         _lib.check(_lib.lib().egnn_sampler_final(self.ctx.handle, self._sp(), self.precision, self.norm_scope,
                                                  _lib.ptr(keep[0]), _lib.ptr(keep[1]), _lib.ptr(pos), _lib.ptr(hc), _lib.ptr(oh)))
         bad = torch.empty(len(self.sizes), dtype=torch.int32, device=self.device)

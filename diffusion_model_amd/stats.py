@@ -1,5 +1,5 @@
 """Acceptance statistics of sampled structures on the device: RDF about the excited O
-(atom 0) with its similarity metrics (evaluate_RDF.py:30-63) and the Si-O-Si angle / bond-length comparison
+(atom 0) with its similarity metrics cos / L2 / MSE / Wasserstein (evaluate_RDF.py:13-83) and the Si-O-Si angle / bond-length comparison
 with R^2 (evaluate_Si-O-Si.py:23-53, CN2_evaluate.py:12-37)."""
 from __future__ import annotations
 
@@ -39,17 +39,44 @@ def rdf(position: torch.Tensor, sizes: Sequence[int] | None = None, sigma=5, R=5
 
 def cos_similarity(a, b):
     """evaluate_RDF.py:62-63"""
-    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    a, b = _np(a), _np(b)
     return float(np.dot(a, b) / (np.linalg.norm(a) * np.linalg.norm(b)))
 
 
+def _np(a):
+    return a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+
+
 def rdf_l2(a, b):
-    return float(np.linalg.norm(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)))
+    """euclidean_distance(a, b) of evaluate_RDF.py:82-83 (the L2 the reference ranks RDF pairs by, :105-123)"""
+    return float(np.linalg.norm(_np(a) - _np(b)))
+
+
+def wasserstein(a, b):
+    """calculate_wasserstein_distance(rdf1, rdf2) of evaluate_RDF.py:13-24 = scipy.stats.wasserstein_distance(u_values,
+    v_values): the two arrays are taken as SAMPLES of two 1-D distributions (the RDF values themselves, not weights
+    over r), W1 = integral |U(x) - V(x)| dx over the merged support; for equal lengths mean |sort(a) - sort(b)|.
+    Tensors stay on their device (sort + searchsorted), numpy inputs are computed on the host."""
+    if torch.is_tensor(a) or torch.is_tensor(b):
+        dev = a.device if torch.is_tensor(a) else b.device
+        u = torch.as_tensor(a, device=dev).double().reshape(-1).sort().values
+        v = torch.as_tensor(b, device=dev).double().reshape(-1).sort().values
+        allv = torch.cat((u, v)).sort().values
+        deltas = allv[1:] - allv[:-1]
+        ucdf = torch.searchsorted(u, allv[:-1], right=True).double() / u.numel()
+        vcdf = torch.searchsorted(v, allv[:-1], right=True).double() / v.numel()
+        return float(((ucdf - vcdf).abs() * deltas).sum())
+    u, v = np.sort(_np(a).reshape(-1)), np.sort(_np(b).reshape(-1))
+    allv = np.sort(np.concatenate((u, v)))
+    deltas = np.diff(allv)
+    ucdf = np.searchsorted(u, allv[:-1], side="right") / u.size
+    vcdf = np.searchsorted(v, allv[:-1], side="right") / v.size
+    return float(np.sum(np.abs(ucdf - vcdf) * deltas))
 
 
 def rdf_mse(a, b):
-    """evaluate_RDF.py:37"""
-    return float(np.mean((np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)) ** 2))
+    """mean_squared_error(rdf1, rdf2) of evaluate_RDF.py:26-37"""
+    return float(np.mean((_np(a) - _np(b)) ** 2))
 
 
 def si_o_si(position: torch.Tensor, onehot: torch.Tensor, sizes: Sequence[int], cutoff=2.0):

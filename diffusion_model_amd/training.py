@@ -17,35 +17,46 @@ from .diffusion import remove_mean
 
 
 def diffuse_as_batch(pos, x_types, batch, diffusion_process, times: Optional[Sequence[int]] = None,
-                     noise_pos: Optional[torch.Tensor] = None, noise_h: Optional[torch.Tensor] = None):
+                     noise_pos: Optional[torch.Tensor] = None, noise_h: Optional[torch.Tensor] = None,
+                     num_graphs: Optional[int] = None):
     """-> dict(pos_t, h_t, y_pos, y_h, t_frac [N,1], times).  One random t in 1..T per graph
-    (random.choice in the reference, :56), eps_x mean-removed per graph, eps_h plain (:58-70)."""
+    (random.choice in the reference, :56), eps_x mean-removed per graph, eps_h plain (:58-70).
+
+    ``num_graphs`` (a collated batch knows it) avoids the reference's ``batch.max().item()`` host sync (:46).
+    alpha_t / sigma_t are gathered from the device copy of the schedule in one indexed read; with
+    noise_schedule='learned' they are evaluated WITH autograd (diffusion_x_h.py:36-46), so pos_t / h_t carry the
+    gradient to gamma_0 / gamma_1 exactly as in the reference's train_epoch."""
     T = diffusion_process.num_diffusion_timestep
-    nb = int(batch.max().item()) + 1
+    nb = int(batch.max().item()) + 1 if num_graphs is None else int(num_graphs)
     if times is None:
         times = [random.choice(range(1, T + 1)) for _ in range(nb)]
     times_t = torch.as_tensor(list(times), dtype=torch.long)
-    a = torch.stack([diffusion_process.alpha(int(t)) for t in times_t]).to(pos.device).float()
-    s = torch.stack([diffusion_process.sigma(int(t)) for t in times_t]).to(pos.device).float()
-    an, sn = a.index_select(0, batch).unsqueeze(1), s.index_select(0, batch).unsqueeze(1)
+    if times_t.numel() != nb:
+        raise ValueError("one diffusion time per graph")
+    times_d = times_t.to(pos.device, non_blocking=True)
+    a_all, s_all = diffusion_process.alpha_sigma_tables(pos.device, with_grad=torch.is_grad_enabled())
+    t_node = times_d.index_select(0, batch)
+    an, sn = a_all.index_select(0, t_node).unsqueeze(1), s_all.index_select(0, t_node).unsqueeze(1)
     if noise_pos is None:
         noise_pos = torch.zeros_like(pos, dtype=torch.float32).normal_()
     if noise_h is None:
         noise_h = torch.zeros(x_types.shape, dtype=torch.float32, device=pos.device).normal_()
-    y_pos = remove_mean(noise_pos.clone().float(), batch)          # HIP kernel, per graph
+    y_pos = remove_mean(noise_pos.clone().float(), batch, num_graphs=nb)          # HIP kernel, per graph
     y_h = noise_h.float()
     return dict(pos_t=an * pos.float() + sn * y_pos, h_t=an * x_types.float() + sn * y_h, y_pos=y_pos, y_h=y_h,
-                t_frac=(times_t.float() / T).to(pos.device).index_select(0, batch).unsqueeze(1), times=times_t)
+                t_frac=(t_node.float() / T).unsqueeze(1), times=times_t)
 
 
-def training_loss(egnn, edge_index, batch, noised, cond, atom_type_size, num_graph_global=None):
+def training_loss(egnn, edge_index, batch, noised, cond, atom_type_size, num_graph_global=None,
+                  num_graphs: Optional[int] = None):
     """loss = sum((eps_pred - eps)^2) / num_graph (:161-169); returns (loss, eps_x, eps_h)."""
     cols = [noised["h_t"]] + ([cond] if cond is not None and cond.shape[1] > 0 else []) + [noised["t_frac"]]
     h_in = torch.cat(cols, dim=1)
     h, x = egnn(edge_index, h_in, noised["pos_t"], batch=batch)
     d = x - noised["pos_t"]
-    nb = int(batch.max().item()) + 1
-    mean = torch.zeros(nb, 3, device=d.device).index_add_(0, batch, d) / torch.bincount(batch, minlength=nb).unsqueeze(1)
+    nb = int(batch.max().item()) + 1 if num_graphs is None else int(num_graphs)
+    cnt = torch.zeros(nb, device=d.device).index_add_(0, batch, torch.ones(batch.shape[0], device=d.device))
+    mean = torch.zeros(nb, 3, device=d.device).index_add_(0, batch, d) / cnt.unsqueeze(1)
     eps_x = d - mean.index_select(0, batch)                         # remove_mean(x - pos_t, graph_index), differentiable
     eps_h = h[:, :atom_type_size]
     pred = torch.cat((eps_x, eps_h), dim=1)
@@ -55,35 +66,96 @@ def training_loss(egnn, edge_index, batch, noised, cond, atom_type_size, num_gra
 
 
 class GradAllReducer:
-    """Sum gradients over the data-parallel group, one flat bucket per EGCL layer, on a side stream so the
-    exchange of layer l overlaps whatever the default stream does next (backward of the compressor,
-    optimizer of earlier buckets).  With 7.2 M fp32 parameters (28.8 MB) the exchange is far below one
-    step's compute; buckets keep each collective large enough for RCCL's direct algorithms over xGMI."""
+    """Sum gradients over the data-parallel group, one flat bucket per module (one per EGCL layer).
+
+    Overlapped form (``arm()`` ... backward ... ``finish()``): EquivariantGNN's backward walks the layers last to
+    first and hands each layer's parameter gradients to ``layer_ready`` as soon as they are final; the bucket is
+    all-reduced on a side stream while the backward of the earlier layers runs, and only the first layer's bucket
+    is exposed.  ``finish()`` reduces whatever did not come through that hook (modules differentiated by plain
+    torch autograd, e.g. the spectrum compressor).  ``reduce()`` is the un-overlapped form on ``.grad``.
+    With 7.2 M fp32 parameters (28.8 MB per step) a per-layer bucket is 7.2 MB: large enough for RCCL's direct
+    algorithms over the 7 xGMI links, small enough to hide under one layer's backward."""
 
     def __init__(self, modules, group=None):
         self.group = group
-        self.buckets = []
+        self.buckets, self.bucket_of = [], {}
         for m in modules:
             ps = [p for p in m.parameters() if p.requires_grad]
             if ps:
+                self.bucket_of[id(m)] = len(self.buckets)
                 self.buckets.append(ps)
-        self.stream = torch.cuda.Stream() if torch.cuda.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl" else None
+        self._nccl = torch.cuda.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"
+        self.stream = torch.cuda.Stream() if self._nccl else None
+        self._done, self._pending, self._armed = set(), [], False
 
+    def _active(self):
+        return dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    # -- overlapped form -------------------------------------------------------------------------------
+    def arm(self):
+        from . import autograd
+        self._done, self._pending, self._armed = set(), [], True
+        autograd.ACTIVE_REDUCER = self
+
+    def layer_ready(self, module, grads):
+        """grads: tensors (or None) aligned with the module's trainable parameters.  Starts the bucket's all-reduce
+        and returns views of the reduced flat buffer in the same order (valid after ``sync()``)."""
+        i = self.bucket_of.get(id(module))
+        if i is None or not self._active():
+            return grads
+        ps = self.buckets[i]
+        flat = torch.cat([(g if g is not None else torch.zeros_like(p)).reshape(-1).float() for p, g in zip(ps, grads)])
+        if self.stream is not None:
+            flat.record_stream(self.stream)
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            self._pending.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._done.add(i)
+        out, off = [], 0
+        for p in ps:
+            out.append(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        return out
+
+    def sync(self):
+        """order the consumer (current stream / host) after every bucket exchange started so far"""
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+
+    def finish(self):
+        from . import autograd
+        if autograd.ACTIVE_REDUCER is self:
+            autograd.ACTIVE_REDUCER = None
+        self._armed = False
+        self.sync()
+        self._reduce_from_grad([i for i in range(len(self.buckets)) if i not in self._done])
+        self._done = set()
+
+    # -- plain form ------------------------------------------------------------------------------------
     def reduce(self):
-        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+        self._reduce_from_grad(range(len(self.buckets)))
+
+    def _reduce_from_grad(self, which):
+        if not self._active():
             return
         work = []
-        for ps in self.buckets:
+        for i in which:
+            ps = self.buckets[i]
             gs = [p.grad if p.grad is not None else torch.zeros_like(p) for p in ps]
             flat = torch.cat([g.reshape(-1) for g in gs])
             if self.stream is not None:
+                flat.record_stream(self.stream)
                 self.stream.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(self.stream):
                     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-                work.append((flat, ps, gs))
             else:
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-                work.append((flat, ps, gs))
+            work.append((flat, ps, gs))
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
         for flat, ps, gs in work:
@@ -95,6 +167,8 @@ class GradAllReducer:
 
 
 def global_graph_count(nb_local: int, device) -> int:
+    """number of graphs over all ranks; a loader that knows its global batch size passes it to train_step instead
+    (this form costs one tiny collective and a host sync per step)"""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return nb_local
     t = torch.tensor([nb_local], device=device, dtype=torch.long)
@@ -103,15 +177,17 @@ def global_graph_count(nb_local: int, device) -> int:
 
 
 def train_step(nn_dict, data, params, diffusion_process, optimizer, reducer: Optional[GradAllReducer] = None,
-               times=None):
+               times=None, num_graphs: Optional[int] = None, num_graphs_global: Optional[int] = None):
     """One iteration of train_epoch's loop body (:122-179) for an already collated batch ``data`` with
     .pos [N,3], .x [N,A], .edge_index, .batch and optionally .spectrum / .exO.  Under data parallelism
     every rank passes its own shard; gradients are summed and the loss is divided by the global graph
-    count, which equals the single-process loss on the concatenated batch."""
+    count, which equals the single-process loss on the concatenated batch.  ``num_graphs`` /
+    ``num_graphs_global`` (known to the loader) make the step free of host syncs."""
     egnn = nn_dict["egnn"]
     dev = data.pos.device
     optimizer.zero_grad()
-    noised = diffuse_as_batch(data.pos, data.x, data.batch, diffusion_process, times=times)
+    nb = int(data.batch.max().item()) + 1 if num_graphs is None else int(num_graphs)
+    noised = diffuse_as_batch(data.pos, data.x, data.batch, diffusion_process, times=times, num_graphs=nb)
     cols = []
     if params["conditional"]:
         spec = data.spectrum.to(dev).float()
@@ -121,12 +197,14 @@ def train_step(nn_dict, data, params, diffusion_process, optimizer, reducer: Opt
     if params["give_exO"]:
         cols.append(data.exO.to(dev).float())
     cond = torch.cat(cols, dim=1) if cols else None
-    nb = int(data.batch.max().item()) + 1
+    nglob = global_graph_count(nb, dev) if num_graphs_global is None else int(num_graphs_global)
+    if reducer is not None:
+        reducer.arm()
     loss, _, _ = training_loss(egnn, data.edge_index, data.batch, noised, cond, params["atom_type_size"],
-                               num_graph_global=global_graph_count(nb, dev))
+                               num_graph_global=nglob, num_graphs=nb)
     loss.backward()
     if reducer is not None:
-        reducer.reduce()
+        reducer.finish()
     optimizer.step()
     return loss.detach()
 

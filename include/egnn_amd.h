@@ -216,8 +216,9 @@ int egnn_radius_graph_fill(void* stream, int N, const float* d_x, const int32_t*
 
 /* ---- evaluation statistics -------------------------------------------------------
  * RDF(position, sigma, R, dR, Normalize) about atom 0 of every graph (evaluate_RDF.py:39-60), out
- * float[B, nbins], nbins = number of entries of np.arange(dR, R + dR, dR). */
-int egnn_rdf(void* stream, int B, const float* d_pos, const int32_t* d_graph_ptr, float R, float dR, float sigma,
+ * float[B, nbins], nbins = number of entries of np.arange(dR, R + dR, dR).  R and dR are doubles: the bin edges are
+ * numpy's float64 values (rounded to float32 only inside the reference's `r < d < r + dR` comparison). */
+int egnn_rdf(void* stream, int B, const float* d_pos, const int32_t* d_graph_ptr, double R, double dR, float sigma,
              int normalize, int nbins, float* d_out);
 /* Si-O-Si selection + CN2 angle / bond lengths (evaluate_Si-O-Si.py:23-53, CN2_evaluate.py:12-21):
  * out float[B,4] = {valid, angle in degrees, |r1-r0|, |r2-r0|}; onehot int32 [N, A], Si = [0,1]. */

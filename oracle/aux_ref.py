@@ -2,8 +2,9 @@
 
 * GammaNetwork / PositiveLinear : /root/reference/SNR.py:5-64
 * SpectrumCompressor            : /root/reference/DataPreprocessor.py:4-22
-* RDF about atom 0              : /root/reference/evaluate_RDF.py:39-60
-* CN2 angle / bond / r2score    : /root/reference/CN2_evaluate.py:12-37
+* RDF about atom 0 + metrics    : /root/reference/evaluate_RDF.py:13-83   (pinned by execution: stats_golden.npz)
+* CN2 angle / bond / r2score    : /root/reference/CN2_evaluate.py:12-37 (= evaluate_by_angle_for_2_atoms_graph.py:6-16,
+                                  evaluate_RDF.py:65-79; pinned by execution: stats_golden.npz)
 * Si-O-Si selection rule        : /root/reference/evaluate_Si-O-Si.py:23-41
 """
 from __future__ import annotations
@@ -87,12 +88,15 @@ def gaussian_filter1d_reflect(a: np.ndarray, sigma: float, truncate: float = 4.0
 def rdf_about_atom0(position: torch.Tensor, sigma=5, R=5.0, dR=0.01, normalize=False) -> np.ndarray:
     """evaluate_RDF.py:39-60: histogram of |r_i - r_0| (i>=1) over bins (r, r+dR), r = dR..R,
     divided by 4*pi*rho*r^2*dR with rho = N/(4/3*pi*R^3), then Gaussian-smoothed (sigma bins)."""
-    pos = position.detach().cpu().double()
-    d = torch.norm(pos[1:] - pos[0], dim=1).numpy()
+    pos = position.detach().cpu().float()
+    # length_from_exO (:39-45): a float32 torch.norm per atom; `r < d < r+dR` (:57) then compares that 0-dim float32
+    # tensor with Python floats, i.e. with the float64 bin edges ROUNDED TO float32 (an atom exactly on a float32
+    # edge is counted in no bin) -- pinned by tests/golden/stats_golden.npz (tri* cases)
+    d = np.array([float(torch.norm(pos[i] - pos[0])) for i in range(1, pos.shape[0])], dtype=np.float32)
     num_atom = pos.shape[0]
     ro = num_atom / (4.0 / 3.0 * np.pi * R ** 3)
     rs = np.arange(0 + dR, R + dR, dR)
-    rdf = np.array([np.sum((r < d) & (d < r + dR)) / (4 * np.pi * ro * r ** 2 * dR) for r in rs])
+    rdf = np.array([np.sum((np.float32(r) < d) & (d < np.float32(r + dR))) / (4 * np.pi * ro * r ** 2 * dR) for r in rs])
     sm = gaussian_filter1d_reflect(rdf, sigma)
     if normalize:
         sm = sm / np.max(sm)
@@ -105,8 +109,24 @@ def cos_similarity(a, b):
 
 
 def rdf_mse(a, b):
-    """evaluate_RDF.py:37."""
+    """evaluate_RDF.py:26-37."""
     return float(np.mean((np.asarray(a) - np.asarray(b)) ** 2))
+
+
+def rdf_l2(a, b):
+    """euclidean_distance, evaluate_RDF.py:82-83."""
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)))
+
+
+def wasserstein(a, b):
+    """calculate_wasserstein_distance (evaluate_RDF.py:13-24) -> scipy.stats.wasserstein_distance(u_values, v_values)
+    (third-party: scipy, unpinned by the reference; scipy 1.15.3 here).  Published algorithm (scipy _cdf_distance, p=1):
+    sort all values, W1 = sum |U_cdf - V_cdf| * diff(all_values) with right-continuous empirical CDFs."""
+    u, v = np.sort(np.asarray(a, dtype=np.float64).ravel()), np.sort(np.asarray(b, dtype=np.float64).ravel())
+    allv = np.sort(np.concatenate((u, v)))
+    ucdf = np.searchsorted(u, allv[:-1], side="right") / u.size
+    vcdf = np.searchsorted(v, allv[:-1], side="right") / v.size
+    return float(np.sum(np.abs(ucdf - vcdf) * np.diff(allv)))
 
 
 # ---------------- CN2_evaluate.py / evaluate_Si-O-Si.py ----------------

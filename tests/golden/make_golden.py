@@ -8,6 +8,12 @@ Run only where /root/reference exists (it does not travel to the GPU box):
 What is executed:
   * diffusion_x_h, E3diffusion_new, E3diffusion, SNR, DataPreprocessor are imported as they are
     (torch only).
+  * evaluate_by_angle_for_2_atoms_graph.py (calculate_angle_for_CN2 / calculate_bond_length_for_CN2, the same
+    functions as CN2_evaluate.py:12-21) is imported as it is (torch, numpy, matplotlib).
+  * evaluate_RDF.py (RDF, cos_similarity, mean_squared_error, calculate_wasserstein_distance, euclidean_distance,
+    r2score, :13-83) has `import wandb` at top level (the logging service client: absent, unused by these
+    functions; the file's driver body is under __main__).  An EMPTY module object is registered under that name so
+    the import statement succeeds; nothing of wandb is imitated or called.
   * EquivariantGraphNeuralNetwork.py needs torch_geometric.nn.MessagePassing, which is not
     installed and cannot be fetched.  A ~25-line stand-in implementing PyG's documented
     gather/scatter contract (``_i`` <- edge_index[0] and ``_j`` <- edge_index[1] for
@@ -234,6 +240,55 @@ def run_aux_cases(SNR, DP):
     return out
 
 
+def stats_geometries():
+    """hand geometries + seeded clouds (first three atoms double as a CN2 triple: centre, neighbour, neighbour)"""
+    import math
+    geos = {}
+    for ang in (180.0, 90.0, 144.0, 109.47):
+        a = math.radians(ang)
+        geos[f"tri{int(ang)}"] = torch.tensor([[0.0, 0, 0], [1.62, 0, 0], [1.6 * math.cos(a), 1.6 * math.sin(a), 0]])
+    g = torch.Generator().manual_seed(2718)
+    grid = torch.stack(torch.meshgrid(*[torch.arange(4, dtype=torch.float32)] * 3, indexing="ij"), -1).reshape(-1, 3) * 1.6
+    geos["cell64"] = grid + 0.1 * torch.randn(64, 3, generator=g)                 # SiO2-like 64-atom cell (SURVEY 8(d))
+    geos["cell64b"] = grid + 0.25 * torch.randn(64, 3, generator=g)
+    geos["cloud64"] = torch.randn(64, 3, generator=g) * 2.0
+    geos["cloud20"] = torch.randn(20, 3, generator=g) * 1.5
+    geos["shell"] = torch.tensor([[0.0, 0, 0], [1.605, 0, 0], [0, 2.605, 0], [0, 0, 4.005], [0.004, 0, 0], [0, 4.996, 0]])
+    return geos
+
+
+def run_stats_cases(ER, EA):
+    out = {}
+    geos = stats_geometries()
+    out["names"] = np.array(list(geos))
+    rdfs = {}
+    for name, pos in geos.items():
+        out[f"{name}.pos"] = pos.numpy()
+        rdfs[name] = np.asarray(ER.RDF(pos))                                      # sigma=5, R=5.0, dR=0.01
+        out[f"{name}.rdf"] = rdfs[name]
+        out[f"{name}.rdf_norm"] = np.asarray(ER.RDF(pos, Normalize=True))
+        out[f"{name}.rdf_s3_R4_d02"] = np.asarray(ER.RDF(pos, sigma=3, R=4.0, dR=0.02))
+        out[f"{name}.angle"] = np.array(EA.calculate_angle_for_CN2(pos[:3]))
+        out[f"{name}.bonds"] = np.array(EA.calculate_bond_length_for_CN2(pos[:3]))
+    names = list(geos)
+    pairs = [(names[i], names[j]) for i in range(len(names)) for j in range(i + 1, len(names))]
+    out["pairs"] = np.array([f"{a}|{b}" for a, b in pairs])
+    out["pair.cos"] = np.array([ER.cos_similarity(rdfs[a], rdfs[b]) for a, b in pairs])
+    out["pair.mse"] = np.array([ER.mean_squared_error(rdfs[a], rdfs[b]) for a, b in pairs])
+    out["pair.l2"] = np.array([ER.euclidean_distance(rdfs[a], rdfs[b]) for a, b in pairs])
+    out["pair.wasserstein"] = np.array([ER.calculate_wasserstein_distance(rdfs[a], rdfs[b]) for a, b in pairs])
+    # unequal lengths (the general CDF form of scipy's wasserstein_distance)
+    out["w_uneq.a"], out["w_uneq.b"] = rdfs["cell64"][:137], rdfs["cloud20"][40:400]
+    out["w_uneq.out"] = np.array(ER.calculate_wasserstein_distance(out["w_uneq.a"], out["w_uneq.b"]))
+    g = np.random.default_rng(5)
+    for k in range(3):
+        a = g.normal(size=11 + 7 * k) * 30 + 120
+        b = 0.8 * a + g.normal(size=a.shape) * (3 + 4 * k) + 20
+        out[f"r2.a{k}"], out[f"r2.b{k}"] = a, b
+        out[f"r2.out{k}"] = np.array(ER.r2score(list(a), list(b)))
+    return out
+
+
 def main():
     assert os.path.isdir(REF), "reference not present: goldens can only be regenerated in the build container"
     _install_stub()
@@ -248,7 +303,12 @@ def main():
     np.savez_compressed(os.path.join(OUT, "egnn_golden.npz"), **run_egnn_cases(EG.EquivariantGNN))
     np.savez_compressed(os.path.join(OUT, "diffusion_golden.npz"), **run_diffusion_cases(dxh, dnew, dold))
     np.savez_compressed(os.path.join(OUT, "aux_golden.npz"), **run_aux_cases(SNR, DP))
-    for f in ("egnn_golden.npz", "diffusion_golden.npz", "aux_golden.npz"):
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    import evaluate_by_angle_for_2_atoms_graph as EA
+    sys.modules.setdefault("wandb", types.ModuleType("wandb"))    # empty: lets `import wandb` succeed, nothing else
+    import evaluate_RDF as ER
+    np.savez_compressed(os.path.join(OUT, "stats_golden.npz"), **run_stats_cases(ER, EA))
+    for f in ("egnn_golden.npz", "diffusion_golden.npz", "aux_golden.npz", "stats_golden.npz"):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 
 

@@ -218,10 +218,39 @@ def test_diffusion_steps_match_reference_golden(tag):
     assert max_rel(mu.cpu(), torch.from_numpy(G_DIFF[f"{tag}.mu3_xhat.t{t}"])) <= 1e-4
     got = xo.reverse_diffuse_one_step(mu, t, noise=torch.from_numpy(G_DIFF[f"{tag}.noise_xhat.t{t}"]).to(DEV))
     assert max_rel(got.cpu(), torch.from_numpy(G_DIFF[f"{tag}.rev_xhat.t{t}"])) <= 1e-4
-    # forward noising: statistics only (torch RNG on the device)
+    # forward noising with torch's RNG on the device: statistics only
     zt, noise = proc.diffuse_zero_to_t(z3, t, mode="pos")
     assert noise.mean(0).abs().max() < 1e-5
     assert max_rel(zt.cpu(), (proc.alpha(t) * z3.cpu() + proc.sigma(t) * noise.cpu())) <= 1e-5
+    # ... and with the reference's own recorded draw (goldens fwd_*: executed diffuse_zero_to_t, :51-59)
+    z2 = torch.from_numpy(G_DIFF[f"{tag}.z2"]).to(DEV)
+    for t in [int(v) for v in G_DIFF[f"{tag}.ts"]]:
+        for mode, z in (("pos", z3), ("h", z2)):
+            draw = torch.from_numpy(G_DIFF[f"{tag}.fwd_noise_{mode}.t{t}"]).to(DEV)
+            zt, used = proc.diffuse_zero_to_t(z, t, mode=mode, noise=draw)
+            assert max_rel(used.cpu(), torch.from_numpy(G_DIFF[f"{tag}.fwd_used_{mode}.t{t}"])) <= 1e-6, (mode, t)
+            assert max_rel(zt.cpu(), torch.from_numpy(G_DIFF[f"{tag}.fwd_{mode}.t{t}"])) <= 1e-5, (mode, t)
+
+
+def test_egnn_eps_matches_reference_callers():
+    """egnn_eps of the C ABI: eps_x = remove_mean(x_L - x_in [, batch]), eps_h = h_L[:, :A]
+    (parts/train_per_iretation.py:161-163, :367-369) against the oracle's remove_mean (pinned by the rm.* goldens)."""
+    from diffusion_model_amd import _lib
+    from oracle.diffusion_ref import remove_mean as rm_ref
+    g = torch.Generator().manual_seed(31)
+    sizes = [5, 1, 9, 300]
+    n, Hh, A = sum(sizes), 36, 2
+    h_out, x_out, x_in = torch.randn(n, Hh, generator=g), torch.randn(n, 3, generator=g), torch.randn(n, 3, generator=g)
+    bidx = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    ptr = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int32, device=DEV)
+    hd, xd, xi = h_out.to(DEV), x_out.to(DEV), x_in.to(DEV)
+    for per_graph in (True, False):
+        ex, eh = torch.empty(n, 3, device=DEV), torch.empty(n, A, device=DEV)
+        _lib.check(_lib.lib().egnn_eps(_lib.stream_ptr(), n, Hh, A, _lib.ptr(ptr) if per_graph else None, len(sizes),
+                                       _lib.ptr(hd), _lib.ptr(xd), _lib.ptr(xi), _lib.ptr(ex), _lib.ptr(eh)))
+        want = rm_ref((x_out - x_in).clone(), bidx) if per_graph else rm_ref((x_out - x_in).clone())
+        assert max_rel(ex.cpu(), want) <= 1e-5
+        assert torch.equal(eh.cpu(), h_out[:, :A])
 
 
 def test_remove_mean_matches_reference_golden():

@@ -130,6 +130,33 @@ def test_train_step_reduces_loss():
     assert all(p.grad is not None for p in nn_dict["spectrum_compressor"].parameters())
 
 
+@pytest.mark.gpu
+def test_learned_schedule_receives_gradient():
+    """noise_schedule='learned': alpha(t) / sigma(t) are differentiable in the reference (diffusion_x_h.py:36-46) and
+    the loss reaches gamma_0 / gamma_1 through pos_at_t / h_at_t (train_per_iretation.py:130-150; SURVEY Q7: only
+    these two ever train).  One train_step must leave a non-zero gradient on them and move them."""
+    from types import SimpleNamespace
+    H, A, T = 3, 2, 50
+    params = dict(conditional=False, to_compress_spectrum=False, give_exO=False, atom_type_size=A)
+    d = dims_for(H, 32, 64, 64, 64)
+    torch.manual_seed(1)
+    dev = "cuda"
+    nn_dict = {"egnn": dma.EquivariantGNN(2, **d).to(dev)}
+    nn_dict["egnn"].norm_scope = "graph"
+    pos0, x0, _, batch, ei, *_ = _problem(H=H)
+    data = SimpleNamespace(pos=pos0.to(dev), x=x0.to(dev), batch=batch.to(dev), edge_index=ei.to(dev))
+    proc = dma.E3DiffusionProcess(1e-5, 2.0, T, noise_schedule="learned").to(dev)
+    opt = torch.optim.SGD(list(nn_dict["egnn"].parameters()) + list(proc.parameters()), lr=1e-3)
+    g0, g1 = float(proc.gamma.gamma_0), float(proc.gamma.gamma_1)
+    a_before = float(proc.alpha(20))
+    loss = dma.train_step(nn_dict, data, params, proc, opt, times=[20, 5, 45], num_graphs=3, num_graphs_global=3)
+    assert torch.isfinite(loss)
+    assert proc.gamma.gamma_0.grad is not None and float(proc.gamma.gamma_0.grad.abs()) > 0
+    assert proc.gamma.gamma_1.grad is not None and float(proc.gamma.gamma_1.grad.abs()) > 0
+    assert (float(proc.gamma.gamma_0), float(proc.gamma.gamma_1)) != (g0, g1)
+    assert float(proc.alpha(20)) != a_before      # the tabulated schedule follows the updated parameters
+
+
 # ---------------- data-parallel exchange, gloo on CPU ----------------
 def _free_port():
     s = socket.socket()
@@ -139,23 +166,52 @@ def _free_port():
     return p
 
 
+def _rank_grads(params, rank):
+    g = torch.Generator().manual_seed(1234 + rank)
+    return [torch.randn(p.shape, generator=g) for p in params]
+
+
 def _ddp_worker(rank, world, port, out):
+    """GradAllReducer on the bucket structure of the real EquivariantGNN (one bucket per EGCL layer + one for the
+    spectrum compressor): per-rank gradients are injected in the order the backward produces them (last layer
+    first, through the overlapped layer_ready hook; the compressor through .grad), and every bucket must come back
+    as the sum over ranks."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(0)
-    model = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.SiLU(), torch.nn.Linear(7, 3))
-    g = torch.Generator().manual_seed(42)
-    x_all, y_all = torch.randn(8, 5, generator=g), torch.randn(8, 3, generator=g)      # 8 "graphs"
-    shard = slice(rank * 3, rank * 3 + 3) if rank == 0 else slice(3, 8)                   # uneven shards: 3 + 5
-    n_global = dma.training.global_graph_count(x_all[shard].shape[0], "cpu")
-    loss = ((model(x_all[shard]) - y_all[shard]) ** 2).sum() / n_global
-    loss.backward()
-    dma.GradAllReducer([model]).reduce()
+    d = dims_for(36, 16, 32, 32, 24)
+    net = dma.EquivariantGNN(3, **d)
+    comp = dma.SpectrumCompressor(200, [150, 100, 50], 32)
+    red = dma.GradAllReducer(list(net.egcl_list) + [comp])
+    assert len(red.buckets) == 4 and [len(b) for b in red.buckets[:3]] == [16, 16, 16]
+    n_global = dma.training.global_graph_count(3 if rank == 0 else 5, "cpu")      # uneven shards: 3 + 5 graphs
+    errs = []
+    for rep in range(2):       # two steps: buckets must not alias the previous step's gradients
+        red.arm()
+        got = {}
+        for layer in reversed(list(net.egcl_list)):
+            ps = red.buckets[red.bucket_of[id(layer)]]
+            views = red.layer_ready(layer, _rank_grads(ps, rank + 10 * rep))
+            for p_, v in zip(ps, views):
+                got[p_] = v
+        red.sync()
+        for p_, v in got.items():
+            p_.grad = v
+        for p_, g_ in zip(comp.parameters(), _rank_grads(list(comp.parameters()), rank + 10 * rep)):
+            p_.grad = g_
+        red.finish()
+        for m in list(net.egcl_list) + [comp]:
+            ps = [q for q in m.parameters()]
+            want = [a + b for a, b in zip(_rank_grads(ps, 0 + 10 * rep), _rank_grads(ps, 1 + 10 * rep))]
+            errs += [float((q.grad - w).abs().max()) for q, w in zip(ps, want)]
+    # the plain (un-overlapped) form on .grad
+    for p_, g_ in zip(net.parameters(), _rank_grads(list(net.parameters()), rank)):
+        p_.grad = g_
+    dma.GradAllReducer(list(net.egcl_list)).reduce()
+    ps = list(net.parameters())
+    want = [a + b for a, b in zip(_rank_grads(ps, 0), _rank_grads(ps, 1))]
+    errs += [float((q.grad - w).abs().max()) for q, w in zip(ps, want)]
     if rank == 0:
-        ref = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.SiLU(), torch.nn.Linear(7, 3))
-        ref.load_state_dict(model.state_dict())
-        (((ref(x_all) - y_all) ** 2).sum() / 8).backward()
-        errs = [float((a.grad - b.grad).abs().max()) for a, b in zip(model.parameters(), ref.parameters())]
         torch.save({"n_global": n_global, "errs": errs}, out)
     dist.barrier()
     dist.destroy_process_group()

@@ -1,0 +1,16 @@
+#!/bin/bash
+# one GPU-box visit: tests, the bench lines of every single-GPU BASELINE config, the 2-rank rehearsal
+set -o pipefail
+cd "$GRAFT_REPO_ROOT" || exit 1
+tag=${1:-r02a}
+mkdir -p gpurun_out/$tag
+python -m pytest tests -m gpu -x -q > gpurun_out/$tag/gpu_tests.log 2>&1; echo "pytest rc=$?" | tee -a gpurun_out/$tag/gpu_tests.log
+tail -3 gpurun_out/$tag/gpu_tests.log
+python bench.py > gpurun_out/$tag/bench_c2.json 2> gpurun_out/$tag/bench_c2.err; echo "c2 rc=$?"
+python bench.py --atoms 512 --batch 32 --steps 5 --warmup 2 --reps 3 --no-cpu-baseline > gpurun_out/$tag/bench_c3.json 2> gpurun_out/$tag/bench_c3.err; echo "c3 rc=$?"
+python bench.py --mode train --steps 10 --warmup 3 > gpurun_out/$tag/bench_train.json 2> gpurun_out/$tag/bench_train.err; echo "train rc=$?"
+BENCH_DEVICE=0 BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 5 --warmup 2 --reps 2 --train-steps 3 > gpurun_out/$tag/bench_2rank_gloo.json 2> gpurun_out/$tag/bench_2rank_gloo.err; echo "2rank rc=$?"
+tail -c 600 gpurun_out/$tag/bench_c2.json; echo
+tail -c 400 gpurun_out/$tag/bench_c3.json; echo
+tail -c 400 gpurun_out/$tag/bench_train.json; echo
+tail -c 400 gpurun_out/$tag/bench_2rank_gloo.json; tail -5 gpurun_out/$tag/bench_2rank_gloo.err
