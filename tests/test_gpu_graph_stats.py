@@ -75,6 +75,57 @@ def test_rdf_matches_oracle():
     assert abs(dma.stats.cos_similarity(out[0], out[0]) - 1.0) < 1e-12
 
 
+def test_statistics_match_executed_reference_goldens():
+    """device RDF (+ similarity metrics on device tensors) and the CN2 angle / bond kernels against stats_golden.npz
+    (outputs of the reference's own evaluate_RDF.py / evaluate_by_angle_for_2_atoms_graph.py functions)."""
+    from tests._util import load_golden
+    G = load_golden("stats_golden.npz")
+    names = [str(n) for n in G["names"]]
+    sizes = [G[f"{n}.pos"].shape[0] for n in names]
+    pos = torch.cat([torch.from_numpy(G[f"{n}.pos"]) for n in names]).to(DEV)
+    out = dma.stats.rdf(pos, sizes)                      # one launch over the batch of graphs
+    assert out.shape == (len(names), 500)
+    # float32 storage of values computed in fp64 like the reference: 1e-6 relative to the curve's maximum
+    for k, n in enumerate(names):
+        want = G[f"{n}.rdf"]
+        assert np.abs(out[k].cpu().numpy() - want).max() <= 1e-6 * max(1.0, np.abs(want).max()), n
+    out2 = dma.stats.rdf(pos, sizes, sigma=3, R=4.0, dR=0.02)
+    for k, n in enumerate(names):
+        want = G[f"{n}.rdf_s3_R4_d02"]
+        assert out2.shape[1] == want.shape[0]
+        assert np.abs(out2[k].cpu().numpy() - want).max() <= 1e-6 * max(1.0, np.abs(want).max()), n
+    off = 0
+    for k, n in enumerate(names):
+        wn = G[f"{n}.rdf_norm"]
+        if not np.isnan(wn).any():
+            one = dma.stats.rdf(pos[off:off + sizes[k]], Normalize=True).cpu().numpy()
+            assert np.abs(one - wn).max() <= 1e-6, n
+        off += sizes[k]
+    for k, pair in enumerate(str(p) for p in G["pairs"]):
+        ia, ib = (names.index(t) for t in pair.split("|"))
+        a, b = out[ia], out[ib]                          # device tensors
+        if not np.isnan(G["pair.cos"][k]):
+            assert abs(dma.stats.cos_similarity(a, b) - G["pair.cos"][k]) <= 1e-5, pair
+        assert abs(dma.stats.rdf_mse(a, b) - G["pair.mse"][k]) <= 1e-5 * max(1.0, G["pair.mse"][k]), pair
+        assert abs(dma.stats.rdf_l2(a, b) - G["pair.l2"][k]) <= 1e-5 * max(1.0, G["pair.l2"][k]), pair
+        assert abs(dma.stats.wasserstein(a, b) - G["pair.wasserstein"][k]) <= 1e-5 * max(1.0, G["pair.wasserstein"][k]), pair
+    assert abs(dma.stats.wasserstein(torch.from_numpy(G["w_uneq.a"]).to(DEV), torch.from_numpy(G["w_uneq.b"]).to(DEV))
+               - float(G["w_uneq.out"])) <= 1e-9
+    assert abs(dma.stats.wasserstein(G["w_uneq.a"], G["w_uneq.b"]) - float(G["w_uneq.out"])) <= 1e-12
+    for k in range(3):
+        assert abs(dma.stats.r2score(G[f"r2.a{k}"], G[f"r2.b{k}"]) - float(G[f"r2.out{k}"])) <= 1e-12
+    # CN2 angle / bond lengths: graphs [centre, Si, Si] built from the first three atoms of every geometry
+    tri = torch.cat([torch.from_numpy(G[f"{n}.pos"][:3]) for n in names]).to(DEV)
+    oh = torch.tensor([[1, 0], [0, 1], [0, 1]]).repeat(len(names), 1).to(DEV)
+    valid, ang, ln = dma.stats.si_o_si(tri, oh, [3] * len(names), cutoff=100.0)
+    for k, n in enumerate(names):
+        assert bool(valid[k])
+        # float32 acos: 2e-3 degrees away from the 180-degree singularity of acos, where one ulp of cos is 0.03 degrees
+        wa = float(G[f"{n}.angle"])
+        assert abs(float(ang[k]) - wa) <= (5e-2 if wa > 179.0 else 2e-3), (n, float(ang[k]), wa)
+        assert abs(float(ln[k]) - 0.5 * float(G[f"{n}.bonds"].sum())) <= 1e-6, n
+
+
 def test_si_o_si_matches_oracle():
     sizes, poss, ohs, want = [], [], [], []
     for ang in (180.0, 90.0, 144.0):

@@ -140,9 +140,45 @@ def test_gamma_and_compressor_match_reference():
     assert max_rel(outc, torch.from_numpy(G_AUX["comp.out"])) <= 1e-6
 
 
+def test_statistics_match_executed_reference():
+    """RDF / similarity metrics / CN2 angle + bond lengths / r2score restatements against tests/golden/stats_golden.npz,
+    which make_golden.py produced by EXECUTING evaluate_RDF.py:13-83 and evaluate_by_angle_for_2_atoms_graph.py:6-16."""
+    G = load_golden("stats_golden.npz")
+    names = [str(n) for n in G["names"]]
+    rdfs = {}
+    for n in names:
+        pos = torch.from_numpy(G[f"{n}.pos"])
+        rdfs[n] = aux_ref.rdf_about_atom0(pos)
+        want = G[f"{n}.rdf"]
+        assert rdfs[n].shape == want.shape == (500,)
+        assert np.abs(rdfs[n] - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), n
+        wn = G[f"{n}.rdf_norm"]
+        if np.isnan(wn).any():      # an all-zero RDF (atoms exactly on float32 bin edges): 0/0 in the reference too
+            assert np.abs(want).max() == 0.0 and np.abs(rdfs[n]).max() == 0.0
+        else:
+            assert np.abs(aux_ref.rdf_about_atom0(pos, normalize=True) - wn).max() <= 1e-12, n
+        w2 = G[f"{n}.rdf_s3_R4_d02"]
+        got2 = aux_ref.rdf_about_atom0(pos, sigma=3, R=4.0, dR=0.02)
+        assert got2.shape == w2.shape and np.abs(got2 - w2).max() <= 1e-12 * max(1.0, np.abs(w2).max()), n
+        assert abs(aux_ref.angle_cn2(pos[:3]) - float(G[f"{n}.angle"])) <= 1e-9, n
+        assert np.allclose(aux_ref.bond_lengths_cn2(pos[:3]), G[f"{n}.bonds"], rtol=0, atol=1e-12), n
+    for k, pair in enumerate(str(p) for p in G["pairs"]):
+        a, b = (rdfs[t] for t in pair.split("|"))
+        if np.isnan(G["pair.cos"][k]):
+            assert np.abs(a).max() == 0.0 or np.abs(b).max() == 0.0
+        else:
+            assert abs(aux_ref.cos_similarity(a, b) - G["pair.cos"][k]) <= 1e-12, pair
+        assert abs(aux_ref.rdf_mse(a, b) - G["pair.mse"][k]) <= 1e-12 * max(1.0, G["pair.mse"][k]), pair
+        assert abs(aux_ref.rdf_l2(a, b) - G["pair.l2"][k]) <= 1e-12 * max(1.0, G["pair.l2"][k]), pair
+        assert abs(aux_ref.wasserstein(a, b) - G["pair.wasserstein"][k]) <= 1e-12 * max(1.0, G["pair.wasserstein"][k]), pair
+    assert abs(aux_ref.wasserstein(G["w_uneq.a"], G["w_uneq.b"]) - float(G["w_uneq.out"])) <= 1e-12
+    for k in range(3):
+        assert abs(aux_ref.r2score(G[f"r2.a{k}"], G[f"r2.b{k}"]) - float(G[f"r2.out{k}"])) <= 1e-12
+
+
 def test_statistics_hand_geometries():
-    """G7: RDF / Si-O-Si restatements on hand-made geometries (parity unpinned by execution:
-    evaluate_RDF.py and CN2_evaluate.py import wandb at top level)."""
+    """RDF / Si-O-Si restatements on hand-made geometries.  (The Si-O-Si SELECTION loop lives under `__main__` of
+    evaluate_Si-O-Si.py:23-41 and cannot be executed by import: it stays pinned by these hand cases only.)"""
     for ang in (180.0, 90.0, 144.0):
         a = math.radians(ang)
         c = torch.tensor([[0.0, 0, 0], [1.62, 0, 0], [1.62 * math.cos(a), 1.62 * math.sin(a), 0]])
