@@ -328,6 +328,67 @@ def sample_leg(args, rk):
     return out, sd
 
 
+def slab_leg(args, rk, steps, warmup):
+    """BASELINE configs[4]: one 4096-atom slab (16x16x16 jittered grid, spacing 1.6 A), fixed radius graph with ~10
+    neighbours per atom (~40 k directed edges; the reference only has fully connected graphs), T = 1000 sampling.
+    N = 1: the device-resident sampler on the one graph (hipGraph replay).  N > 1: the graph's receiving nodes are
+    partitioned over the ranks (PartitionedSampler: per layer one all-reduce of the d^2 sum and one all-gather of the
+    updated rows, strong scaling -- total work fixed); the unpartitioned sampler is timed beside it on rank 0's GPU."""
+    import diffusion_model_amd as dma
+    dev, world, rank = rk.dev, rk.world, rk.rank
+    L, n = args.layers, 4096
+    g = torch.Generator().manual_seed(7)
+    grid = torch.stack(torch.meshgrid(*[torch.arange(16, dtype=torch.float32)] * 3, indexing="ij"), -1).reshape(-1, 3) * 1.6
+    x0 = (grid + 0.1 * torch.randn(n, 3, generator=g)).to(dev)
+    d = torch.cdist(x0, x0)
+    d.fill_diagonal_(float("inf"))
+    radius = float(torch.kthvalue(d.reshape(-1), 10 * n).values) + 1e-6      # the 40,960 closest ordered pairs
+    i, j = (d < radius).nonzero(as_tuple=True)
+    ei = torch.stack((i, j))
+    del d
+    net = build_net(dma, L, 64).to(dev).eval()
+    net.precision = args.precision
+    proc = dma.E3DiffusionProcess(1e-5, 2.0, T)
+    cond = synthetic_cond(1, n, H - A - 1, seed=3)
+    out = {"metric": "atoms*denoise-steps/sec, 4096-atom slab, radius graph", "unit": "atoms*denoise-steps/s",
+           "atoms": n, "directed_edges": int(ei.shape[1]), "radius": radius, "steps": steps, "warmup": warmup,
+           "scaling": "strong" if world > 1 else None}
+
+    def time_single():
+        smp = dma.DeviceSampler(net, proc, [n], cond, atom_type_size=A, seed=0, norm_scope="graph", device=dev, edge_index=ei)
+        smp.init()
+        smp.run(nsteps=warmup, use_graph=True)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        smp.run(nsteps=steps, use_graph=True, sync=True)
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        bad = int(smp.state()[2].sum())
+        del smp
+        return el, bad
+
+    if world == 1:
+        el, bad = time_single()
+        out.update({"value": n * steps / el, "ms_per_step": el * 1e3 / steps, "nonfinite_graphs": bad,
+                    "implementation": "DeviceSampler on one GPU, hipGraph replay"})
+        return out
+    single_ms = None
+    if rank == 0:
+        el1, _ = time_single()
+        single_ms = el1 * 1e3 / steps
+    smp = dma.PartitionedSampler(net, proc, [n], cond, ei, rank, world, atom_type_size=A, seed=0, norm_scope="graph", device=dev)
+    smp.init()
+    smp.run(nsteps=warmup)
+    el = rk.timed(lambda: smp.run(nsteps=steps))
+    out.update({"value": n * steps / el, "ms_per_step": el * 1e3 / steps, "nonfinite_graphs": int(smp.bad.sum()),
+                "implementation": f"PartitionedSampler, receiving nodes over {world} ranks, 2 collectives per layer "
+                                  f"({rk.backend})", "local_edges_rank0": smp.plan.E,
+                "single_gpu_ms_per_step": single_ms,
+                "note": "at 40 k edges one GPU runs a step in about the time of the 2 x L latency-bound collectives a "
+                        "partitioned step adds; the partition pays for graphs two orders of magnitude larger"})
+    return out
+
+
 def self_launch(args):
     """`python bench.py --gpus N` from a plain shell: start the N ranks as a child torch.distributed.run (nothing in
     this process has touched the GPU; the child is a new process, not an exec of this one)."""
@@ -351,11 +412,12 @@ def main():
     ap.add_argument("--atoms", type=int, default=64)
     ap.add_argument("--layers", type=int, default=4)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--mode", default="sample", choices=["sample", "train"],
+    ap.add_argument("--mode", default="sample", choices=["sample", "train", "slab"],
                     help="sample = headline metric (default, with the ddp_train sub-record); train = BASELINE configs[3] "
-                         "shape only (fwd+bwd+all-reduce+Adam) as the headline of the line")
+                         "shape only (fwd+bwd+all-reduce+Adam) as the headline of the line; slab = BASELINE configs[4] only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-leg", action="store_true")
+    ap.add_argument("--no-slab-leg", action="store_true")
     ap.add_argument("--train-steps", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -375,6 +437,13 @@ def main():
                                            f"{tr['step']}", "global_batch": rk.world * args.batch,
                                "parallelism": f"dp{rk.world}"}})
         valid = tr["finite"]
+    elif args.mode == "slab":
+        out = slab_leg(args, rk, args.steps, args.warmup)
+        out.update({"n_gpus": rk.world, "higher_is_better": True, "vs_baseline": None, "dtype": args.precision,
+                    "data": "synthetic", "config": {"workload": "4096-atom slab, radius graph ~40k directed edges, "
+                                                                f"{args.layers}-layer EGNN, T=1000 reverse steps",
+                                                    "parallelism": f"node-partitioned x{rk.world}"}})
+        valid = out["nonfinite_graphs"] == 0
     else:
         out, sd = sample_leg(args, rk)
         valid = out["nonfinite_graphs"] == 0
@@ -383,6 +452,10 @@ def main():
                 tr = train_leg(args, rk, args.train_steps, 2, 256)
                 out["ddp_train"] = tr
                 valid = valid and tr["finite"]
+        if not args.no_slab_leg and args.atoms == 64:
+            sl = slab_leg(args, rk, 50, 10)
+            out["slab_4096"] = sl
+            valid = valid and sl["nonfinite_graphs"] == 0
         if rk.world == 1 and rk.rank == 0 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, args.atoms, args.cpu_seconds)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

@@ -6,6 +6,7 @@ from .egnn import EGCL, EquivariantGNN  # noqa: F401
 from .diffusion import E3DiffusionProcess, remove_mean  # noqa: F401
 from .graph import GraphPlan, fully_connected_edge_index, fully_connected_plan, plan_edge_index, radius_plan  # noqa: F401
 from . import partition, stats  # noqa: F401
+from .partition import PartitionedSampler  # noqa: F401
 from .optim import RAdamScheduleFree, define_optimizer  # noqa: F401
 from .sampler import DeviceSampler, generate  # noqa: F401
 from .preprocessor import SpectrumCompressor  # noqa: F401

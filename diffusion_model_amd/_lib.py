@@ -43,6 +43,9 @@ SIGNATURES = {
     "egnn_sampler_run": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "egnn_sampler_final": (_i, [_vp, _vp, _i, _i] + [_vp] * 5),
     "egnn_sampler_state": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(_i)]),
+    "ddpm_sampler_init": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _u64] + [_vp] * 6),
+    "ddpm_sampler_step": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _f, _u64] + [_vp] * 7),
+    "ddpm_sampler_final": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _u64] + [_vp] * 10),
     "egnn_fc_graph_build": (_i, [_vp, _i, _i] + [_vp] * 6),
     "egnn_radius_graph_count": (_i, [_vp, _i, _vp, _vp, _vp, _f, _vp]),
     "egnn_radius_graph_fill": (_i, [_vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp]),

@@ -116,8 +116,9 @@ struct StepParams {
   uint64_t seed;
   const int* graph_ptr;
   const float* table;   // [(T+1)][4]
-  const int* t_dev;     // current t
+  const int* t_dev;     // current t (device-resident loop); null -> t_imm (caller-driven loop)
   const int* t0_dev;    // t at the start of the run (indexes explicit noise)
+  int t_imm;
   const float* noise_pos;  // [steps][N][3] or null
   const float* noise_h;    // [steps][N][A] or null
   const float* h_out;   // EGNN outputs
@@ -134,11 +135,11 @@ constexpr int kMaxA = 8;
 __global__ __launch_bounds__(kThreads) void sampler_step_kernel(const StepParams p) {
   __shared__ float red[3 * kThreads];
   const int g = blockIdx.x, lo = p.graph_ptr[g], hi = p.graph_ptr[g + 1], cnt = hi - lo;
-  const int t = *p.t_dev;
+  const int t = p.t_dev ? *p.t_dev : p.t_imm;
   if (t < 1) return;
   const float c0 = p.table[4 * t], c1 = p.table[4 * t + 1], c2 = p.table[4 * t + 2];
   const float tnext = p.table[4 * (t - 1) + 3];
-  const size_t nstep = (size_t)(*p.t0_dev - t);
+  const size_t nstep = p.t_dev ? (size_t)(*p.t0_dev - t) : 0;
   // pass 1: means of (x_out - pos) and of the position noise
   float e[3] = {0.f, 0.f, 0.f}, m[3] = {0.f, 0.f, 0.f};
   for (int n = lo + threadIdx.x; n < hi; n += kThreads) {
@@ -274,7 +275,7 @@ static StepParams make_params(egnn_ctx* c) {
   p.N = c->N; p.H = c->H; p.A = s.A; p.T = s.T; p.scale = s.onehot_scale; p.seed = s.seed;
   p.graph_ptr = c->graph_ptr; p.table = s.d_table; p.t_dev = s.t_dev; p.t0_dev = s.t_dev + 1;
   p.noise_pos = nullptr; p.noise_h = nullptr; p.h_out = s.h_out; p.x_out = s.x_out; p.pos = s.pos; p.h = s.h;
-  p.bad = s.bad;
+  p.bad = s.bad; p.t_imm = 0;
   return p;
 }
 
@@ -349,6 +350,61 @@ int ddpm_reverse_step(void* stream, int N, int D, int mode_pos, const int32_t* g
   const int pg = graph_ptr != nullptr;
   hipLaunchKernelGGL(reverse_step_kernel, dim3(pg ? B : 1), dim3(kThreads), 0, reinterpret_cast<hipStream_t>(stream), D,
                      mode_pos, pg, c0, c1, c2, z, ldz, eps, noise, z_out, ldo, graph_ptr, N);
+  EGNN_HIP(hipGetLastError());
+  return EGNN_OK;
+}
+
+// ---- the sampler's three fused kernels on CALLER-owned state (node-partitioned graphs: the EGNN forward between two
+// steps is run stage by stage with collectives in between, so the loop is driven by the caller) ----
+static int ext_params(StepParams& p, int N, int H, int A, int B, int T, const int32_t* graph_ptr, const float* table,
+                      float scale, uint64_t seed, float* pos, float* h, int32_t* bad) {
+  if (N < 1 || B < 1 || T < 1 || A < 1 || A > kMaxA || A + 1 > H || !graph_ptr || !table || !pos || !h || !bad) {
+    set_error("bad ddpm_sampler_* arguments (N=%d B=%d T=%d A=%d H=%d)", N, B, T, A, H);
+    return EGNN_EINVAL;
+  }
+  p.N = N; p.H = H; p.A = A; p.T = T; p.scale = scale; p.seed = seed; p.graph_ptr = graph_ptr; p.table = table;
+  p.t_dev = nullptr; p.t0_dev = nullptr; p.t_imm = 0; p.noise_pos = nullptr; p.noise_h = nullptr;
+  p.h_out = nullptr; p.x_out = nullptr; p.pos = pos; p.h = h; p.bad = bad;
+  return EGNN_OK;
+}
+
+int ddpm_sampler_init(void* stream, int N, int H, int A, int B, int T, const int32_t* graph_ptr, const float* table,
+                      float onehot_scale, uint64_t seed, const float* cond, const float* pos_init, const float* x_init,
+                      float* pos, float* h, int32_t* bad) {
+  StepParams p;
+  int rc = ext_params(p, N, H, A, B, T, graph_ptr, table, onehot_scale, seed, pos, h, bad);
+  if (rc) return rc;
+  if (H - A - 1 > 0 && !cond) { set_error("conditioning block missing"); return EGNN_EINVAL; }
+  hipLaunchKernelGGL(sampler_init_kernel, dim3(B), dim3(kThreads), 0, reinterpret_cast<hipStream_t>(stream), p, cond, pos_init,
+                     x_init);
+  EGNN_HIP(hipGetLastError());
+  return EGNN_OK;
+}
+
+int ddpm_sampler_step(void* stream, int N, int H, int A, int B, int T, int t, const int32_t* graph_ptr, const float* table,
+                      float onehot_scale, uint64_t seed, const float* h_out, const float* x_out, const float* noise_pos,
+                      const float* noise_h, float* pos, float* h, int32_t* bad) {
+  StepParams p;
+  int rc = ext_params(p, N, H, A, B, T, graph_ptr, table, onehot_scale, seed, pos, h, bad);
+  if (rc) return rc;
+  if (t < 1 || t > T || !h_out || !x_out) { set_error("bad ddpm_sampler_step arguments (t=%d)", t); return EGNN_EINVAL; }
+  p.t_imm = t; p.h_out = h_out; p.x_out = x_out; p.noise_pos = noise_pos; p.noise_h = noise_h;
+  hipLaunchKernelGGL(sampler_step_kernel, dim3(B), dim3(kThreads), 0, reinterpret_cast<hipStream_t>(stream), p);
+  EGNN_HIP(hipGetLastError());
+  return EGNN_OK;
+}
+
+int ddpm_sampler_final(void* stream, int N, int H, int A, int B, int T, const int32_t* graph_ptr, const float* table,
+                       float onehot_scale, uint64_t seed, const float* h_out, const float* x_out, const float* noise_pos,
+                       const float* noise_h, float* pos, float* h, int32_t* bad, float* pos_out, float* hc_out,
+                       int32_t* onehot_out) {
+  StepParams p;
+  int rc = ext_params(p, N, H, A, B, T, graph_ptr, table, onehot_scale, seed, pos, h, bad);
+  if (rc) return rc;
+  if (!h_out || !x_out || !pos_out || !hc_out || !onehot_out) { set_error("bad ddpm_sampler_final arguments"); return EGNN_EINVAL; }
+  p.h_out = h_out; p.x_out = x_out;
+  hipLaunchKernelGGL(sampler_final_kernel, dim3(B), dim3(kThreads), 0, reinterpret_cast<hipStream_t>(stream), p, noise_pos,
+                     noise_h, pos_out, hc_out, onehot_out);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }

@@ -199,6 +199,23 @@ int egnn_sampler_final(egnn_ctx* ctx, void* stream, int prec, int norm_scope,
 int egnn_sampler_state(egnn_ctx* ctx, void* stream, float* d_pos, float* d_x_types,
                        int32_t* d_bad_flags, int* t_host);
 
+/* The same three fused kernels (x_T/h_T draw, one reverse step :366-373, t = 0 decode :412-428) on CALLER-owned state,
+ * for the sampler of ONE LARGE GRAPH whose receiving nodes are partitioned over ranks (BASELINE configs[4]): between
+ * two steps the EGNN forward runs stage-wise (egcl_forward_begin / _end) with collectives in between, so the loop is
+ * driven by the caller and every rank applies the step to its replicated copy of the state (Philox noise is keyed by
+ * (seed, step, GLOBAL node id): identical on every rank).  pos [N,3] and h [N,H] = [s*x_types | cond | t/T] are updated
+ * in place; bad int32[B] is the sticky non-finite flag; d_noise_* (this step's draws, [N,3] / [N,A]) may be NULL. */
+int ddpm_sampler_init(void* stream, int N, int H, int A, int B, int T, const int32_t* d_graph_ptr, const float* d_table,
+                      float onehot_scale, uint64_t seed, const float* d_cond, const float* d_pos_init,
+                      const float* d_x_init, float* d_pos, float* d_h, int32_t* d_bad);
+int ddpm_sampler_step(void* stream, int N, int H, int A, int B, int T, int t, const int32_t* d_graph_ptr,
+                      const float* d_table, float onehot_scale, uint64_t seed, const float* d_h_out, const float* d_x_out,
+                      const float* d_noise_pos, const float* d_noise_h, float* d_pos, float* d_h, int32_t* d_bad);
+int ddpm_sampler_final(void* stream, int N, int H, int A, int B, int T, const int32_t* d_graph_ptr, const float* d_table,
+                       float onehot_scale, uint64_t seed, const float* d_h_out, const float* d_x_out,
+                       const float* d_noise_pos, const float* d_noise_h, float* d_pos, float* d_h, int32_t* d_bad,
+                       float* d_pos_out, float* d_hc_out, int32_t* d_onehot_out);
+
 /* ---- graph construction ----------------------------------------------------------
  * Fully connected graphs in the edge kernels' CSR layout: node i receives from every j != i of its graph,
  * j ascending -- the edge set and order of parts/train_per_iretation.py:308-313 /

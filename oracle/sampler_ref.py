@@ -29,17 +29,19 @@ def assemble_h(x_types, cond, t_frac, onehot_scale=1.0):
 
 def sample_one_graph(sd, diff: DiffusionRef, num_atoms: int, cond: Optional[torch.Tensor],
                      noise_fn: Callable, atom_type_size=2, onehot_scale=1.0,
-                     n_steps: Optional[int] = None, return_traj=False):
+                     n_steps: Optional[int] = None, return_traj=False, edge_index: Optional[torch.Tensor] = None):
     """One pass of the while-body of generate() (:301-428) for a single graph.
 
     Returns (pos [N,3], h_cont [N,A] before argmax, onehot [N,A], finite flag).
     ``n_steps`` limits the number of reverse steps taken from t=T (testing aid);
-    the final decode is applied only when the loop ran down to t=1.
+    the final decode is applied only when the loop ran down to t=1.  ``edge_index`` replaces the reference's
+    fully connected edge list (:308-313) for the radius-graph configuration (BASELINE configs[4], not a reference
+    feature); everything else is unchanged.
     """
     T = diff.num_diffusion_timestep
     pos = remove_mean(noise_fn("init_pos", T + 1, (num_atoms, 3)))
     x = noise_fn("init_h", T + 1, (num_atoms, atom_type_size))
-    ei = fully_connected_edge_index(num_atoms)
+    ei = fully_connected_edge_index(num_atoms) if edge_index is None else edge_index
     traj = []
     last_t = 1 if n_steps is None else max(1, T - n_steps + 1)
     for t in range(T, last_t - 1, -1):

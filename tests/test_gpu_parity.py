@@ -197,6 +197,56 @@ def test_full_size_c2_properties(precision, tol):
         assert rel_err(x0[sl].cpu() - x[sl], xo - x[sl]) <= tol
 
 
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16", 6e-2)])
+def test_full_size_c3_properties(precision, tol):
+    """BASELINE configs[2] size at FULL width (32 graphs x 512 atoms, E = 8,372,224, L=4, widths 1024/256: the
+    edge_kernel_bf16_v3<2,false> / <1,true> kernels on degree-511 rows, 4 tiles per receiving node): E(3)
+    equivariance, graph-permutation equivariance, run-to-run bitwise determinism, and one whole 512-atom graph
+    against the oracle (261,632 edges x 4 layers on the CPU)."""
+    B, n = 32, 512
+    d = dims_for(36, 256, 1024, 1024, 1024)
+    torch.manual_seed(2024)
+    net = dma.EquivariantGNN(4, **d)
+    with torch.no_grad():      # 8x more messages per node than the 64-atom cell: keep the untrained stack in range
+        for layer in net.egcl_list:
+            layer.mlp_m[2].weight.mul_(64.0 / n)
+            layer.mlp_m[2].bias.mul_(64.0 / n)
+    net.to(DEV).eval()
+    net.precision, net.norm_scope = precision, "graph"
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(1234)
+    grid = torch.stack(torch.meshgrid(*[torch.arange(8, dtype=torch.float32)] * 3, indexing="ij"), -1).reshape(-1, 3) * 1.6
+    x = grid.repeat(B, 1) + 0.1 * torch.randn(B * n, 3, generator=g)
+    x = x - x.view(B, n, 3).mean(1, keepdim=True).expand(B, n, 3).reshape(-1, 3)
+    h = torch.randn(B * n, 36, generator=g)
+    h[:, 35] = 0.5
+    plan = dma.fully_connected_plan([n] * B, DEV)
+    assert plan.E == 8372224
+    ei, batch = dma.plan_edge_index(plan), plan.batch
+    with torch.no_grad():
+        h0, x0 = net(ei, h.to(DEV), x.to(DEV), batch=batch)
+        h0b, x0b = net(ei, h.to(DEV), x.to(DEV), batch=batch)
+        R, tvec = _rot(6), torch.tensor([-0.3, 0.9, 0.4])
+        h1, x1 = net(ei, h.to(DEV), (x @ R.T + tvec).to(DEV), batch=batch)
+    assert torch.isfinite(h0).all() and torch.isfinite(x0).all()
+    assert torch.equal(h0, h0b) and torch.equal(x0, x0b)
+    etol = 1e-4 if precision == "fp32" else tol
+    assert rel_err(h1.cpu(), h0.cpu()) <= etol
+    assert rel_err((x1.cpu() - (x @ R.T + tvec)), (x0.cpu() - x) @ R.T) <= etol
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(4))
+    idx = (perm.repeat_interleave(n) * n + torch.arange(n).repeat(B))
+    with torch.no_grad():
+        h2, x2 = net(ei, h[idx].to(DEV), x[idx].to(DEV), batch=batch)
+    # every 512-atom graph starts on a tile boundary (261,632 = 2044 x 128), so a permutation of graphs is exact
+    ptol = 1e-5 if precision == "fp32" else 5e-3
+    assert rel_err(h2.cpu(), h0.cpu()[idx]) <= ptol and rel_err(x2.cpu(), x0.cpu()[idx]) <= ptol
+    gidx = 17
+    sl = slice(gidx * n, (gidx + 1) * n)
+    ho, xo = egnn_ref.egnn_forward(sd, egnn_ref.fully_connected_edge_index(n), h[sl], x[sl])
+    assert rel_err(h0[sl].cpu(), ho) <= tol
+    assert rel_err(x0[sl].cpu() - x[sl], xo - x[sl]) <= tol
+
+
 @pytest.mark.parametrize("tag", ["T1000", "T50", "T200"])
 def test_diffusion_steps_match_reference_golden(tag):
     T, p, s = G_DIFF[f"{tag}.params"]

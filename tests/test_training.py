@@ -106,6 +106,51 @@ def test_gradients_match_oracle_autograd(norm_scope, widths, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_gradients_full_width_64_atom_graphs():
+    """BASELINE configs[3] shape per graph: 64-atom fully connected graphs at the reference widths (W = 1024, m = 256,
+    H = 36), three graphs = 12,096 edges in backward chunks of 5,000 (so a layer spans several chunks): fp32 gradients
+    against the oracle's autograd at 2e-3, bf16-mode gradients against the fp32 ones at 8e-2."""
+    from diffusion_model_amd import autograd as _ag
+    H, A, T = 36, 2, 50
+    d = dims_for(H, 256, 1024, 1024, 1024)
+    torch.manual_seed(6)
+    net = dma.EquivariantGNN(2, **d)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    sizes = (64, 64, 64)
+    pos0, x0, cond, batch, ei, npos, nh, times = _problem(seed=2, sizes=sizes)
+    pos0 = pos0 * 2.0
+    ref = DiffusionRef(1e-5, 2.0, T)
+    ptr = torch.tensor([0, 64, 128, 192])
+    loss_ref, ex_ref, eh_ref, _, _ = oracle_training_loss(sd, ref, pos0, x0, cond, ei, batch, times, npos.clone(), nh.clone(),
+                                                         atom_type_size=A, norm_scope="graph", graph_ptr=ptr)
+    loss_ref.backward()
+    dev = "cuda"
+    proc = dma.E3DiffusionProcess(1e-5, 2.0, T)
+    grads = {}
+    old_chunk = _ag.EDGE_CHUNK
+    _ag.EDGE_CHUNK = 5000
+    try:
+        for prec in ("fp32", "bf16"):
+            m = dma.EquivariantGNN(2, **d)
+            m.load_state_dict({k: v.detach() for k, v in sd.items()})
+            m.to(dev).train()
+            m.precision, m.norm_scope = prec, "graph"
+            noised = dma.diffuse_as_batch(pos0.to(dev), x0.to(dev), batch.to(dev), proc, times=times,
+                                          noise_pos=npos.to(dev), noise_h=nh.to(dev), num_graphs=3)
+            loss, ex, eh = dma.training_loss(m, ei.to(dev), batch.to(dev), noised, cond.to(dev), A, num_graphs=3)
+            loss.backward()
+            grads[prec] = {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
+            if prec == "fp32":
+                assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 1e-4 * abs(float(loss_ref.detach()))
+                assert rel_err(ex.detach().cpu(), ex_ref.detach()) <= 1e-4 and rel_err(eh.detach().cpu(), eh_ref.detach()) <= 1e-4
+    finally:
+        _ag.EDGE_CHUNK = old_chunk
+    for k in grads["fp32"]:
+        assert rel_err(grads["fp32"][k], sd[k].grad) <= 2e-3, k
+        assert rel_err(grads["bf16"][k], grads["fp32"][k]) <= 8e-2, k
+
+
+@pytest.mark.gpu
 def test_train_step_reduces_loss():
     from types import SimpleNamespace
     H, A, T = 36, 2, 50
