@@ -389,6 +389,52 @@ def slab_leg(args, rk, steps, warmup):
     return out
 
 
+def latency_leg(args, rk, steps=64, warmup=16):
+    """Small-batch latency (the reference's actual use: generate() samples ONE 20-64-atom graph per call, T + 1 forwards,
+    parts/train_per_iretation.py:288-364; its only timing trace is ~6.9 ms per reverse step on an unnamed NVIDIA GPU,
+    model_flex.ipynb:218 -- context, not a same-node number).  ms per reverse step of the device-resident sampler,
+    eager launches vs hipGraph replay (8 steps per graph)."""
+    import diffusion_model_amd as dma
+    dev = rk.dev
+    rows = []
+    proc = dma.E3DiffusionProcess(1e-5, 2.0, T)
+
+    def run(name, net, sizes, ncond, launches):
+        cond = torch.randn(sum(sizes), ncond, generator=torch.Generator().manual_seed(1)) if ncond else None
+        smp = dma.DeviceSampler(net, proc, sizes, cond, atom_type_size=A, seed=0, norm_scope="graph", device=dev)
+        row = {"workload": name, "graphs": len(sizes), "atoms": sum(sizes), "launches_per_step": launches}
+        for key, graph in (("eager_ms_per_step", False), ("graph_replay_ms_per_step", True)):
+            smp.init()
+            smp.run(nsteps=warmup, use_graph=graph)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            smp.run(nsteps=steps, use_graph=graph, sync=True)
+            torch.cuda.synchronize(dev)
+            row[key] = (time.perf_counter() - t0) * 1e3 / steps
+        row["nonfinite_graphs"] = int(smp.state()[2].sum())
+        rows.append(row)
+        del smp
+
+    net = build_net(dma, args.layers, 64).to(dev).eval()
+    net.precision = args.precision
+    per_step = args.layers * 4 + 1            # L x {node_pre, edge X, edge M, node_post} + fused update
+    run("1 x 64-atom cell, fully connected (the reference's per-call workload)", net, [64], H - A - 1, per_step)
+    run("5 x 64-atom cells (gen_num_per_spectrum = 5, one device batch)", net, [64] * 5, H - A - 1, per_step)
+    run("1 x 20-atom cell", net, [20], H - A - 1, per_step)
+    torch.manual_seed(2025)
+    toy = dma.EquivariantGNN(args.layers, 7, W, M, 7, W, 1, 3 + M, W, 3)     # unconditional variant: H = 2 + 1
+    with torch.no_grad():
+        for layer in toy.egcl_list:
+            layer.mlp_x[4].weight.mul_(1e-3)
+            layer.mlp_x[4].bias.mul_(1e-3)
+    toy.to(dev).eval()
+    toy.precision = args.precision
+    run("configs[0] shape: 4 x 2-atom Si-O graphs, H = 3", toy, [2] * 4, 0, per_step)
+    return {"unit": "ms per reverse step", "steps": steps, "rows": rows,
+            "reference_trace_ms_per_step": 6.9,
+            "reference_trace_note": "model_flex.ipynb:218, 34.64 s per 5 samples x (T+1) forwards if T = 1000; unknown NVIDIA GPU"}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` from a plain shell: start the N ranks as a child torch.distributed.run (nothing in
     this process has touched the GPU; the child is a new process, not an exec of this one)."""
@@ -418,6 +464,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-leg", action="store_true")
     ap.add_argument("--no-slab-leg", action="store_true")
+    ap.add_argument("--no-latency-leg", action="store_true")
     ap.add_argument("--train-steps", type=int, default=8)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -456,6 +503,8 @@ def main():
             sl = slab_leg(args, rk, 50, 10)
             out["slab_4096"] = sl
             valid = valid and sl["nonfinite_graphs"] == 0
+        if rk.world == 1 and not args.no_latency_leg and args.atoms == 64:
+            out["latency"] = latency_leg(args, rk)
         if rk.world == 1 and rk.rank == 0 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, args.atoms, args.cpu_seconds)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

@@ -57,6 +57,7 @@ struct LayerPack {
   void* w2h_bf16p = nullptr;  // mlp_h.2 bf16 fragments, k in accumulator-row order
 };
 
+constexpr int kGraphSteps = 8;   // reverse steps captured per hipGraph
 struct Sampler {
   bool ready = false;
   int T = 0, A = 0, t = 0;
@@ -70,8 +71,8 @@ struct Sampler {
   float* cond = nullptr;           // [N][H-A-1] constant conditioning block
   int* t_dev = nullptr;            // current t on device (graph replay reads it)
   int* bad = nullptr;              // [B] sticky non-finite flags
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t graph_exec = nullptr;
+  hipGraph_t graph[2] = {nullptr, nullptr};            // [0]: one reverse step, [1]: kGraphSteps steps
+  hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
   int graph_prec = -1, graph_norm = -1;
 };
 
@@ -98,6 +99,7 @@ struct egnn_ctx {
   float* node_d2 = nullptr;  // [N]
   float* gscale = nullptr;   // [B] sum of d^2 per graph (G^2); node_post applies 1/(G+1)
   int last_R = 64, last_nsplit_x = 1;   // edge path chosen by the last launch_layer_begin
+  bool sq_from_agg = false;             // node_post takes the d^2 sums from the coordinate sums' component 3
   unsigned long long* stamps = nullptr;  // [2 kernels][8 waves][32 chunks][4] diagnostic time stamps
   float* h_tmp[2] = {nullptr, nullptr};  // [N][H] ping-pong between layers
   float* x_tmp[2] = {nullptr, nullptr};  // [N][3]
@@ -112,6 +114,6 @@ struct egnn_ctx {
 namespace egnn {
 int reserve(egnn_ctx* c);
 int launch_layer(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_scope, const float* h,
-                 const float* x, float* h_out, float* x_out);
+                 const float* x, float* h_out, float* x_out, bool need_gscale = false);
 int edge_rows_per_tile(int prec);
 }  // namespace egnn

@@ -1,4 +1,16 @@
-// Fused per-edge kernels, bf16 MFMA, 128-edge tiles with the output columns split over workgroups (gfx950).
+// Fused per-edge kernels, bf16 MFMA, 128-edge tiles with the output columns split over workgroups (gfx950) -- v4.
+//
+// Same tiling, prologue and epilogue as edge_bf16_v3.hip; the K loop differs:
+//   * v3 runs the two waves of a SIMD in opposite phase (multiply chunk c | build chunk c+1): the partner's vector work
+//     hides under this wave's matrix work, but every wave still executes its OWN matrix phase and vector phase one after
+//     the other, so a chunk costs (matrix 1.3 k + vector 1.0 k cycles) per wave however well the partners overlap.
+//   * v4 interleaves inside each wave: between two groups of MFMAs (which only occupy the issue port for 8 of their 32
+//     cycles) the wave finishes ONE activation of the chunk two ahead (SiLU(P[dst] + Q[src] + wd*d2) -> bf16), so its
+//     vector work rides in its own MFMA shadow.  The activation chunks live in a 3-deep LDS ring: chunk c is multiplied
+//     while chunk c+2 is written, and chunk c+1 (complete since the previous barrier) can already be read for the first
+//     k-step of the next iteration BEFORE this iteration's barrier -- no LDS-latency bubble after the barrier.
+//   * table rows are re-requested the moment their registers are free (row 0 mid-chunk, row 1 at the end) and have a
+//     whole chunk to arrive.
 //
 // Why: at a 64-edge tile every CU must stream 40 KiB of weight fragments per 640 MFMA-cycles = 64 B/clk,
 // the per-CU L2 fill rate, and the tile cannot grow because the fp32 accumulators of all 1280 output
@@ -44,15 +56,18 @@ constexpr size_t kOffSegRe = kOffSegRs + kR3 * 4;              // int[R]
 constexpr size_t kOffSegMode = kOffSegRe + kR3 * 4;            // int[R]
 constexpr size_t kOffMisc = kOffSegMode + kR3 * 4;             // int[16]
 constexpr size_t kOffGseg = kOffMisc + 64;                     // float[kSegFast3][R]
-constexpr size_t kOffA1 = kOffGseg + kSegFast3 * kR3 * 4;      // 2 activation chunks, then wd[KP]
-__host__ __device__ inline size_t v3_smem_bytes(int KP, int MP, bool is_m) {
-  const size_t loop = 2 * kA1_3 + (size_t)KP * 4;
-  const size_t msg = is_m ? (size_t)kR3 * (MP + 1) * 4 : 0;   // fallback message tile aliases the loop buffers
-  return kOffA1 + (loop > msg ? loop : msg);
+constexpr size_t kOffA1 = kOffGseg + kSegFast3 * kR3 * 4;      // ring of 3 activation chunks, then wd[KP]
+constexpr int kRing = 3;
+__host__ __device__ inline size_t v4_smem_bytes(int KP, int MP, bool is_m) {
+  (void)MP; (void)is_m;
+  return kOffA1 + kRing * kA1_3 + (size_t)KP * 4;
 }
 
+#ifndef EGNN_V4_M_WAVES
+#define EGNN_V4_M_WAVES 3   // waves per SIMD the message kernel is compiled for (4 would allow two workgroups per CU, but spills)
+#endif
 template <int CB, bool IS_M>
-__global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p) {
+__global__ __launch_bounds__(kT3, (IS_M ? EGNN_V4_M_WAVES : 2)) void edge_kernel_bf16_v4(const EdgeParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* s_dst = reinterpret_cast<int*>(smem + kOffDst);
   int* s_src = reinterpret_cast<int*>(smem + kOffSrc);
@@ -68,8 +83,7 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
   int* s_misc = reinterpret_cast<int*>(smem + kOffMisc);
   float* s_gseg = reinterpret_cast<float*>(smem + kOffGseg);
   char* s_a1 = smem + kOffA1;
-  float* s_wd = reinterpret_cast<float*>(s_a1 + 2 * kA1_3);
-  float* s_msg = reinterpret_cast<float*>(s_a1);   // M fallback path only, after the K-loop
+  float* s_wd = reinterpret_cast<float*>(s_a1 + kRing * kA1_3);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -166,7 +180,7 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
 
   // ---- K-loop ----
   const int NC = KP / kKC3, KS = KP / 16;
-  const int brow = tid >> 3, kg = tid & 7;   // this thread builds rows brow and brow + 64
+  const int brow = tid >> 3, kg = tid & 7;   // this thread builds rows brow and brow + 64, columns [8 kg, 8 kg + 8) of a chunk
   const rsrc_t rs_tab = make_rsrc(p.table, (p.dbg & 2) ? 0u : (unsigned)((size_t)p.N * p.TC * 2));
   const rsrc_t rs_w = make_rsrc(IS_M ? p.w2m : p.w2x, (p.dbg & 1) ? 0u : (unsigned)((size_t)(IS_M ? p.MP : p.WxP) * KP * 2));
   const unsigned vdst0 = (unsigned)s_dst[brow] * (unsigned)p.TC * 2u + (unsigned)kg * 16u;
@@ -178,10 +192,10 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
   char* slot0 = s_a1 + ((size_t)kg * kRPAD3 + brow) * 16;
   char* slot1 = slot0 + 64 * 16;
   const unsigned lane16 = lane * 16u;
-  // 32-bit LDS byte address of this lane's A-fragment slot in activation buffer 0
+  // 32-bit LDS byte address of this lane's A-fragment slot in ring buffer 0
   const unsigned lds_a1_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(s_a1 + ((size_t)hh * kRPAD3 + r) * 16);
   const int colblk0 = half * 8 * CB + wave * CB;   // first 32-column block of this wave
-  const unsigned w0 = (unsigned)colblk0 * KS * 1024u;
+  const unsigned w0off = (unsigned)colblk0 * KS * 1024u;
 
   f32x16 acc[kRB3][CB];
 #pragma unroll
@@ -191,190 +205,135 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[rb][cb][i] = 0.f;
 
-  {  // chunk 0
-    UnitH u;
-    unith_load(u, rs_tab, vdst0, vsrc0, offP, offQ);
-    unith_finish(u, s_wd + kg * 8, d2r0, slot0);
-    unith_load(u, rs_tab, vdst1, vsrc1, offP, offQ);
-    unith_finish(u, s_wd + kg * 8, d2r1, slot1);
-  }
+  UnitH u0, u1;   // table rows of rows brow / brow + 64 for the chunk that is built next
+  auto uload = [&](UnitH& u, const unsigned vd, const unsigned vs, const int cq) {
+    const int c = cq < NC ? cq : NC - 1;                    // past the end: a harmless repeat of the last chunk
+    const unsigned kb = (unsigned)c * kKC3 * 2u;
+    unith_load(u, rs_tab, vd, vs, offP + kb, offQ + kb);
+  };
+  // chunks 0 and 1 are built up front (ring slots 0 and 1)
+  uload(u0, vdst0, vsrc0, 0); uload(u1, vdst1, vsrc1, 0);
+  unith_finish(u0, s_wd + kg * 8, d2r0, slot0);
+  unith_finish(u1, s_wd + kg * 8, d2r1, slot1);
+  uload(u0, vdst0, vsrc0, 1); uload(u1, vdst1, vsrc1, 1);
+  unith_finish(u0, s_wd + kKC3 + kg * 8, d2r0, slot0 + kA1_3);
+  unith_finish(u1, s_wd + kKC3 + kg * 8, d2r1, slot1 + kA1_3);
+  uload(u0, vdst0, vsrc0, 2); uload(u1, vdst1, vsrc1, 2);
   bf16x8 bq[4][CB];   // weight fragments of the 4 k-steps of the current chunk
 #pragma unroll
   for (int s = 0; s < 4; ++s)
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb) bq[s][cb] = ldbuf_bf16x8(rs_w, lane16, w0 + ((unsigned)cb * KS + s) * 1024u);
+    for (int cb = 0; cb < CB; ++cb) bq[s][cb] = ldbuf_bf16x8(rs_w, lane16, w0off + ((unsigned)cb * KS + s) * 1024u);
   __syncthreads();
 
-  // matrix phase of chunk c: 4 k-steps x (4 row blocks x CB column blocks)
-  // Operand pipeline of the matrix phase: the weight fragments of k-step s of chunk c+1 are requested right
-  // after the MFMAs of k-step s of chunk c were issued (a whole chunk = 4 k-steps of distance, enough to cover
-  // an L2 round trip under load), the LDS A fragments one k-step ahead.
-  auto mphase = [&](const int c, const bool last) {
-#ifndef EGNN_EXP_NO_MFMA
-    // A fragments by inline-asm ds_read_b128 so that hipcc cannot sink them to their use: a[rb] is refilled in
-    // place for k-step s+1 right after the MFMAs of (s, rb) were issued and flies under the next 3 row blocks'
-    // MFMAs.  LDS operations of a wave return in order, so lgkmcnt(3) before a use means "all but the 3
-    // younger reads have landed" (a scalar load in flight only makes the wait conservative).
-    const unsigned abase = lds_a1_base + (unsigned)(c & 1) * (unsigned)kA1_3;
-    bf16x8 a[kRB3];
-#define LDS_RD(dst, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(abase), "n"(off))
+  // ring offsets (bytes): chunk c is read at off_cur, chunk c+1 at off_nxt, chunk c+2 is written at off_wr
+  unsigned off_cur = 0u, off_nxt = (unsigned)kA1_3, off_wr = 2u * (unsigned)kA1_3;
+  bf16x8 a[kRB3];
+#define LDS_RD(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(off))
 #define LDS_WAIT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
-    LDS_RD(a[0], 0); LDS_RD(a[1], 512); LDS_RD(a[2], 1024); LDS_RD(a[3], 1536);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-#pragma unroll
-      for (int rb = 0; rb < kRB3; ++rb) {
-        // LDS returns in order: at most 3 younger reads may still be in flight when a[rb] is consumed
-        if (s < 3 || rb == 0) LDS_WAIT(3);
-        else if (rb == 1) LDS_WAIT(2);
-        else if (rb == 2) LDS_WAIT(1);
-        else LDS_WAIT(0);
-        asm volatile("" : "+v"(a[rb]));   // uses of a[rb] stay below the wait
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb)
-          acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rb], bq[s][cb], acc[rb][cb], 0, 0, 0);
-        // refill a[rb] in place for the next k-step (the MFMAs above have read it at issue)
-        if (s == 0) { if (rb == 0) LDS_RD(a[0], 4128); if (rb == 1) LDS_RD(a[1], 4128 + 512); if (rb == 2) LDS_RD(a[2], 4128 + 1024); if (rb == 3) LDS_RD(a[3], 4128 + 1536); }
-        if (s == 1) { if (rb == 0) LDS_RD(a[0], 8256); if (rb == 1) LDS_RD(a[1], 8256 + 512); if (rb == 2) LDS_RD(a[2], 8256 + 1024); if (rb == 3) LDS_RD(a[3], 8256 + 1536); }
-        if (s == 2) { if (rb == 0) LDS_RD(a[0], 12384); if (rb == 1) LDS_RD(a[1], 12384 + 512); if (rb == 2) LDS_RD(a[2], 12384 + 1024); if (rb == 3) LDS_RD(a[3], 12384 + 1536); }
-      }
-      if (!last) {
-        const unsigned ksn = (unsigned)((c + 1) * 4 + s) * 1024u;
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb) bq[s][cb] = ldbuf_bf16x8(rs_w, lane16, w0 + (unsigned)cb * KS * 1024u + ksn);
-      }
-      if (s == 0) STAMP2(c, 2, wave < 4);
+  LDS_RD(a[0], lds_a1_base, 0); LDS_RD(a[1], lds_a1_base, 512); LDS_RD(a[2], lds_a1_base, 1024); LDS_RD(a[3], lds_a1_base, 1536);
+
+  // One chunk.  16 groups (k-step s, row block rb): wait for a[rb] (LDS returns in order: the 3 younger refills may
+  // still fly), CB MFMAs, refill a[rb] in place for the next k-step (from the NEXT chunk's buffer after the last
+  // k-step), and ONE activation of chunk c+2 in two halves of ~16 issue cycles, each behind an MFMA: an in-order wave can
+  // only use the 24 free issue cycles of an MFMA's 32 if the fillers sit BETWEEN two MFMAs in program order.
+  // sched_barrier(0) pins this order; inside a half the compiler schedules freely.
+  auto chunk = [&](const int c, const bool build, const bool last) {
+    STAMP(c, 0);
+    const unsigned abase = lds_a1_base + off_cur, nbase = lds_a1_base + off_nxt;
+    f32x4 wv0, wv1;
+    f16x8 t;
+    bf16x8 o;
+    if (build) {
+      const float* wd = s_wd + (c + 2) * kKC3 + kg * 8;
+      wv0 = *reinterpret_cast<const f32x4*>(wd);
+      wv1 = *reinterpret_cast<const f32x4*>(wd + 4);
     }
+    // The 16 activations a thread owes to chunk c+2 are finished 4 per k-step, as a software pipeline over the 8 MFMA
+    // gaps of the k-step: every gap issues ~16 cycles of INDEPENDENT vector instructions whose operands were produced at
+    // least one gap earlier (an in-order wave stalls on a dependent transcendental otherwise), between two MFMAs in
+    // program order (that is where an in-order wave can use the 24 issue cycles an MFMA leaves free of its 32):
+    //   gap 0: 4 x fma_mix (pre-activation)   1-2: 2 x exp2 each   3: 4 x add 1   4-5: 2 x rcp each   6: 4 x mul
+    //   gap 7: bf16 pack; every second k-step completes a 16-byte LDS slot and re-requests the consumed table row.
+    float pu[4], pe[4];
+#define STAGE(S, Q)                                                                                           \
+    if (build) {                                                                                              \
+      constexpr int e0_ = 4 * ((S) & 1);   /* first element of this k-step inside its unit */                 \
+      if ((Q) == 0) {                                                                                         \
+        if ((S) == 0) t = u0.p + u0.q;                                                                        \
+        if ((S) == 2) t = u1.p + u1.q;                                                                        \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                         \
+          pu[k] = fmaf(e0_ ? wv1[k] : wv0[k], (S) < 2 ? d2r0 : d2r1, (float)t[e0_ + k]);                      \
+      }                                                                                                       \
+      if ((Q) == 1) { pe[0] = __builtin_amdgcn_exp2f(pu[0]); pe[1] = __builtin_amdgcn_exp2f(pu[1]); }         \
+      if ((Q) == 2) { pe[2] = __builtin_amdgcn_exp2f(pu[2]); pe[3] = __builtin_amdgcn_exp2f(pu[3]); }         \
+      if ((Q) == 3) { _Pragma("unroll") for (int k = 0; k < 4; ++k) pe[k] = 1.0f + pe[k]; }                   \
+      if ((Q) == 4) { pe[0] = __builtin_amdgcn_rcpf(pe[0]); pe[1] = __builtin_amdgcn_rcpf(pe[1]); }           \
+      if ((Q) == 5) { pe[2] = __builtin_amdgcn_rcpf(pe[2]); pe[3] = __builtin_amdgcn_rcpf(pe[3]); }           \
+      if ((Q) == 6) { _Pragma("unroll") for (int k = 0; k < 4; ++k) pu[k] = pu[k] * pe[k]; }                  \
+      if ((Q) == 7) {                                                                                         \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) o[e0_ + k] = (__bf16)pu[k];                             \
+        if ((S) == 1) { *reinterpret_cast<bf16x8*>(slot0 + off_wr) = o; uload(u0, vdst0, vsrc0, c + 3); }     \
+        if ((S) == 3) { *reinterpret_cast<bf16x8*>(slot1 + off_wr) = o; uload(u1, vdst1, vsrc1, c + 3); }     \
+      }                                                                                                       \
+    }
+#define GROUP(S, RB)                                                                                          \
+    {                                                                                                         \
+      if (!last || (S) < 3 || (RB) == 0) LDS_WAIT(3);                                                         \
+      else if ((RB) == 1) LDS_WAIT(2);                                                                        \
+      else if ((RB) == 2) LDS_WAIT(1);                                                                        \
+      else LDS_WAIT(0);                                                                                       \
+      asm volatile("" : "+v"(a[RB]));                                                                         \
+      acc[RB][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[RB], bq[S][0], acc[RB][0], 0, 0, 0);             \
+      __builtin_amdgcn_sched_barrier(0);                                                                      \
+      STAGE(S, 2 * (RB))                                                                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                                      \
+      _Pragma("unroll") for (int cb = 1; cb < CB; ++cb)                                                       \
+        acc[RB][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[RB], bq[S][cb], acc[RB][cb], 0, 0, 0);        \
+      if ((S) < 3) LDS_RD(a[RB], abase, ((S) + 1) * 4128 + (RB) * 512);                                       \
+      else if (!last) LDS_RD(a[RB], nbase, (RB) * 512);                                                       \
+      __builtin_amdgcn_sched_barrier(0);                                                                      \
+      STAGE(S, 2 * (RB) + 1)                                                                                  \
+      __builtin_amdgcn_sched_barrier(0);                                                                      \
+    }
+#ifdef EGNN_V4_PRIO_FLIP   /* alternate which of the two waves of a SIMD wins arbitration, per k-step */
+#define KPRIO(S) if (((((S) & 1) ^ (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#else
+#define KPRIO(S)
+#endif
+#define KSTEP(S)                                                                                              \
+    KPRIO(S)                                                                                                  \
+    GROUP(S, 0) GROUP(S, 1) GROUP(S, 2) GROUP(S, 3)                                                           \
+    if (!last) {                                                                                              \
+      const unsigned ksn = (unsigned)((c + 1) * 4 + (S)) * 1024u;                                             \
+      _Pragma("unroll") for (int cb = 0; cb < CB; ++cb)                                                       \
+        bq[S][cb] = ldbuf_bf16x8(rs_w, lane16, w0off + (unsigned)cb * KS * 1024u + ksn);                      \
+    }
+    KSTEP(0) KSTEP(1)
+    STAMP(c, 1);
+    KSTEP(2) KSTEP(3)
+    STAMP(c, 2);
+#undef KSTEP
+#undef GROUP
+#undef STAGE
+    const unsigned tmp = off_cur; off_cur = off_nxt; off_nxt = off_wr; off_wr = tmp;
+  };
+  // (the steady-state loop body is branch-free so that hipcc's waitcnt insertion keeps counted vmcnt waits across
+  // the back edge instead of draining the queue at every control-flow join)
+  STAMP(30, 2);   // chunks 0 and 1 built, first weights requested
+  RSTAMP(31, 1);
+  for (int c = 0; c < NC - 2; ++c) { chunk(c, true, false); __syncthreads(); STAMP(c, 3); }
+  chunk(NC - 2, false, false);
+  __syncthreads();
+  STAMP(NC - 2, 3);
+  chunk(NC - 1, false, true);
+  __syncthreads();
+  STAMP(NC - 1, 3);
+  RSTAMP(31, 2);
 #undef LDS_WAIT
 #undef LDS_RD
-#else   // timing experiment without MFMAs: compiler-visible LDS reads
-    const char* cur = s_a1 + (size_t)(c & 1) * kA1_3 + ((size_t)hh * kRPAD3 + r) * 16;
-    bf16x8 a[kRB3], an[kRB3];
-#pragma unroll
-    for (int rb = 0; rb < kRB3; ++rb) a[rb] = *reinterpret_cast<const bf16x8*>(cur + (size_t)(32 * rb) * 16);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      if (s < 3) {
-#pragma unroll
-        for (int rb = 0; rb < kRB3; ++rb)
-          an[rb] = *reinterpret_cast<const bf16x8*>(cur + ((size_t)((s + 1) * 2) * kRPAD3 + 32 * rb) * 16);
-      }
-#pragma unroll
-      for (int rb = 0; rb < kRB3; ++rb)
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb)
-          acc[rb][cb][0] += (float)a[rb][0] * (float)bq[s][cb][0];
-      if (!last) {
-        const unsigned ksn = (unsigned)((c + 1) * 4 + s) * 1024u;
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb) bq[s][cb] = ldbuf_bf16x8(rs_w, lane16, w0 + (unsigned)cb * KS * 1024u + ksn);
-      }
-      if (s < 3) {
-#pragma unroll
-        for (int rb = 0; rb < kRB3; ++rb) a[rb] = an[rb];
-      }
-    }
-#endif
-  };
-  // Table-row units: set A serves every chunk (depth 1) or the odd chunks (depth 2), set B the even chunks of
-  // the depth-2 pipeline.  Depth 2 = rows requested two chunks ahead; the message kernel has the registers for
-  // it (and a chunk period shorter than an L2 round trip under load), the coordinate kernel does not.
-  constexpr bool DEPTH2 = (CB == 1);   // the message kernel and narrow coordinate MLPs
-  UnitH ua0, ua1, ub0, ub1;
-  auto vload = [&](UnitH& x0, UnitH& x1, const int cq) {   // table rows for the activations of chunk cq (clamped)
-    const int c = cq < NC ? cq : NC - 1;                    // past the end: a harmless repeat of the last chunk
-    const unsigned kb = (unsigned)c * kKC3 * 2u;
-    unith_load(x0, rs_tab, vdst0, vsrc0, offP + kb, offQ + kb);
-    unith_load(x1, rs_tab, vdst1, vsrc1, offP + kb, offQ + kb);
-  };
-  auto vfinish = [&](const UnitH& x0, const UnitH& x1, const int c) {  // SiLU + bf16 pack of chunk c into its LDS buffer
-    const size_t nbuf = (size_t)(c & 1) * kA1_3;
-    // vector work wins issue arbitration over the partner wave's MFMAs (which only need 1 slot in 4)
-    __builtin_amdgcn_s_setprio(3);
-    unith_finish(x0, s_wd + c * kKC3 + kg * 8, d2r0, slot0 + nbuf);
-    STAMP2(c - 1, 1, wave >= 4);
-    unith_finish(x1, s_wd + c * kKC3 + kg * 8, d2r1, slot1 + nbuf);
-    STAMP2(c - 1, 2, wave >= 4);
-    __builtin_amdgcn_s_setprio(0);
-  };
-  STAMP(30, 2);   // chunk 0 built, first weights requested
-  RSTAMP(31, 1);
-  // The two waves that share a SIMD (w and w+4) run the chunk in opposite phase: waves 0-3 multiply chunk c
-  // and then build chunk c+1, waves 4-7 build chunk c+1 first and then multiply chunk c -- one wave's vector
-  // work runs under its partner's matrix work instead of both alternating in lockstep.  One barrier per chunk
-  // either way.  A unit set is reloaded as soon as it has been consumed (for waves 0-3 that is ahead of the
-  // barrier: the vector-memory issue time -- 1 KiB per instruction through a 64 B/clk path -- then overlaps
-  // the group's barrier wait instead of delaying its matrix phase).
-  // (the steady-state loop bodies are branch-free so that hipcc's waitcnt insertion can keep counted
-  // vmcnt waits across the back edge instead of draining the queue at every control-flow join)
-#ifdef EGNN_EXP_NO_BUILD
-  for (int c = 0; c < NC; ++c) { mphase(c, c == NC - 1); __syncthreads(); }
-#else
-  if (wave < 4) {
-    auto step = [&](UnitH& x0, UnitH& x1, const int i) {   // chunk i: multiply, build i+1, request the set's next chunk
-      STAMP(i, 0);
-      STAMP2(i, 1, true);
-      mphase(i, false);
-      STAMP1(i, 1);
-      STAMP2(i, 3, true);
-      vfinish(x0, x1, i + 1);
-      vload(x0, x1, i + (DEPTH2 ? 3 : 2));
-      STAMP1(i, 2);
-      __syncthreads();
-      STAMP1(i, 3);
-    };
-    vload(ua0, ua1, 1);
-    if constexpr (DEPTH2) {
-      vload(ub0, ub1, 2);
-      int i = 0;
-      for (; i + 1 <= NC - 2; i += 2) { step(ua0, ua1, i); step(ub0, ub1, i + 1); }
-      if (i <= NC - 2) step(ua0, ua1, i);
-    } else {
-      for (int i = 0; i < NC - 1; ++i) step(ua0, ua1, i);
-    }
-    mphase(NC - 1, true);
-    __syncthreads();
-  } else {
-    auto step = [&](UnitH& x0, UnitH& x1, const int i) {   // build i+1, request the set's next chunk, multiply chunk i
-      STAMP(i, 0);
-      vfinish(x0, x1, i + 1);
-      vload(x0, x1, i + (DEPTH2 ? 3 : 2));
-      __builtin_amdgcn_sched_barrier(0);
-      STAMP1(i, 1);
-      STAMP2(i, 3, true);
-      mphase(i, false);
-      STAMP1(i, 2);
-      __syncthreads();
-      STAMP1(i, 3);
-    };
-    vload(ua0, ua1, 1);
-    if constexpr (DEPTH2) {
-      vload(ub0, ub1, 2);
-      int i = 0;
-      for (; i + 1 <= NC - 2; i += 2) { step(ua0, ua1, i); step(ub0, ub1, i + 1); }
-      if (i <= NC - 2) step(ua0, ua1, i);
-    } else {
-      for (int i = 0; i < NC - 1; ++i) step(ua0, ua1, i);
-    }
-    mphase(NC - 1, true);
-    __syncthreads();
-  }
-#endif
   STAMP(30, 3);   // K loop done
-  RSTAMP(31, 2);
-#ifdef EGNN_EXP_NO_EPI
-  {
-    float keep = 0.f;
-#pragma unroll
-    for (int rb = 0; rb < kRB3; ++rb)
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) keep += acc[rb][cb][i];
-    if (keep == 1.2345e-30f) p.agg_x[tid] = keep;
-    return;
-  }
-#endif
+
 
   // row of value index q (q = rb*16 + reg) for this lane
   auto row_of = [&](int q) { return 32 * (q >> 4) + acc_row(q & 15, lane); };
@@ -484,14 +443,19 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
       s_val[tid] = sigmoid_f(g) * kNegInvLog2e;   // also undoes the scale of mval
     }
     __syncthreads();
-    if (S <= kSegFast3) {
-      for (int t = tid; t < S * kR3; t += kT3) {
-        const int seg = t >> 7, row = t & 127;
+    // segment sums, kSegFast3 segments per pass (one pass unless the tile holds many short segments): the gate of
+    // each row is laid out per segment in LDS and every lane dots its 64 message values with it
+    for (int base = 0; base < S; base += kSegFast3) {
+      const int ns = min(kSegFast3, S - base);
+      if (base > 0) __syncthreads();   // the previous pass has been read
+      for (int t = tid; t < ns * kR3; t += kT3) {
+        const int seg = base + (t >> 7), row = t & 127;
         s_gseg[t] = (s_seg_of_row[row] == seg) ? s_val[row] : 0.f;
       }
       __syncthreads();
-      for (int seg = 0; seg < S; ++seg) {
-        const float* gw = s_gseg + seg * kR3 + 4 * hh;
+      for (int sg = 0; sg < ns; ++sg) {
+        const int seg = base + sg;
+        const float* gw = s_gseg + sg * kR3 + 4 * hh;
         float v = 0.f;
 #pragma unroll
         for (int rb = 0; rb < kRB3; ++rb)
@@ -504,73 +468,52 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
           dstp[ncol] = v;
         }
       }
-    } else {
-      // many short segments: stage the gated messages in LDS (over the finished K-loop buffers)
-      const int ld = p.MP + 1;
-#pragma unroll
-      for (int rb = 0; rb < kRB3; ++rb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int row = 32 * rb + acc_row(i, lane);
-          s_msg[row * ld + ncol] = mval[rb * 16 + i] * s_val[row];
-        }
-      __syncthreads();
-      for (int c = tid; c < p.MP; c += kT3) {
-        for (int seg = 0; seg < S; ++seg) {
-          const int mode = s_seg_mode[seg];
-          float sum = 0.f;
-          for (int rr = s_seg_rs[seg]; rr <= s_seg_re[seg]; ++rr) sum += s_msg[rr * ld + c];
-          float* dstp = mode == 2 ? p.agg_m + (size_t)s_seg_node[seg] * p.MP : p.part_m + ((size_t)tile * 2 + mode) * p.MP;
-          dstp[c] = sum;
-        }
-      }
     }
   }
   STAMP(31, 0);   // epilogue done
 }
 
 template <int CB, bool IS_M>
-int launch_v3(const EdgeParams& p, int blocks, size_t smem, hipStream_t st) {
-  hipLaunchKernelGGL((edge_kernel_bf16_v3<CB, IS_M>), dim3(blocks), dim3(kT3), smem, st, p);
+int launch_v4(const EdgeParams& p, int blocks, size_t smem, hipStream_t st) {
+  hipLaunchKernelGGL((edge_kernel_bf16_v4<CB, IS_M>), dim3(blocks), dim3(kT3), smem, st, p);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }
 
 }  // namespace
 
-int init_edge_bf16_v3_attributes() {
-  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v3<2, false>),
+int init_edge_bf16_v4_attributes() {
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v4<2, false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v3<1, false>),
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v4<1, false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v3<1, true>),
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v4<1, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   return EGNN_OK;
 }
 
-int edge_v3_rows() { return kR3; }
+int edge_v4_rows() { return kR3; }
 
-bool edge_bf16_v3_supported(const EdgeParams& p) {
+bool edge_bf16_v4_supported(const EdgeParams& p) {
   return (p.WxP == 256 || p.WxP == 512 || p.WxP == 1024) && p.MP == 256 && p.WmP % 64 == 0 &&
-         v3_smem_bytes(p.WmP, p.MP, true) <= 160 * 1024 && v3_smem_bytes(p.WxP, p.MP, false) <= 160 * 1024 &&
+         v4_smem_bytes(p.WmP, p.MP, true) <= 160 * 1024 && v4_smem_bytes(p.WxP, p.MP, false) <= 160 * 1024 &&
          (size_t)p.N * p.TC * 4 < ((size_t)1 << 32);
 }
 
-// coordinate kernels only (the message kernel of edge_bf16_v4.hip is the faster one)
-int launch_edge_bf16_v3_x(const EdgeParams& p, hipStream_t st) {
+// message kernel only
+int launch_edge_bf16_v4_m(const EdgeParams& p, hipStream_t st) {
   const int tiles = (p.E + kR3 - 1) / kR3;
-  if (p.WxP >= 512) return launch_v3<2, false>(p, tiles * (p.WxP / 512), v3_smem_bytes(p.WxP, p.MP, false), st);
-  return launch_v3<1, false>(p, tiles, v3_smem_bytes(p.WxP, p.MP, false), st);
+  return launch_v4<1, true>(p, tiles, v4_smem_bytes(p.WmP, p.MP, true), st);
 }
 
-int launch_edge_bf16_v3(const EdgeParams& p, hipStream_t st) {
+int launch_edge_bf16_v4(const EdgeParams& p, hipStream_t st) {
   const int tiles = (p.E + kR3 - 1) / kR3;
   int rc;
   // X: CB = 2 (512 columns per workgroup) when the hidden width allows, else one 256-column workgroup
-  if (p.WxP >= 512) rc = launch_v3<2, false>(p, tiles * (p.WxP / 512), v3_smem_bytes(p.WxP, p.MP, false), st);
-  else rc = launch_v3<1, false>(p, tiles, v3_smem_bytes(p.WxP, p.MP, false), st);
+  if (p.WxP >= 512) rc = launch_v4<2, false>(p, tiles * (p.WxP / 512), v4_smem_bytes(p.WxP, p.MP, false), st);
+  else rc = launch_v4<1, false>(p, tiles, v4_smem_bytes(p.WxP, p.MP, false), st);
   if (rc) return rc;
-  return launch_v3<1, true>(p, tiles, v3_smem_bytes(p.WmP, p.MP, true), st);
+  return launch_v4<1, true>(p, tiles, v4_smem_bytes(p.WmP, p.MP, true), st);
 }
 
 }  // namespace egnn

@@ -258,6 +258,28 @@ __global__ __launch_bounds__(kThreads) void graph_sum_kernel(const float* __rest
   if (threadIdx.x == 0) gscale[blockIdx.x] = red[0];
 }
 
+// The same sums from what the v4 edge kernels leave in component 3 of the coordinate sums (no pass over the edges):
+// only launched where the sums are needed OUTSIDE node_post -- 'call' scope, the two-stage (partitioned) layer and
+// egcl_read_aggregates; in the per-graph sampling path node_post adds them up itself.
+__global__ __launch_bounds__(kThreads) void graph_sq_sums_kernel(const int* __restrict__ row_ptr, int R,
+                                                                   const float* __restrict__ agg_x,
+                                                                   const float* __restrict__ part_x,
+                                                                   const int* __restrict__ graph_ptr, int N, int per_graph,
+                                                                   float* __restrict__ gscale) {
+  __shared__ float red[kThreads];
+  const int lo = per_graph ? graph_ptr[blockIdx.x] : 0;
+  const int hi = per_graph ? graph_ptr[blockIdx.x + 1] : N;
+  float s = 0.f;
+  for (int n = lo + threadIdx.x; n < hi; n += kThreads) s += node_sq_sum(n, row_ptr, R, agg_x, part_x);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = kThreads / 2; w > 0; w >>= 1) {
+    if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) gscale[blockIdx.x] = red[0];
+}
+
 // ------------------------------------------------------------------------------------------------
 // fused edge kernel
 // ------------------------------------------------------------------------------------------------
@@ -800,6 +822,7 @@ int init_kernel_attributes() {
   int rc = init_edge_bf16_v2_attributes();
   if (rc) return rc;
   if ((rc = init_edge_bf16_v3_attributes())) return rc;
+  if ((rc = init_edge_bf16_v4_attributes())) return rc;
   if ((rc = init_node_bf16_attributes())) return rc;
   done = true;
   return EGNN_OK;
@@ -815,7 +838,7 @@ static int launch_edge(const EdgeParams& p, int tiles, size_t smem, hipStream_t 
 // Stage 1 of a layer: node_pre, squared-distance sums and the fused edge pass.  gsum (c->gscale) then holds the
 // sum of d^2 over the edges THIS context received, per graph (or per call).
 int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_scope, const float* h,
-                       const float* x) {
+                       const float* x, bool need_gscale) {
   const LayerPack& lp = c->layers[layer];
   if (!lp.packed) { set_error("layer %d has no packed parameters", layer); return EGNN_ESTATE; }
   const int N = c->N, E = c->E;
@@ -840,9 +863,10 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
     static const int dbg = getenv("EGNN_DEBUG") ? atoi(getenv("EGNN_DEBUG")) : 0;
     p.dbg = dbg;
   }
-  static const int edge_sel = getenv("EGNN_EDGE") ? atoi(getenv("EGNN_EDGE")) : 3;   // A/B switch: 1, 2 or 3
+  static const int edge_sel = getenv("EGNN_EDGE") ? atoi(getenv("EGNN_EDGE")) : 4;   // A/B switch: 1, 2, 3 or 4
   int path = 1;
-  if (prec == EGNN_PREC_BF16 && edge_sel >= 3 && edge_bf16_v3_supported(p)) path = 3;
+  if (prec == EGNN_PREC_BF16 && edge_sel >= 4 && edge_bf16_v4_supported(p) && edge_bf16_v3_supported(p)) path = 4;
+  else if (prec == EGNN_PREC_BF16 && edge_sel >= 3 && edge_bf16_v3_supported(p)) path = 3;
   else if (prec == EGNN_PREC_BF16 && edge_sel >= 2 && edge_bf16_v2_supported(p)) path = 2;
   const float* w1catT = lp.w1catT;
   const float* b1cat = lp.b1cat;
@@ -866,7 +890,7 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
       dim3 grid((N + kPre2Nodes - 1) / kPre2Nodes, (c->TC + kPre2Cols - 1) / kPre2Cols);
       const size_t sm = (size_t)((c->H + 1) & ~1) * 33 * sizeof(float);
       const size_t sm16 = (size_t)kPre2Nodes * (kPre2Cols + 8) * 2;   // output staging tile of the fp16 variant
-      if (path == 3)   // the v3 edge kernels read a half-precision table
+      if (path >= 3)   // the v3 / v4 edge kernels read a half-precision table
         hipLaunchKernelGGL(node_pre_mfma_kernel<_Float16>, grid, dim3(kThreads), sm > sm16 ? sm : sm16, st, h, N, c->H,
                            w1catT, b1cat, c->TC, reinterpret_cast<_Float16*>(c->table));
       else
@@ -875,17 +899,19 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
     } else {
       dim3 grid((N + kPreNodes - 1) / kPreNodes, (c->TC + kThreads - 1) / kThreads);
       const size_t sm = (size_t)kPreNodes * c->H * sizeof(float);
-      if (path == 3)
+      if (path >= 3)
         hipLaunchKernelGGL(node_pre_kernel<_Float16>, grid, dim3(kThreads), sm, st, h, N, c->H, w1catT, b1cat, c->TC,
                            reinterpret_cast<_Float16*>(c->table));
       else
         hipLaunchKernelGGL(node_pre_kernel<float>, grid, dim3(kThreads), sm, st, h, N, c->H, w1catT, b1cat, c->TC,
                            c->table);
     }
-    hipLaunchKernelGGL(node_d2_kernel, dim3((N + 255) / 256), dim3(256), 0, st, x, c->row_ptr, c->edge_src, N,
-                       c->node_d2);
-    hipLaunchKernelGGL(graph_sum_kernel, dim3(per_graph ? c->B : 1), dim3(kThreads), 0, st, c->node_d2,
-                       c->graph_ptr, N, per_graph, c->gscale);
+    if (path != 4) {   // the v4 edge kernels sum d^2 per receiving node themselves
+      hipLaunchKernelGGL(node_d2_kernel, dim3((N + 255) / 256), dim3(256), 0, st, x, c->row_ptr, c->edge_src, N,
+                         c->node_d2);
+      hipLaunchKernelGGL(graph_sum_kernel, dim3(per_graph ? c->B : 1), dim3(kThreads), 0, st, c->node_d2,
+                         c->graph_ptr, N, per_graph, c->gscale);
+    }
   }
   prof_end(c, st);
   EGNN_HIP(hipGetLastError());
@@ -895,7 +921,18 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
     const size_t smem = edge_smem_bytes(R, c->MP);
     prof_begin(c, st, 0);
     int rc;
-    if (path == 3) {
+    if (path == 4) {
+      R = edge_v4_rows();
+      nsplit_x = p.WxP >= 512 ? p.WxP / 512 : 1;
+      // coordinate kernels with the phase-opposed K loop of edge_bf16_v3.hip, message kernel with the in-wave pipeline
+      // of edge_bf16_v4.hip: each the faster one for its shape (EGNN_V4_X=1 selects the v4 coordinate kernel, A/B)
+      static const int v4x = getenv("EGNN_V4_X") ? atoi(getenv("EGNN_V4_X")) : 0;
+      if (v4x) rc = launch_edge_bf16_v4(p, st);
+      else {
+        rc = launch_edge_bf16_v3_x(p, st);
+        if (!rc) rc = launch_edge_bf16_v4_m(p, st);
+      }
+    } else if (path == 3) {
       R = edge_v3_rows();
       nsplit_x = p.WxP >= 512 ? p.WxP / 512 : 1;
       rc = launch_edge_bf16_v3(p, st);
@@ -907,6 +944,18 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
   }
 
   c->last_R = R; c->last_nsplit_x = nsplit_x;
+  c->sq_from_agg = false;
+  if (path == 4) {
+    if (E == 0) {
+      EGNN_HIP(hipMemsetAsync(c->gscale, 0, sizeof(float) * (per_graph ? c->B : 1), st));
+    } else if (!per_graph || need_gscale) {
+      hipLaunchKernelGGL(graph_sq_sums_kernel, dim3(per_graph ? c->B : 1), dim3(kThreads), 0, st, c->row_ptr, R, c->agg_x,
+                         c->part_x, c->graph_ptr, N, per_graph, c->gscale);
+      EGNN_HIP(hipGetLastError());
+    } else {
+      c->sq_from_agg = true;   // node_post adds the per-graph sums up itself: no launch
+    }
+  }
   return EGNN_OK;
 }
 
@@ -924,6 +973,7 @@ int launch_layer_end(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_
     q.h = h; q.x = x; q.row_ptr = c->row_ptr; q.node_graph = c->node_graph;
     q.agg_m = c->agg_m; q.agg_x = c->agg_x; q.part_m = c->part_m; q.part_x = c->part_x;
     q.gscale = c->gscale; q.per_graph = per_graph;
+    q.graph_ptr = c->graph_ptr; q.sq_from_agg = c->sq_from_agg ? 1 : 0;
     q.agg_x_stride = agg_x_stride; q.part_x_stride = part_x_stride; q.nsplit_x = nsplit_x;
     q.w1h = reinterpret_cast<const f32x4*>(lp.w1h_f32); q.w2h = reinterpret_cast<const f32x4*>(lp.w2h_f32);
     q.b1h = lp.b1h; q.b2h = lp.b2h; q.h_out = h_out; q.x_out = x_out;
@@ -934,6 +984,11 @@ int launch_layer_end(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_
       int rc = launch_node_post_bf16(q, st);
       if (rc) return rc;
     } else {
+      if (q.sq_from_agg) {   // the fp32 node kernel reads gscale
+        hipLaunchKernelGGL(graph_sq_sums_kernel, dim3(per_graph ? c->B : 1), dim3(kThreads), 0, st, c->row_ptr, R, c->agg_x,
+                           c->part_x, c->graph_ptr, N, per_graph, c->gscale);
+        q.sq_from_agg = 0;
+      }
       hipLaunchKernelGGL(node_post_kernel, dim3((N + kPostNodes - 1) / kPostNodes), dim3(kThreads),
                          post_smem_bytes(c->K1P, c->WhP), st, q);
     }
@@ -944,8 +999,8 @@ int launch_layer_end(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_
 }
 
 int launch_layer(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_scope, const float* h,
-                 const float* x, float* h_out, float* x_out) {
-  int rc = launch_layer_begin(c, st, layer, prec, norm_scope, h, x);
+                 const float* x, float* h_out, float* x_out, bool need_gscale) {
+  int rc = launch_layer_begin(c, st, layer, prec, norm_scope, h, x, need_gscale);
   if (rc) return rc;
   return launch_layer_end(c, st, layer, prec, norm_scope, h, x, h_out, x_out);
 }
@@ -1153,7 +1208,8 @@ int egcl_forward(egnn_ctx* c, void* stream, int layer, int prec, int norm_scope,
     set_error("bad egcl_forward arguments");
     return EGNN_EINVAL;
   }
-  return launch_layer(c, reinterpret_cast<hipStream_t>(stream), layer, prec, norm_scope, h, x, h_out, x_out);
+  // the single-layer entry keeps the per-graph sums of d^2 available for egcl_read_aggregates
+  return launch_layer(c, reinterpret_cast<hipStream_t>(stream), layer, prec, norm_scope, h, x, h_out, x_out, true);
 }
 
 int egcl_forward_begin(egnn_ctx* c, void* stream, int layer, int prec, int norm_scope, const float* h, const float* x,
@@ -1162,7 +1218,7 @@ int egcl_forward_begin(egnn_ctx* c, void* stream, int layer, int prec, int norm_
   if (rc) return rc;
   if (layer < 0 || layer >= c->L || !h || !x) { set_error("bad egcl_forward_begin arguments"); return EGNN_EINVAL; }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if ((rc = launch_layer_begin(c, st, layer, prec, norm_scope, h, x))) return rc;
+  if ((rc = launch_layer_begin(c, st, layer, prec, norm_scope, h, x, true))) return rc;
   if (d_sq_sums)
     EGNN_HIP(hipMemcpyAsync(d_sq_sums, c->gscale, sizeof(float) * (norm_scope == EGNN_NORM_GRAPH ? c->B : 1),
                             hipMemcpyDeviceToDevice, st));
@@ -1181,6 +1237,7 @@ int egcl_forward_end(egnn_ctx* c, void* stream, int layer, int prec, int norm_sc
   if (d_sq_sums)
     EGNN_HIP(hipMemcpyAsync(c->gscale, d_sq_sums, sizeof(float) * (norm_scope == EGNN_NORM_GRAPH ? c->B : 1),
                             hipMemcpyDeviceToDevice, st));
+  c->sq_from_agg = false;
   return launch_layer_end(c, st, layer, prec, norm_scope, h, x, h_out, x_out);
 }
 

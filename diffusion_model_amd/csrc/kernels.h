@@ -58,6 +58,30 @@ __host__ __device__ inline size_t edge_smem_bytes(int R, int MP) {
 }
 
 
+// Sum of d^2 over the edges node n receives, as left by the v4 edge kernels in component 3 of the coordinate sums
+// (column-split copy 0): the node's own slot when all its edges sit in one tile, else its tile partials in tile order.
+__device__ __forceinline__ float node_sq_sum(int n, const int* __restrict__ row_ptr, int R, const float* __restrict__ agg_x,
+                                             const float* __restrict__ part_x) {
+  const int rp0 = row_ptr[n], rp1 = row_ptr[n + 1];
+  if (rp1 <= rp0) return 0.f;
+  const int t0 = rp0 / R, t1 = (rp1 - 1) / R;
+  if (t0 == t1) return agg_x[(size_t)n * 4 + 3];
+  float v = part_x[((size_t)t0 * 2 + 1) * 4 + 3];
+  for (int t = t0 + 1; t <= t1; ++t) v += part_x[((size_t)t * 2) * 4 + 3];
+  return v;
+}
+// Sum over the nodes [lo, hi) of one graph by an aligned group of 8 lanes (g8 = lane's index in the group): every
+// group that sums the same graph produces the same bits (fixed stride, fixed butterfly order).
+__device__ __forceinline__ float graph_sq_sum8(int lo, int hi, int g8, const int* __restrict__ row_ptr, int R,
+                                               const float* __restrict__ agg_x, const float* __restrict__ part_x) {
+  float s = 0.f;
+  for (int m = lo + g8; m < hi; m += 8) s += node_sq_sum(m, row_ptr, R, agg_x, part_x);
+  s += __shfl_xor(s, 1);
+  s += __shfl_xor(s, 2);
+  s += __shfl_xor(s, 4);
+  return s;
+}
+
 // ---- helpers shared by the bf16 edge kernels ---------------------------------------------------------
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
@@ -173,6 +197,9 @@ struct PostParams {
   const float *h, *x;
   const int *row_ptr, *node_graph;
   const float *agg_m, *agg_x, *part_m, *part_x, *gscale;
+  const int* graph_ptr;   // [B+1]
+  int sq_from_agg;        // 1: the per-graph sums of d^2 are taken from component 3 of the coordinate sums (v4 edge
+                          //    kernels) by node_post itself; 0: gscale holds them
   size_t agg_x_stride, part_x_stride;
   int nsplit_x;   // column-split copies of the coordinate sums to add
   int per_graph;
@@ -190,6 +217,12 @@ int launch_edge_bf16_v2(const EdgeParams& p, int tiles, hipStream_t st);
 int launch_edge_bf16_v3(const EdgeParams& p, hipStream_t st);
 bool edge_bf16_v3_supported(const EdgeParams& p);
 int edge_v3_rows();
+int launch_edge_bf16_v4(const EdgeParams& p, hipStream_t st);
+int launch_edge_bf16_v4_m(const EdgeParams& p, hipStream_t st);
+int launch_edge_bf16_v3_x(const EdgeParams& p, hipStream_t st);
+bool edge_bf16_v4_supported(const EdgeParams& p);
+int edge_v4_rows();
+int init_edge_bf16_v4_attributes();
 int init_edge_bf16_v2_attributes();
 int init_edge_bf16_v3_attributes();
 bool edge_bf16_v2_supported(const EdgeParams& p);

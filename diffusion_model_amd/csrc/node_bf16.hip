@@ -56,6 +56,39 @@ __global__ __launch_bounds__(kThreadsN) void node_post_bf16_kernel(const PostPar
     dst[0] = (__bf16)v[0];
     dst[1] = (__bf16)v[1];
   }
+  // normaliser G^2 = sum of d^2 over the edges of the node's graph (:64), from component 3 of the coordinate sums.
+  // Small graphs (<= 64 nodes): 8 lanes per node.  Larger graphs: the whole workgroup sums each distinct graph of its
+  // 32 nodes (a latency-bound loop of dependent loads otherwise).  Either way every workgroup that needs a graph's
+  // sum adds the same values in the same order: the result is bitwise the same everywhere.
+  float* gsq = reinterpret_cast<float*>(smem + nb_smem_bytes(p.K1Q, p.HP / 32));   // [kNodes] then [kThreadsN] scratch
+  if (p.sq_from_agg) {
+    float* red = gsq + kNodes;
+    const int node = tid >> 3, n = n0 + node;
+    int g = -1, lo = 0, hi = 0;
+    if (n < p.N) { g = p.node_graph[n]; lo = p.graph_ptr[g]; hi = p.graph_ptr[g + 1]; }
+    if (g >= 0 && hi - lo <= 64) {
+      const float sq = graph_sq_sum8(lo, hi, tid & 7, p.row_ptr, p.R, p.agg_x, p.part_x);
+      if ((tid & 7) == 0) gsq[node] = sq;
+    }
+    const int nlast = min(n0 + kNodes, p.N) - 1;
+    const int g_first = p.node_graph[n0], g_last = p.node_graph[nlast];
+    for (int gg = g_first; gg <= g_last; ++gg) {          // workgroup-uniform loop over the distinct graphs
+      const int glo = p.graph_ptr[gg], ghi = p.graph_ptr[gg + 1];
+      if (ghi - glo <= 64) continue;
+      float sacc = 0.f;
+      for (int m = glo + tid; m < ghi; m += kThreadsN) sacc += node_sq_sum(m, p.row_ptr, p.R, p.agg_x, p.part_x);
+      red[tid] = sacc;
+      __syncthreads();
+      for (int w = kThreadsN / 2; w > 0; w >>= 1) {
+        if (tid < w) red[tid] += red[tid + w];
+        __syncthreads();
+      }
+      const float tot = red[0];
+      __syncthreads();
+      if (g == gg && (tid & 7) == 0) gsq[node] = tot;
+    }
+    __syncthreads();
+  }
   // coordinate update
   if (tid < kNodes * 3) {
     const int node = tid / 3, d = tid % 3, n = n0 + node;
@@ -74,7 +107,8 @@ __global__ __launch_bounds__(kThreadsN) void node_post_bf16_kernel(const PostPar
           }
         }
       }
-      const float g = 1.0f / (sqrtf(p.gscale[p.per_graph ? p.node_graph[n] : 0]) + 1.0f);
+      const float sq = p.sq_from_agg ? gsq[node] : p.gscale[p.per_graph ? p.node_graph[n] : 0];
+      const float g = 1.0f / (sqrtf(sq) + 1.0f);
       p.x_out[3 * n + d] = p.x[3 * n + d] + v * g;
     }
   }
@@ -164,12 +198,12 @@ int init_node_bf16_attributes() {
 
 bool node_post_bf16_supported(const PostParams& q) {
   return q.w1h_bf16 && q.w2h_bf16p && q.WhP % 128 == 0 && q.HP / 32 <= kPostMaxOB && q.K1Q / 16 <= kMaxKS1 &&
-         nb_smem_bytes(q.K1Q, q.HP / 32) <= 160 * 1024;
+         nb_smem_bytes(q.K1Q, q.HP / 32) + (kNodes + kThreadsN) * 4 <= 160 * 1024;
 }
 
 int launch_node_post_bf16(const PostParams& q, hipStream_t st) {
   hipLaunchKernelGGL(node_post_bf16_kernel, dim3((q.N + kNodes - 1) / kNodes), dim3(kThreadsN),
-                     nb_smem_bytes(q.K1Q, q.HP / 32), st, q);
+                     nb_smem_bytes(q.K1Q, q.HP / 32) + (kNodes + kThreadsN) * 4, st, q);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }

@@ -116,7 +116,8 @@ struct StepParams {
   uint64_t seed;
   const int* graph_ptr;
   const float* table;   // [(T+1)][4]
-  const int* t_dev;     // current t (device-resident loop); null -> t_imm (caller-driven loop)
+  int* t_dev;           // current t (device-resident loop); null -> t_imm (caller-driven loop)
+  unsigned* ticket;     // arrival counter of the step kernel's workgroups (device-resident loop)
   const int* t0_dev;    // t at the start of the run (indexes explicit noise)
   int t_imm;
   const float* noise_pos;  // [steps][N][3] or null
@@ -180,9 +181,19 @@ __global__ __launch_bounds__(kThreads) void sampler_step_kernel(const StepParams
     p.h[(size_t)n * p.H + p.H - 1] = tnext;
   }
   if (bad) p.bad[g] = 1;
+  // t <- t - 1 by the workgroup that finishes last: by then every workgroup has read t (no launch of its own)
+  if (p.t_dev) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      if (atomicAdd(p.ticket, 1u) == gridDim.x - 1) {
+        *p.ticket = 0u;
+        *p.t_dev = t - 1;
+      }
+    }
+  }
 }
 
-__global__ void advance_t_kernel(int* t_dev) { if (*t_dev > 0) *t_dev -= 1; }
 __global__ void set_int_kernel(int* dst, int v, int* dst2, int v2) { *dst = v; if (dst2) *dst2 = v2; }
 
 // x_T, h_T ~ N(0, I), positions mean-removed per graph (:301-305); h = [scale*x | cond | 1.0]
@@ -274,6 +285,7 @@ static StepParams make_params(egnn_ctx* c) {
   StepParams p;
   p.N = c->N; p.H = c->H; p.A = s.A; p.T = s.T; p.scale = s.onehot_scale; p.seed = s.seed;
   p.graph_ptr = c->graph_ptr; p.table = s.d_table; p.t_dev = s.t_dev; p.t0_dev = s.t_dev + 1;
+  p.ticket = reinterpret_cast<unsigned*>(s.t_dev + 2);
   p.noise_pos = nullptr; p.noise_h = nullptr; p.h_out = s.h_out; p.x_out = s.x_out; p.pos = s.pos; p.h = s.h;
   p.bad = s.bad; p.t_imm = 0;
   return p;
@@ -292,15 +304,29 @@ static int enqueue_step(egnn_ctx* c, hipStream_t st, int prec, int norm_scope, c
   StepParams p = make_params(c);
   p.noise_pos = npos; p.noise_h = nh;
   hipLaunchKernelGGL(sampler_step_kernel, dim3(c->B), dim3(kThreads), 0, st, p);
-  hipLaunchKernelGGL(advance_t_kernel, dim3(1), dim3(1), 0, st, s.t_dev);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }
 
 static void graph_free(Sampler& s) {
-  if (s.graph_exec) { (void)hipGraphExecDestroy(s.graph_exec); s.graph_exec = nullptr; }
-  if (s.graph) { (void)hipGraphDestroy(s.graph); s.graph = nullptr; }
+  for (int i = 0; i < 2; ++i) {
+    if (s.graph_exec[i]) { (void)hipGraphExecDestroy(s.graph_exec[i]); s.graph_exec[i] = nullptr; }
+    if (s.graph[i]) { (void)hipGraphDestroy(s.graph[i]); s.graph[i] = nullptr; }
+  }
   s.graph_prec = s.graph_norm = -1;
+}
+
+// hipGraph of `nsteps` consecutive reverse steps (the step index lives in device memory, so one graph serves any t)
+static int graph_build(egnn_ctx* c, hipStream_t st, int prec, int norm_scope, int slot, int nsteps) {
+  Sampler& s = c->smp;
+  EGNN_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+  int rc = EGNN_OK;
+  for (int i = 0; i < nsteps && !rc; ++i) rc = enqueue_step(c, st, prec, norm_scope, nullptr, nullptr);
+  hipError_t e = hipStreamEndCapture(st, &s.graph[slot]);
+  if (rc) return rc;
+  if (e != hipSuccess) { set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return EGNN_EHIP; }
+  EGNN_HIP(hipGraphInstantiate(&s.graph_exec[slot], s.graph[slot], nullptr, nullptr, 0));
+  return EGNN_OK;
 }
 
 }  // namespace egnn
@@ -363,7 +389,7 @@ static int ext_params(StepParams& p, int N, int H, int A, int B, int T, const in
     return EGNN_EINVAL;
   }
   p.N = N; p.H = H; p.A = A; p.T = T; p.scale = scale; p.seed = seed; p.graph_ptr = graph_ptr; p.table = table;
-  p.t_dev = nullptr; p.t0_dev = nullptr; p.t_imm = 0; p.noise_pos = nullptr; p.noise_h = nullptr;
+  p.t_dev = nullptr; p.t0_dev = nullptr; p.ticket = nullptr; p.t_imm = 0; p.noise_pos = nullptr; p.noise_h = nullptr;
   p.h_out = nullptr; p.x_out = nullptr; p.pos = pos; p.h = h; p.bad = bad;
   return EGNN_OK;
 }
@@ -480,7 +506,8 @@ int egnn_sampler_prepare(egnn_ctx* c, int T, int A, float onehot_scale, const fl
   EGNN_HIP(hipMalloc((void**)&s.h, N * c->H * sizeof(float)));
   EGNN_HIP(hipMalloc((void**)&s.h_out, N * c->H * sizeof(float)));
   EGNN_HIP(hipMalloc((void**)&s.x_out, N * 3 * sizeof(float)));
-  EGNN_HIP(hipMalloc((void**)&s.t_dev, 4 * sizeof(int)));
+  EGNN_HIP(hipMalloc((void**)&s.t_dev, 4 * sizeof(int)));   // {t, t at the start of the run, arrival ticket, -}
+  EGNN_HIP(hipMemset(s.t_dev, 0, 4 * sizeof(int)));
   EGNN_HIP(hipMalloc((void**)&s.bad, (size_t)c->B * sizeof(int)));
   EGNN_HIP(hipMemset(s.bad, 0, (size_t)c->B * sizeof(int)));
   s.T = T; s.A = A; s.onehot_scale = onehot_scale; s.seed = seed; s.d_table = d_table; s.t = T;
@@ -520,17 +547,19 @@ int egnn_sampler_run(egnn_ctx* c, void* stream, int prec, int norm_scope, int ns
   if (use_graph) {
     if (st == nullptr) { set_error("hipGraph replay needs a non-default stream"); return EGNN_EINVAL; }
     if (c->prof) { set_error("disable profiling events before graph replay"); return EGNN_ESTATE; }
-    if (!s.graph_exec || s.graph_prec != prec || s.graph_norm != norm_scope) {
+    if (s.graph_prec != prec || s.graph_norm != norm_scope) {
       graph_free(s);
-      EGNN_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
-      rc = enqueue_step(c, st, prec, norm_scope, nullptr, nullptr);
-      hipError_t e = hipStreamEndCapture(st, &s.graph);
-      if (rc) { graph_free(s); return rc; }
-      if (e != hipSuccess) { set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); graph_free(s); return EGNN_EHIP; }
-      EGNN_HIP(hipGraphInstantiate(&s.graph_exec, s.graph, nullptr, nullptr, 0));
       s.graph_prec = prec; s.graph_norm = norm_scope;
     }
-    for (int i = 0; i < nsteps; ++i) EGNN_HIP(hipGraphLaunch(s.graph_exec, st));
+    // one replay = kGraphSteps reverse steps (a replay costs the host ~10-16 us: amortised over 8 steps), single
+    // steps for the remainder
+    int left = nsteps;
+    for (int slot = 1; slot >= 0; --slot) {
+      const int per = slot ? kGraphSteps : 1;
+      if (left < per) continue;
+      if (!s.graph_exec[slot] && (rc = graph_build(c, st, prec, norm_scope, slot, per))) { graph_free(s); return rc; }
+      for (; left >= per; left -= per) EGNN_HIP(hipGraphLaunch(s.graph_exec[slot], st));
+    }
   } else {
     for (int i = 0; i < nsteps; ++i)
       if ((rc = enqueue_step(c, st, prec, norm_scope, d_noise_pos, d_noise_h))) return rc;

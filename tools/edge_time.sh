@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 for spec in "$@"; do
   lib=${spec%%:*}; d=${spec##*:}
   if [ "$lib" = "base" ]; then unset EGNN_LIB; else export EGNN_LIB=$GRAFT_REPO_ROOT/diffusion_model_amd/exp_$lib.so; fi
-  rm -rf /tmp/pp; EGNN_EDGE=${EDGE:-3} EGNN_DEBUG=$d rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pp -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+  rm -rf /tmp/pp; EGNN_EDGE=${EDGE:-4} EGNN_DEBUG=$d rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pp -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --reps 1 --no-cpu-baseline --no-train-leg --no-slab-leg --no-latency-leg > /dev/null 2>&1
   python3 - "$spec" <<'PY'
 import csv,glob,sys
 for f in glob.glob('/tmp/pp/**/*kernel_stats.csv', recursive=True):
