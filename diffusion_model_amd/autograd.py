@@ -21,11 +21,12 @@ Math (reference EquivariantGraphNeuralNetwork.py:55-71), per edge e = (i <- j):
 """
 from __future__ import annotations
 
+import math
+import os
+
 import torch
 
 from . import _lib
-
-import os
 
 EDGE_CHUNK = int(os.environ.get("EGNN_BWD_CHUNK", 1 << 19))   # edges per backward chunk (workspace = 6 bf16 [chunk, W] buffers)
 
@@ -71,8 +72,10 @@ def _wgrad(g, a, n_pad, splits):
     return torch.bmm(gv.transpose(1, 2), av).float().sum(0)
 
 
-def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_S, g_h, g_x, grads):
-    """adds the edge part's contributions to g_h, g_x and to the parameter gradients in `grads`"""
+def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_S, g_h, g_x, grads, fused=None):
+    """adds the edge part's contributions to g_h, g_x and to the parameter gradients in `grads`.
+    ``fused`` = (context handle, layer index) when the bf16 recompute runs on the forward's own MFMA edge kernels
+    (egcl_backward_edge_recompute) instead of l1_act -> GEMM -> heads."""
     L = _lib.lib()
     st = _lib.stream_ptr()
     P = _lib.ptr
@@ -105,6 +108,8 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_
     g_am, g_ax = g_am.contiguous(), g_ax.contiguous()
     E = dst32.numel()
     rows = ws.s1x.shape[0]
+    if fused is not None:
+        _lib.check(L.egcl_backward_table(fused[0], st, fused[1], P(h)))
     for a in range(0, E, rows):
         n = min(rows, E - a)
         n_pad = _round_up(n, 64)
@@ -115,13 +120,19 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_
             for t in (ws.s1x, ws.s1m, ws.a2x, ws.a2m, ws.g1x, ws.g1m, ws.inp):
                 t[n:n_pad].zero_()
         _lib.check(L.egcl_backward_gather_in(st, prec, n, H, K1P, P(d32), P(s32), P(h), P(x), P(inp), P(d2)))
-        _lib.check(L.egcl_backward_l1_act(st, prec, n, Wx, P(d32), P(s32), P(Px), P(Qx), P(wdx), P(d2), P(s1x)))
-        _lib.check(L.egcl_backward_l1_act(st, prec, n, Wm, P(d32), P(s32), P(Pm), P(Qm), P(wdm), P(d2), P(s1m)))
-        torch.mm(s1x, w2x.t(), out=a2x)
-        torch.mm(s1m, w2m.t(), out=a2m)
-        _lib.check(L.egcl_backward_heads(st, prec, n, Wx, M, P(d32), P(s32), P(x), P(g_ax), P(g_am), P(a2x), P(a2m),
-                                         P(b2x), P(w3), P(b3), P(b2m), P(wa), P(ba), P(g_diff), P(g_b2x), P(g_w3),
-                                         P(g_b3), P(g_b2m), P(g_wa), P(g_ba)))
+        if fused is not None:
+            # s1 (scaled by -log2 e), dL/da2, g_diff and the bias / w3 / wa column sums in one pass of the MFMA edge kernels
+            _lib.check(L.egcl_backward_edge_recompute(fused[0], st, fused[1], P(x), P(g_ax), P(g_am), a, n, P(s1x), P(s1m),
+                                                      P(a2x), P(a2m), P(g_diff), P(g_b2x), P(g_w3), P(g_b3), P(g_b2m),
+                                                      P(g_wa), P(g_ba)))
+        else:
+            _lib.check(L.egcl_backward_l1_act(st, prec, n, Wx, P(d32), P(s32), P(Px), P(Qx), P(wdx), P(d2), P(s1x)))
+            _lib.check(L.egcl_backward_l1_act(st, prec, n, Wm, P(d32), P(s32), P(Pm), P(Qm), P(wdm), P(d2), P(s1m)))
+            torch.mm(s1x, w2x.t(), out=a2x)
+            torch.mm(s1m, w2m.t(), out=a2m)
+            _lib.check(L.egcl_backward_heads(st, prec, n, Wx, M, P(d32), P(s32), P(x), P(g_ax), P(g_am), P(a2x), P(a2m),
+                                             P(b2x), P(w3), P(b3), P(b2m), P(wa), P(ba), P(g_diff), P(g_b2x), P(g_w3),
+                                             P(g_b3), P(g_b2m), P(g_wa), P(g_ba)))
         # a2x / a2m now hold dL/da2: wgrad and dgrad of the second Linear layers
         g_w2x += _wgrad(ws.a2x, ws.s1x, n_pad, 16)
         g_w2m += _wgrad(ws.a2m, ws.s1m, n_pad, 32)
@@ -136,6 +147,10 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_
         g_in.addmm_(g1m, w1m)
         _lib.check(L.egcl_backward_scatter(st, prec, n, H, K1P, P(d32), P(s32), P(x), P(g_in), P(g_diff), P(g_S),
                                            P(node_seg), P(g_h), P(g_x)))
+
+    if fused is not None:   # the recompute kernels store s1 as the MFMA consumed it: -log2(e) * SiLU(a1)
+        g_w2x *= -math.log(2.0)
+        g_w2m *= -math.log(2.0)
 
     def acc(p, g):
         grads[p] = grads.get(p, 0) + g.reshape(p.shape)
@@ -170,7 +185,7 @@ class _EGNNFunction(torch.autograd.Function):
                                               _lib.ptr(S)))
             saved += [hc, xc, sum_m, sum_x, S]
             hc, xc = ho, xo
-        ctx.layers, ctx.plan, ctx.scope, ctx.prec = layers, plan, scope, prec
+        ctx.layers, ctx.plan, ctx.scope, ctx.prec, ctx.egnn_ctx = layers, plan, scope, prec, c
         ctx.save_for_backward(*saved)
         return hc, xc
 
@@ -191,6 +206,13 @@ class _EGNNFunction(torch.autograd.Function):
         if E > 0:
             ws = _Workspace(min(EDGE_CHUNK, E), d0["H"], layers[0].mlp_x[0].out_features, layers[0].mlp_m[0].out_features, d0["M"],
                             torch.bfloat16 if prec == _lib.PREC_BF16 else torch.float32, gh.device)
+        # bf16 at the reference widths: the recompute half of the edge backward runs on the forward's MFMA edge kernels
+        c = ctx.egnn_ctx
+        use_fused = (E > 0 and prec == _lib.PREC_BF16 and os.environ.get("EGNN_BWD_FUSED", "1") != "0")
+        if use_fused:
+            c.set_graph(plan)
+            c.pack(layers)
+            use_fused = bool(_lib.lib().egcl_backward_fused_supported(c.handle))
         for l in reversed(range(len(layers))):
             layer = layers[l]
             h_l, x_l, sum_m, sum_x, S = saved[5 * l:5 * l + 5]
@@ -213,7 +235,8 @@ class _EGNNFunction(torch.autograd.Function):
                     grads[p] = grads.get(p, 0) + g
             # edge part
             if E > 0:
-                _edge_backward(layer, prec, ws, h_l, x_l, dst32, src32, node_seg, g_am, g_ax, g_S.contiguous(), g_h, g_x, grads)
+                _edge_backward(layer, prec, ws, h_l, x_l, dst32, src32, node_seg, g_am, g_ax, g_S.contiguous(), g_h, g_x, grads,
+                               fused=(c.handle, l) if use_fused else None)
             gh, gx = g_h, g_x
             red = ACTIVE_REDUCER
             if red is not None and id(layer) in red.bucket_of:

@@ -326,6 +326,19 @@ __global__ __launch_bounds__(kThreads) void bwd_scatter_kernel(int n_edges, int 
   }
 }
 
+// g_diff[e] = dL/d(sum_x[i]) * s_e with s_e = sum of the column-split shares the coordinate recompute kernels wrote
+__global__ void bwd_gdiff_kernel(int n_edges, int nsplit, const int* __restrict__ dst, const float* __restrict__ g_sum_x,
+                                 const float* __restrict__ s_halves, float* __restrict__ g_diff) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_edges) return;
+  float sv = 0.f;
+  for (int hs = 0; hs < nsplit; ++hs) sv += s_halves[(size_t)hs * n_edges + e];
+  const int i = dst[e];
+  g_diff[3 * (size_t)e] = g_sum_x[3 * i] * sv;
+  g_diff[3 * (size_t)e + 1] = g_sum_x[3 * i + 1] * sv;
+  g_diff[3 * (size_t)e + 2] = g_sum_x[3 * i + 2] * sv;
+}
+
 // ---- segment sums of the last edge pass, as dense per-node arrays --------------------------------------------
 __global__ __launch_bounds__(kThreads) void agg_export_kernel(int N, int M, int MP, int R, int nsplit_x,
                                                                const int* __restrict__ row_ptr,
@@ -383,6 +396,44 @@ int egcl_read_aggregates(egnn_ctx* c, void* stream, int norm_scope, float* sum_m
   EGNN_HIP(hipGetLastError());
   EGNN_HIP(hipMemcpyAsync(sq_sums, c->gscale, sizeof(float) * (norm_scope == EGNN_NORM_GRAPH ? c->B : 1),
                           hipMemcpyDeviceToDevice, st));
+  return EGNN_OK;
+}
+
+int egcl_backward_fused_supported(egnn_ctx* c) {
+  if (!c || c->L == 0 || c->N == 0) return 0;
+  return backward_recompute_supported(c);
+}
+
+int egcl_backward_table(egnn_ctx* c, void* stream, int layer, const float* h) {
+  if (!c || c->L == 0 || c->N == 0 || layer < 0 || layer >= c->L || !h) { set_error("bad egcl_backward_table arguments"); return EGNN_EINVAL; }
+  if (!c->layers[layer].packed) { set_error("layer %d has no packed parameters", layer); return EGNN_ESTATE; }
+  if (!backward_recompute_supported(c)) { set_error("fused backward recompute is not available for these widths"); return EGNN_EINVAL; }
+  return backward_table(c, reinterpret_cast<hipStream_t>(stream), layer, h);
+}
+
+int egcl_backward_edge_recompute(egnn_ctx* c, void* stream, int layer, const float* x, const float* g_sum_x,
+                                 const float* g_sum_m, int e_first, int n_edges, void* s1x, void* s1m, void* g_a2x,
+                                 void* g_a2m, float* g_diff, float* g_b2x, float* g_w3, float* g_b3, float* g_b2m,
+                                 float* g_wa, float* g_ba) {
+  if (!c || c->L == 0 || c->N == 0 || layer < 0 || layer >= c->L) { set_error("bad egcl_backward_edge_recompute context/layer"); return EGNN_EINVAL; }
+  if (e_first < 0 || n_edges < 0 || e_first + n_edges > c->E) { set_error("edge range [%d, %d) outside the graph", e_first, e_first + n_edges); return EGNN_EINVAL; }
+  if (n_edges == 0) return EGNN_OK;
+  if (!x || !g_sum_x || !g_sum_m || !s1x || !s1m || !g_a2x || !g_a2m || !g_diff || !g_b2x || !g_w3 || !g_b3 || !g_b2m ||
+      !g_wa || !g_ba) { set_error("bad egcl_backward_edge_recompute arguments"); return EGNN_EINVAL; }
+  if (!backward_recompute_supported(c)) { set_error("fused backward recompute is not available for these widths"); return EGNN_EINVAL; }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int nsplit = c->WxP >= 512 ? c->WxP / 512 : 1;
+  if ((size_t)nsplit * n_edges > c->cap_bwd_s) {
+    if (c->bwd_s) { (void)hipFree(c->bwd_s); c->bwd_s = nullptr; c->cap_bwd_s = 0; }
+    EGNN_HIP(hipMalloc(reinterpret_cast<void**>(&c->bwd_s), (size_t)nsplit * n_edges * sizeof(float)));
+    c->cap_bwd_s = (size_t)nsplit * n_edges;
+  }
+  int rc = backward_recompute(c, st, layer, x, g_sum_x, g_sum_m, e_first, n_edges, s1x, s1m, g_a2x, g_a2m, c->bwd_s, g_b2x,
+                              g_w3, g_b3, g_b2m, g_wa, g_ba);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bwd_gdiff_kernel, dim3((n_edges + 255) / 256), dim3(256), 0, st, n_edges, nsplit, c->edge_dst + e_first,
+                     g_sum_x, c->bwd_s, g_diff);
+  EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }
 

@@ -100,6 +100,8 @@ struct egnn_ctx {
   float* gscale = nullptr;   // [B] sum of d^2 per graph (G^2); node_post applies 1/(G+1)
   int last_R = 64, last_nsplit_x = 1;   // edge path chosen by the last launch_layer_begin
   bool sq_from_agg = false;             // node_post takes the d^2 sums from the coordinate sums' component 3
+  float* bwd_s = nullptr;    // [nsplit][chunk edges] column-split shares of s_e (backward recompute)
+  size_t cap_bwd_s = 0;
   unsigned long long* stamps = nullptr;  // [2 kernels][8 waves][32 chunks][4] diagnostic time stamps
   float* h_tmp[2] = {nullptr, nullptr};  // [N][H] ping-pong between layers
   float* x_tmp[2] = {nullptr, nullptr};  // [N][3]
@@ -116,4 +118,10 @@ int reserve(egnn_ctx* c);
 int launch_layer(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_scope, const float* h,
                  const float* x, float* h_out, float* x_out, bool need_gscale = false);
 int edge_rows_per_tile(int prec);
+// backward recompute on the forward's bf16 edge kernels (egcl_backward_edge_recompute)
+int backward_recompute_supported(egnn_ctx* c);
+int backward_table(egnn_ctx* c, hipStream_t st, int layer, const float* h);
+int backward_recompute(egnn_ctx* c, hipStream_t st, int layer, const float* x, const float* g_sum_x, const float* g_sum_m,
+                       int e_first, int n_edges, void* s1x, void* s1m, void* g_a2x, void* g_a2m, float* s_halves,
+                       float* g_b2x, float* g_w3, float* g_b3, float* g_b2m, float* g_wa, float* g_ba);
 }  // namespace egnn

@@ -51,7 +51,10 @@ __host__ __device__ inline size_t v3_smem_bytes(int KP, int MP, bool is_m) {
   return kOffA1 + (loop > msg ? loop : msg);
 }
 
-template <int CB, bool IS_M>
+// BWD = true: the training backward's recompute pass over a chunk of edges (egcl_backward_edge_recompute).  Same
+// prologue and K loop; the activation chunks are also written to HBM (s1_out: the wgrad of mlp_x.2 needs them as a GEMM
+// operand over ALL edges), and the epilogue turns the accumulators into dL/d(a2) instead of segment sums.
+template <int CB, bool IS_M, bool BWD = false>
 __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* s_dst = reinterpret_cast<int*>(smem + kOffDst);
@@ -129,6 +132,8 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
     s_diff[tid] = dx; s_diff[kR3 + tid] = dy; s_diff[2 * kR3 + tid] = dz;
     const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);  // norm(...)**2 as in the reference (:56)
     s_d2[tid] = nrm * nrm;
+    if constexpr (BWD && !IS_M)   // dL/ds_e = dL/d(sum_x[i]) . (x_i - x_j)   (:64, xm = (x_i - x_j) * s)
+      s_gseg[tid] = tid < nvalid ? (p.g_sum_x[3 * d] * dx + p.g_sum_x[3 * d + 1] * dy + p.g_sum_x[3 * d + 2] * dz) : 0.f;
   }
   {
     const float* wd = IS_M ? p.wdm : p.wdx;
@@ -191,12 +196,21 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[rb][cb][i] = 0.f;
 
+  // backward: the activation chunk also goes to HBM, 16 bytes per thread, 128 contiguous bytes per row and chunk
+  // (the column-split coordinate workgroups build the same activations: only share 0 stores them)
+  auto s1_store = [&](const bf16x8 o0, const bf16x8 o1, const int c) {
+    if (half != 0) return;
+    __bf16* base = static_cast<__bf16*>(p.s1_out) + (size_t)e0 * KP + c * kKC3 + kg * 8;
+    if (brow < nvalid) *reinterpret_cast<bf16x8*>(base + (size_t)brow * KP) = o0;
+    if (brow + 64 < nvalid) *reinterpret_cast<bf16x8*>(base + (size_t)(brow + 64) * KP) = o1;
+  };
   {  // chunk 0
     UnitH u;
     unith_load(u, rs_tab, vdst0, vsrc0, offP, offQ);
-    unith_finish(u, s_wd + kg * 8, d2r0, slot0);
+    const bf16x8 o0 = unith_finish(u, s_wd + kg * 8, d2r0, slot0);
     unith_load(u, rs_tab, vdst1, vsrc1, offP, offQ);
-    unith_finish(u, s_wd + kg * 8, d2r1, slot1);
+    const bf16x8 o1 = unith_finish(u, s_wd + kg * 8, d2r1, slot1);
+    if constexpr (BWD) s1_store(o0, o1, 0);
   }
   bf16x8 bq[4][CB];   // weight fragments of the 4 k-steps of the current chunk
 #pragma unroll
@@ -291,11 +305,12 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
     const size_t nbuf = (size_t)(c & 1) * kA1_3;
     // vector work wins issue arbitration over the partner wave's MFMAs (which only need 1 slot in 4)
     __builtin_amdgcn_s_setprio(3);
-    unith_finish(x0, s_wd + c * kKC3 + kg * 8, d2r0, slot0 + nbuf);
+    const bf16x8 o0 = unith_finish(x0, s_wd + c * kKC3 + kg * 8, d2r0, slot0 + nbuf);
     STAMP2(c - 1, 1, wave >= 4);
-    unith_finish(x1, s_wd + c * kKC3 + kg * 8, d2r1, slot1 + nbuf);
+    const bf16x8 o1 = unith_finish(x1, s_wd + c * kKC3 + kg * 8, d2r1, slot1 + nbuf);
     STAMP2(c - 1, 2, wave >= 4);
     __builtin_amdgcn_s_setprio(0);
+    if constexpr (BWD) s1_store(o0, o1, c);
   };
   STAMP(30, 2);   // chunk 0 built, first weights requested
   RSTAMP(31, 1);
@@ -379,7 +394,66 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
   // row of value index q (q = rb*16 + reg) for this lane
   auto row_of = [&](int q) { return 32 * (q >> 4) + acc_row(q & 15, lane); };
 
-  if constexpr (!IS_M) {
+  if constexpr (BWD && !IS_M) {
+    // ---- backward of the mlp_x head (:62-65): s = w3 . SiLU(a2) + b3, dL/da2[e][n] = dL/ds_e * w3[n] * SiLU'(a2[e][n]) ----
+    const float* s_gsc = s_gseg;
+    float part[64];
+#pragma unroll
+    for (int q = 0; q < 64; ++q) part[q] = 0.f;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+      const int n = 32 * (colblk0 + cb) + r;
+      const float bb = p.b2x[n], w3n = p.w3x[n] * kNegLog2e;   // packed vectors carry the -log2(e) / -1/log2(e) scales
+      float cs_b = 0.f, cs_w = 0.f;
+#pragma unroll
+      for (int rb = 0; rb < kRB3; ++rb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float sv, ds;
+          silu_grad_s(fmaf(acc[rb][cb][i], kNegLog2e, bb), sv, ds);
+          part[rb * 16 + i] = fmaf(w3n, sv, part[rb * 16 + i]);
+          const float gsc = s_gsc[32 * rb + acc_row(i, lane)];
+          const float g = gsc * w3n * ds;
+          cs_b += g;
+          cs_w = fmaf(gsc, sv, cs_w);
+          acc[rb][cb][i] = g;
+        }
+      cs_b += __shfl_xor(cs_b, 32);
+      cs_w += __shfl_xor(cs_w, 32);
+      if (hh == 0) { atomicAdd(p.g_col_a + n, cs_b); atomicAdd(p.g_col_b + n, cs_w); }   // g_b2x, g_w3
+    }
+    {
+      float lo[32], hi[32];
+#pragma unroll
+      for (int q = 0; q < 32; ++q) { lo[q] = part[q]; hi[q] = part[32 + q]; }
+      const float t0 = butterfly32(lo, lane), t1 = butterfly32(hi, lane);
+      s_part[wave * kR3 + row_of(r)] = t0;
+      s_part[wave * kR3 + 64 + row_of(r)] = t1;
+    }
+    __syncthreads();   // also: every wave is done with the K-loop buffers (reused as store staging below)
+    if (tid < kR3) {
+      float v = half == 0 ? p.scal[0] : 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v += s_part[w * kR3 + tid];
+      if (tid < nvalid) p.s_half_out[(size_t)half * p.E + e0 + tid] = v;
+    }
+    if (half == 0 && wave == 2) {   // g_b3 = sum over edges of dL/ds
+      float v = s_gsc[lane] + s_gsc[lane + 64];
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+      if (lane == 0) atomicAdd(p.g_scalar, v);
+    }
+    // dL/da2 as row-major bf16, 16-byte stores through a per-wave LDS transpose
+    __bf16* stg = reinterpret_cast<__bf16*>(s_a1) + (size_t)wave * 32 * 72;
+    __bf16* gout = static_cast<__bf16*>(p.g_a2_out) + (size_t)e0 * p.WxP + 32 * colblk0;
+#pragma unroll
+    for (int rb = 0; rb < kRB3; ++rb) {
+      f32x16 blk[2];
+      blk[0] = acc[rb][0];
+      blk[1] = acc[rb][CB - 1];
+      store_block_bf16(blk, CB, stg, gout + (size_t)(32 * rb) * p.WxP, (size_t)p.WxP, nvalid - 32 * rb, lane);
+    }
+  } else if constexpr (!IS_M) {
     // ---- mlp_x epilogue: s[row] = [b3] + sum_n w3[n] * SiLU(acc + b2[n]) over this workgroup's columns ----
     float part[64];
 #pragma unroll
@@ -529,9 +603,9 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
   STAMP(31, 0);   // epilogue done
 }
 
-template <int CB, bool IS_M>
+template <int CB, bool IS_M, bool BWD = false>
 int launch_v3(const EdgeParams& p, int blocks, size_t smem, hipStream_t st) {
-  hipLaunchKernelGGL((edge_kernel_bf16_v3<CB, IS_M>), dim3(blocks), dim3(kT3), smem, st, p);
+  hipLaunchKernelGGL((edge_kernel_bf16_v3<CB, IS_M, BWD>), dim3(blocks), dim3(kT3), smem, st, p);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }
@@ -544,6 +618,10 @@ int init_edge_bf16_v3_attributes() {
   EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v3<1, false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v3<1, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v3<2, false, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v3<1, false, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   return EGNN_OK;
 }
@@ -561,6 +639,15 @@ int launch_edge_bf16_v3_x(const EdgeParams& p, hipStream_t st) {
   const int tiles = (p.E + kR3 - 1) / kR3;
   if (p.WxP >= 512) return launch_v3<2, false>(p, tiles * (p.WxP / 512), v3_smem_bytes(p.WxP, p.MP, false), st);
   return launch_v3<1, false>(p, tiles, v3_smem_bytes(p.WxP, p.MP, false), st);
+}
+
+// backward recompute of the coordinate branch over the chunk of edges described by p (p.E edges, p.edge_dst / p.edge_src
+// already offset to the chunk)
+int launch_edge_bf16_v3_x_bwd(const EdgeParams& p, hipStream_t st) {
+  const int tiles = (p.E + kR3 - 1) / kR3;
+  static_assert(8 * 32 * 72 * 2 <= 2 * kA1_3 + 1024 * 4, "store staging must fit the K-loop buffers");
+  if (p.WxP >= 512) return launch_v3<2, false, true>(p, tiles * (p.WxP / 512), v3_smem_bytes(p.WxP, p.MP, false), st);
+  return launch_v3<1, false, true>(p, tiles, v3_smem_bytes(p.WxP, p.MP, false), st);
 }
 
 int launch_edge_bf16_v3(const EdgeParams& p, hipStream_t st) {

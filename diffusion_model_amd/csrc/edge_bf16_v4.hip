@@ -66,8 +66,10 @@ __host__ __device__ inline size_t v4_smem_bytes(int KP, int MP, bool is_m) {
 #ifndef EGNN_V4_M_WAVES
 #define EGNN_V4_M_WAVES 3   // waves per SIMD the message kernel is compiled for (4 would allow two workgroups per CU, but spills)
 #endif
-template <int CB, bool IS_M>
-__global__ __launch_bounds__(kT3, (IS_M ? EGNN_V4_M_WAVES : 2)) void edge_kernel_bf16_v4(const EdgeParams p) {
+// BWD = true (message kernel): the training backward's recompute pass over a chunk of edges: the activation chunks are
+// also written to HBM (s1_out) and the epilogue produces dL/d(a2m) through the gate instead of the segment sums.
+template <int CB, bool IS_M, bool BWD = false>
+__global__ __launch_bounds__(kT3, ((IS_M && !BWD) ? EGNN_V4_M_WAVES : 2)) void edge_kernel_bf16_v4(const EdgeParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* s_dst = reinterpret_cast<int*>(smem + kOffDst);
   int* s_src = reinterpret_cast<int*>(smem + kOffSrc);
@@ -212,12 +214,24 @@ __global__ __launch_bounds__(kT3, (IS_M ? EGNN_V4_M_WAVES : 2)) void edge_kernel
     unith_load(u, rs_tab, vd, vs, offP + kb, offQ + kb);
   };
   // chunks 0 and 1 are built up front (ring slots 0 and 1)
+  // backward: the activation chunk also goes to HBM, 16 bytes per thread, 128 contiguous bytes per row and chunk
+  auto s1_store = [&](const bf16x8 ov, const int row, const int c) {
+    if (half != 0) return;
+    if (row < nvalid)
+      *reinterpret_cast<bf16x8*>(static_cast<__bf16*>(p.s1_out) + (size_t)(e0 + row) * KP + c * kKC3 + kg * 8) = ov;
+  };
   uload(u0, vdst0, vsrc0, 0); uload(u1, vdst1, vsrc1, 0);
-  unith_finish(u0, s_wd + kg * 8, d2r0, slot0);
-  unith_finish(u1, s_wd + kg * 8, d2r1, slot1);
+  {
+    const bf16x8 o0 = unith_finish(u0, s_wd + kg * 8, d2r0, slot0);
+    const bf16x8 o1 = unith_finish(u1, s_wd + kg * 8, d2r1, slot1);
+    if constexpr (BWD) { s1_store(o0, brow, 0); s1_store(o1, brow + 64, 0); }
+  }
   uload(u0, vdst0, vsrc0, 1); uload(u1, vdst1, vsrc1, 1);
-  unith_finish(u0, s_wd + kKC3 + kg * 8, d2r0, slot0 + kA1_3);
-  unith_finish(u1, s_wd + kKC3 + kg * 8, d2r1, slot1 + kA1_3);
+  {
+    const bf16x8 o0 = unith_finish(u0, s_wd + kKC3 + kg * 8, d2r0, slot0 + kA1_3);
+    const bf16x8 o1 = unith_finish(u1, s_wd + kKC3 + kg * 8, d2r1, slot1 + kA1_3);
+    if constexpr (BWD) { s1_store(o0, brow, 1); s1_store(o1, brow + 64, 1); }
+  }
   uload(u0, vdst0, vsrc0, 2); uload(u1, vdst1, vsrc1, 2);
   bf16x8 bq[4][CB];   // weight fragments of the 4 k-steps of the current chunk
 #pragma unroll
@@ -273,8 +287,10 @@ __global__ __launch_bounds__(kT3, (IS_M ? EGNN_V4_M_WAVES : 2)) void edge_kernel
       if ((Q) == 6) { _Pragma("unroll") for (int k = 0; k < 4; ++k) pu[k] = pu[k] * pe[k]; }                  \
       if ((Q) == 7) {                                                                                         \
         _Pragma("unroll") for (int k = 0; k < 4; ++k) o[e0_ + k] = (__bf16)pu[k];                             \
-        if ((S) == 1) { *reinterpret_cast<bf16x8*>(slot0 + off_wr) = o; uload(u0, vdst0, vsrc0, c + 3); }     \
-        if ((S) == 3) { *reinterpret_cast<bf16x8*>(slot1 + off_wr) = o; uload(u1, vdst1, vsrc1, c + 3); }     \
+        if ((S) == 1) { *reinterpret_cast<bf16x8*>(slot0 + off_wr) = o; uload(u0, vdst0, vsrc0, c + 3);       \
+                        if constexpr (BWD) s1_store(o, brow, c + 2); }                                        \
+        if ((S) == 3) { *reinterpret_cast<bf16x8*>(slot1 + off_wr) = o; uload(u1, vdst1, vsrc1, c + 3);       \
+                        if constexpr (BWD) s1_store(o, brow + 64, c + 2); }                                   \
       }                                                                                                       \
     }
 #define GROUP(S, RB)                                                                                          \
@@ -338,7 +354,74 @@ __global__ __launch_bounds__(kT3, (IS_M ? EGNN_V4_M_WAVES : 2)) void edge_kernel
   // row of value index q (q = rb*16 + reg) for this lane
   auto row_of = [&](int q) { return 32 * (q >> 4) + acc_row(q & 15, lane); };
 
-  if constexpr (!IS_M) {
+  if constexpr (BWD && IS_M) {
+    // ---- backward of the message head (:57-60): m = SiLU(a2), z = wa . m + ba, gate = sigmoid(z), out = m * gate;
+    //      with g = dL/d(sum_m[i]):  dL/dm = g * gate + (g . m) gate (1 - gate) wa,  dL/da2 = dL/dm * SiLU'(a2) ----
+    static_assert(!(BWD && IS_M) || CB == 1, "message epilogue assumes one 32-column block per wave");
+    const int ncol = 32 * wave + r;
+    const float bb = p.b2m[ncol], wan = p.wa[ncol] * kNegLog2e;   // packed vectors carry the -log2(e) / -1/log2(e) scales
+    const float* gm = p.g_sum_m + ncol;
+    // pass 1: row sums z = wa . m and d = g . m (two halves of 64 rows to bound the live registers)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      float vz[32], vd[32];
+#pragma unroll
+      for (int q = 0; q < 32; ++q) {
+        const int rb = 2 * hf + (q >> 4), i = q & 15, row = 32 * rb + acc_row(i, lane);
+        float m, ds;
+        silu_grad_s(fmaf(acc[rb][0][i], kNegLog2e, bb), m, ds);
+        vz[q] = wan * m;
+        vd[q] = gm[(size_t)s_dst[row] * p.MP] * m;
+      }
+      const float tz = butterfly32(vz, lane), td = butterfly32(vd, lane);
+      s_part[wave * kR3 + 64 * hf + row_of(r)] = tz;
+      s_gseg[wave * kR3 + 64 * hf + row_of(r)] = td;
+    }
+    __syncthreads();
+    if (tid < kR3) {
+      float z = p.scal[1], d = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { z += s_part[w * kR3 + tid]; d += s_gseg[w * kR3 + tid]; }
+      const float gate = sigmoid_f(z);
+      const bool valid = tid < nvalid;
+      s_val[tid] = gate;
+      s_d2[tid] = valid ? d * gate * (1.0f - gate) : 0.f;   // coef (the geometry is no longer needed)
+    }
+    __syncthreads();
+    if (wave == 2) {   // g_ba = sum over edges of coef
+      float v = s_d2[lane] + s_d2[lane + 64];
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+      if (lane == 0) atomicAdd(p.g_scalar, v);
+    }
+    // pass 2: dL/da2, column sums, store
+    float cs_b = 0.f, cs_w = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < kRB3; ++rb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = 32 * rb + acc_row(i, lane);
+        float m, ds;
+        silu_grad_s(fmaf(acc[rb][0][i], kNegLog2e, bb), m, ds);
+        const float coef = s_d2[row];
+        const float g = row < nvalid ? fmaf(gm[(size_t)s_dst[row] * p.MP], s_val[row], coef * wan) * ds : 0.f;
+        cs_b += g;
+        cs_w = fmaf(coef, m, cs_w);
+        acc[rb][0][i] = g;
+      }
+    cs_b += __shfl_xor(cs_b, 32);
+    cs_w += __shfl_xor(cs_w, 32);
+    if (hh == 0) { atomicAdd(p.g_col_a + ncol, cs_b); atomicAdd(p.g_col_b + ncol, cs_w); }   // g_b2m, g_wa
+    __bf16* stg = reinterpret_cast<__bf16*>(s_a1) + (size_t)wave * 32 * 72;
+    __bf16* gout = static_cast<__bf16*>(p.g_a2_out) + (size_t)e0 * p.MP + 32 * wave;
+#pragma unroll
+    for (int rb = 0; rb < kRB3; ++rb) {
+      f32x16 blk[2];
+      blk[0] = acc[rb][0];
+      blk[1] = acc[rb][0];
+      store_block_bf16(blk, 1, stg, gout + (size_t)(32 * rb) * p.MP, (size_t)p.MP, nvalid - 32 * rb, lane);
+    }
+  } else if constexpr (!IS_M) {
     // ---- mlp_x epilogue: s[row] = [b3] + sum_n w3[n] * SiLU(acc + b2[n]) over this workgroup's columns ----
     float part[64];
 #pragma unroll
@@ -473,9 +556,9 @@ __global__ __launch_bounds__(kT3, (IS_M ? EGNN_V4_M_WAVES : 2)) void edge_kernel
   STAMP(31, 0);   // epilogue done
 }
 
-template <int CB, bool IS_M>
+template <int CB, bool IS_M, bool BWD = false>
 int launch_v4(const EdgeParams& p, int blocks, size_t smem, hipStream_t st) {
-  hipLaunchKernelGGL((edge_kernel_bf16_v4<CB, IS_M>), dim3(blocks), dim3(kT3), smem, st, p);
+  hipLaunchKernelGGL((edge_kernel_bf16_v4<CB, IS_M, BWD>), dim3(blocks), dim3(kT3), smem, st, p);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }
@@ -489,6 +572,8 @@ int init_edge_bf16_v4_attributes() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v4<1, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v4<1, true, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   return EGNN_OK;
 }
 
@@ -498,6 +583,13 @@ bool edge_bf16_v4_supported(const EdgeParams& p) {
   return (p.WxP == 256 || p.WxP == 512 || p.WxP == 1024) && p.MP == 256 && p.WmP % 64 == 0 &&
          v4_smem_bytes(p.WmP, p.MP, true) <= 160 * 1024 && v4_smem_bytes(p.WxP, p.MP, false) <= 160 * 1024 &&
          (size_t)p.N * p.TC * 4 < ((size_t)1 << 32);
+}
+
+// backward recompute of the message branch over the chunk of edges described by p
+int launch_edge_bf16_v4_m_bwd(const EdgeParams& p, hipStream_t st) {
+  const int tiles = (p.E + kR3 - 1) / kR3;
+  static_assert(8 * 32 * 72 * 2 <= kRing * kA1_3, "store staging must fit the K-loop buffers");
+  return launch_v4<1, true, true>(p, tiles, v4_smem_bytes(p.WmP, p.MP, true), st);
 }
 
 // message kernel only

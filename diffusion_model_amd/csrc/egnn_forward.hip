@@ -835,20 +835,11 @@ static int launch_edge(const EdgeParams& p, int tiles, size_t smem, hipStream_t 
   return EGNN_OK;
 }
 
-// Stage 1 of a layer: node_pre, squared-distance sums and the fused edge pass.  gsum (c->gscale) then holds the
-// sum of d^2 over the edges THIS context received, per graph (or per call).
-int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_scope, const float* h,
-                       const float* x, bool need_gscale) {
+// EdgeParams of layer `layer` over the graph set on the context (unscaled parameter vectors, fp32 / bf16 fragments)
+static void fill_edge_params(egnn_ctx* c, int layer, int prec, const float* x, EdgeParams& p) {
   const LayerPack& lp = c->layers[layer];
-  if (!lp.packed) { set_error("layer %d has no packed parameters", layer); return EGNN_ESTATE; }
-  const int N = c->N, E = c->E;
-  int R = edge_rows_per_tile(prec), nsplit_x = 1;
-  const size_t agg_x_stride = (size_t)c->cap_nodes * 4, part_x_stride = (c->cap_tiles + 1) * 2 * 4;
-  const int per_graph = norm_scope == EGNN_NORM_GRAPH;
-
-  // choose the edge path first: the bf16 fast kernels consume the pre-scaled first-layer table
-  EdgeParams p;
-  p.N = N; p.E = E;
+  memset(&p, 0, sizeof(p));
+  p.N = c->N; p.E = c->E;
   p.edge_dst = c->edge_dst; p.edge_src = c->edge_src; p.row_ptr = c->row_ptr;
   p.x = x; p.table = c->table;
   p.TC = c->TC; p.WxP = c->WxP; p.WmP = c->WmP; p.MP = c->MP; p.cbx = c->cbx; p.cbm = c->cbm;
@@ -857,12 +848,87 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
   p.w2x = prec == EGNN_PREC_BF16 ? lp.w2x_bf16 : (const void*)lp.w2x_f32;
   p.w2m = prec == EGNN_PREC_BF16 ? lp.w2m_bf16 : (const void*)lp.w2m_f32;
   p.agg_m = c->agg_m; p.agg_x = c->agg_x; p.part_m = c->part_m; p.part_x = c->part_x;
-  p.agg_x_stride = agg_x_stride; p.part_x_stride = part_x_stride;
+  p.agg_x_stride = (size_t)c->cap_nodes * 4; p.part_x_stride = (c->cap_tiles + 1) * 2 * 4;
   p.stamps = c->stamps;
-  {
-    static const int dbg = getenv("EGNN_DEBUG") ? atoi(getenv("EGNN_DEBUG")) : 0;
-    p.dbg = dbg;
+  static const int dbg = getenv("EGNN_DEBUG") ? atoi(getenv("EGNN_DEBUG")) : 0;
+  p.dbg = dbg;
+}
+// the bf16 fast kernels (v2..v4) use the copies pre-scaled by -log2(e) / -1/log2(e) (LayerPack::sc)
+static void use_scaled_pack(egnn_ctx* c, int layer, EdgeParams& p, const float*& w1catT, const float*& b1cat) {
+  const LayerPack& lp = c->layers[layer];
+  const float* o = lp.sc;
+  w1catT = o; o += (size_t)c->H * c->TC;
+  b1cat = o; o += c->TC;
+  p.wdx = o; o += c->WxP;
+  p.wdm = o; o += c->WmP;
+  p.b2x = o; o += c->WxP;
+  p.w3x = o; o += c->WxP;
+  p.b2m = o; o += c->MP;
+  p.wa = o;
+  p.w2x = lp.w2x_bf16s; p.w2m = lp.w2m_bf16s;
+}
+// first-layer table of the v3 / v4 kernels (fp16, pre-scaled) for node features h
+static int launch_node_pre_f16(egnn_ctx* c, hipStream_t st, const float* h, const float* w1catT, const float* b1cat) {
+  const int N = c->N;
+  if (c->H <= 64) {
+    dim3 grid((N + kPre2Nodes - 1) / kPre2Nodes, (c->TC + kPre2Cols - 1) / kPre2Cols);
+    const size_t sm = (size_t)((c->H + 1) & ~1) * 33 * sizeof(float);
+    const size_t sm16 = (size_t)kPre2Nodes * (kPre2Cols + 8) * 2;   // output staging tile of the fp16 variant
+    hipLaunchKernelGGL(node_pre_mfma_kernel<_Float16>, grid, dim3(kThreads), sm > sm16 ? sm : sm16, st, h, N, c->H,
+                       w1catT, b1cat, c->TC, reinterpret_cast<_Float16*>(c->table));
+  } else {
+    dim3 grid((N + kPreNodes - 1) / kPreNodes, (c->TC + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL(node_pre_kernel<_Float16>, grid, dim3(kThreads), (size_t)kPreNodes * c->H * sizeof(float), st, h, N,
+                       c->H, w1catT, b1cat, c->TC, reinterpret_cast<_Float16*>(c->table));
   }
+  EGNN_HIP(hipGetLastError());
+  return EGNN_OK;
+}
+
+// Backward recompute (bf16 fast path), see egcl_backward_edge_recompute in include/egnn_amd.h
+int backward_recompute_supported(egnn_ctx* c) {
+  EdgeParams p;
+  fill_edge_params(c, 0, EGNN_PREC_BF16, nullptr, p);
+  return edge_bf16_v4_supported(p) && edge_bf16_v3_supported(p) && c->Wx == c->WxP && c->Wm == c->WmP && c->M == c->MP;
+}
+int backward_table(egnn_ctx* c, hipStream_t st, int layer, const float* h) {
+  EdgeParams p;
+  fill_edge_params(c, layer, EGNN_PREC_BF16, nullptr, p);
+  const float *w1catT, *b1cat;
+  use_scaled_pack(c, layer, p, w1catT, b1cat);
+  return launch_node_pre_f16(c, st, h, w1catT, b1cat);
+}
+int backward_recompute(egnn_ctx* c, hipStream_t st, int layer, const float* x, const float* g_sum_x, const float* g_sum_m,
+                       int e_first, int n_edges, void* s1x, void* s1m, void* g_a2x, void* g_a2m, float* s_halves,
+                       float* g_b2x, float* g_w3, float* g_b3, float* g_b2m, float* g_wa, float* g_ba) {
+  EdgeParams p;
+  fill_edge_params(c, layer, EGNN_PREC_BF16, x, p);
+  const float *w1catT, *b1cat;
+  use_scaled_pack(c, layer, p, w1catT, b1cat);
+  p.edge_dst = c->edge_dst + e_first; p.edge_src = c->edge_src + e_first; p.E = n_edges;
+  p.g_sum_x = g_sum_x; p.g_sum_m = g_sum_m;
+  p.s1_out = s1x; p.g_a2_out = g_a2x; p.s_half_out = s_halves;
+  p.g_col_a = g_b2x; p.g_col_b = g_w3; p.g_scalar = g_b3;
+  int rc = launch_edge_bf16_v3_x_bwd(p, st);
+  if (rc) return rc;
+  p.s1_out = s1m; p.g_a2_out = g_a2m; p.s_half_out = nullptr;
+  p.g_col_a = g_b2m; p.g_col_b = g_wa; p.g_scalar = g_ba;
+  return launch_edge_bf16_v4_m_bwd(p, st);
+}
+
+// Stage 1 of a layer: node_pre, squared-distance sums and the fused edge pass.  gsum (c->gscale) then holds the
+// sum of d^2 over the edges THIS context received, per graph (or per call).
+int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_scope, const float* h,
+                       const float* x, bool need_gscale) {
+  const LayerPack& lp = c->layers[layer];
+  if (!lp.packed) { set_error("layer %d has no packed parameters", layer); return EGNN_ESTATE; }
+  const int N = c->N, E = c->E;
+  int R = edge_rows_per_tile(prec), nsplit_x = 1;
+  const int per_graph = norm_scope == EGNN_NORM_GRAPH;
+
+  // choose the edge path first: the bf16 fast kernels consume the pre-scaled first-layer table
+  EdgeParams p;
+  fill_edge_params(c, layer, prec, x, p);
   static const int edge_sel = getenv("EGNN_EDGE") ? atoi(getenv("EGNN_EDGE")) : 4;   // A/B switch: 1, 2, 3 or 4
   int path = 1;
   if (prec == EGNN_PREC_BF16 && edge_sel >= 4 && edge_bf16_v4_supported(p) && edge_bf16_v3_supported(p)) path = 4;
@@ -870,18 +936,7 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
   else if (prec == EGNN_PREC_BF16 && edge_sel >= 2 && edge_bf16_v2_supported(p)) path = 2;
   const float* w1catT = lp.w1catT;
   const float* b1cat = lp.b1cat;
-  if (path >= 2) {
-    const float* o = lp.sc;
-    w1catT = o; o += (size_t)c->H * c->TC;
-    b1cat = o; o += c->TC;
-    p.wdx = o; o += c->WxP;
-    p.wdm = o; o += c->WmP;
-    p.b2x = o; o += c->WxP;
-    p.w3x = o; o += c->WxP;
-    p.b2m = o; o += c->MP;
-    p.wa = o;
-    p.w2x = lp.w2x_bf16s; p.w2m = lp.w2m_bf16s;
-  }
+  if (path >= 2) use_scaled_pack(c, layer, p, w1catT, b1cat);
 
   prof_begin(c, st, 1);
   {
@@ -1050,7 +1105,7 @@ int egnn_destroy(egnn_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   for (auto& lp : c->layers) free_layer(lp);
-  void* ptrs[] = {c->table, c->agg_m, c->agg_x, c->part_m, c->part_x, c->node_d2, c->gscale,
+  void* ptrs[] = {c->table, c->agg_m, c->agg_x, c->part_m, c->part_x, c->node_d2, c->gscale, c->bwd_s,
                   c->h_tmp[0], c->h_tmp[1], c->x_tmp[0], c->x_tmp[1]};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);

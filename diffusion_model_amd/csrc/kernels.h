@@ -44,6 +44,13 @@ struct EdgeParams {
   size_t agg_x_stride, part_x_stride;  // elements between the column-split copies of agg_x / part_x
   unsigned long long* stamps;  // diagnostic builds only (EGNN_EXP_STAMP): s_memtime stamps of one workgroup
   int dbg;  // timing experiments only (EGNN_DEBUG): bit0 drop weight loads, bit1 drop table loads
+  // ---- backward recompute variants only (BWD = true instantiations; edges = a chunk [0, E) of the caller's edge list) ----
+  const float* g_sum_x;   // [N][3]  dL/d(sum_x), already multiplied by 1/(G+1)
+  const float* g_sum_m;   // [N][MP] dL/d(sum_m)
+  void* s1_out;           // bf16 [E][KP]: first-layer activations as the MFMA consumed them (scaled by -log2(e))
+  void* g_a2_out;         // bf16 [E][WxP] (coordinate kernel) / [E][MP] (message kernel): dL/d(second-layer pre-activation)
+  float* s_half_out;      // coordinate kernel: [nsplit][E] this workgroup's share of s_e = w3 . SiLU(a2) (+ b3 in share 0)
+  float *g_col_a, *g_col_b, *g_scalar;   // column sums: {g_b2x, g_w3, g_b3} / {g_b2m, g_wa, g_ba} (atomic adds)
 };
 
 // layout helper used by both host (size) and device (carve): ints/floats 12*R*4 bytes, then 2 A1
@@ -178,7 +185,7 @@ __device__ __forceinline__ void unith_load(UnitH& u, rsrc_t tab, unsigned vdst, 
   u.p = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(tab, vdst, __builtin_amdgcn_readfirstlane(sP), 0));
   u.q = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(tab, vsrc, __builtin_amdgcn_readfirstlane(sQ), 0));
 }
-__device__ __forceinline__ void unith_finish(const UnitH& u, const float* wd, float d2, char* slot) {
+__device__ __forceinline__ bf16x8 unith_finish(const UnitH& u, const float* wd, float d2, char* slot) {
   const f32x4 w0 = *reinterpret_cast<const f32x4*>(wd), w1 = *reinterpret_cast<const f32x4*>(wd + 4);
   const f16x8 t = u.p + u.q;
   bf16x8 o;
@@ -188,6 +195,36 @@ __device__ __forceinline__ void unith_finish(const UnitH& u, const float* wd, fl
     o[j + 4] = (__bf16)silu_s(fmaf(w1[j], d2, (float)t[j + 4]));
   }
   *reinterpret_cast<bf16x8*>(slot) = o;
+  return o;
+}
+
+// ---- backward recompute: the second-layer nonlinearity and its derivative from the MFMA accumulator ----------------
+// t2 = -log2(e) * a2 (scaled pre-activation incl. bias).  s = SiLU(a2), ds = SiLU'(a2) = sig + s * (1 - sig).
+__device__ __forceinline__ void silu_grad_s(float t2, float& s, float& ds) {
+  const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t2));
+  s = (t2 * kNegInvLog2e) * sg;
+  ds = fmaf(s, 1.0f - sg, sg);
+}
+// Store one wave's 32-row x 64-column block of an accumulator-layout tile as row-major bf16 with 16-byte accesses:
+// v[cb][i] = value of (row acc_row(i, lane), column 32 cb + (lane & 31)); stg = this wave's [32][72] bf16 LDS scratch;
+// out = address of (row 0, column 0) of the block in a row-major bf16 array with `ld` columns; rows >= nrows are skipped.
+__device__ __forceinline__ void store_block_bf16(const f32x16 (&v)[2], int ncb, __bf16* stg, __bf16* out, size_t ld, int nrows,
+                                                 int lane) {
+  const int r = lane & 31;
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+    if (cb < ncb) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) stg[acc_row(i, lane) * 72 + 32 * cb + r] = (__bf16)v[cb][i];
+    }
+  __builtin_amdgcn_wave_barrier();
+  const int pieces = 32 * (ncb * 4);   // 16-byte pieces: ncb*4 per row
+  for (int q = lane; q < pieces; q += 64) {
+    const int row = q / (ncb * 4), seg = q - row * (ncb * 4);
+    if (row < nrows)
+      *reinterpret_cast<bf16x8*>(out + (size_t)row * ld + 8 * seg) = *reinterpret_cast<const bf16x8*>(stg + row * 72 + 8 * seg);
+  }
+  __builtin_amdgcn_wave_barrier();
 }
 
 constexpr int kPostMaxOB = 8;  // output column blocks of node_post (H <= 256)
@@ -220,6 +257,8 @@ int edge_v3_rows();
 int launch_edge_bf16_v4(const EdgeParams& p, hipStream_t st);
 int launch_edge_bf16_v4_m(const EdgeParams& p, hipStream_t st);
 int launch_edge_bf16_v3_x(const EdgeParams& p, hipStream_t st);
+int launch_edge_bf16_v3_x_bwd(const EdgeParams& p, hipStream_t st);
+int launch_edge_bf16_v4_m_bwd(const EdgeParams& p, hipStream_t st);
 bool edge_bf16_v4_supported(const EdgeParams& p);
 int edge_v4_rows();
 int init_edge_bf16_v4_attributes();

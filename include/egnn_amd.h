@@ -142,6 +142,23 @@ int egcl_backward_scatter(void* stream, int prec, int n_edges, int H, int K1P, c
                           const int32_t* d_src, const float* d_x, const void* d_g_in, const float* d_g_diff,
                           const float* d_g_sq_sums, const int32_t* d_node_segment, float* d_g_h, float* d_g_x);
 
+/* Fused first half of the chain above for the bf16 fast path (reference widths: hidden 256 / 512 / 1024, m = 256, unpadded):
+ * one pass of the forward's own MFMA edge kernels in "backward" mode replaces gather/l1_act -> GEMM -> heads.  For the
+ * edges [e_first, e_first + n_edges) of the graph set on ctx it recomputes SiLU(P[dst] + Q[src] + wd d2) (fp16 table built
+ * by egcl_backward_table from the layer's input h) and the second-layer products exactly as the forward did, and writes
+ *   s1x [n_edges, Wx], s1m [n_edges, Wm]  bf16, the activations AS THE MFMA CONSUMED THEM: scaled by -log2(e) (multiply the
+ *                                         wgrad g_a2^T . s1 by -ln 2),
+ *   g_a2x [n_edges, Wx], g_a2m [n_edges, M]  bf16 = dL/d(second-layer pre-activation) (what egcl_backward_heads leaves),
+ *   g_diff [n_edges, 3] and the column sums ADDED to g_b2x, g_w3, g_b3, g_b2m, g_wa, g_ba, as egcl_backward_heads does.
+ * g_sum_x [N,3] must already carry the 1/(G+1) factor; g_sum_m is [N, M].  egcl_backward_fused_supported = 1 if the
+ * context's model takes this path. */
+int egcl_backward_fused_supported(egnn_ctx* ctx);
+int egcl_backward_table(egnn_ctx* ctx, void* stream, int layer, const float* d_h);
+int egcl_backward_edge_recompute(egnn_ctx* ctx, void* stream, int layer, const float* d_x, const float* d_g_sum_x,
+                                 const float* d_g_sum_m, int e_first, int n_edges, void* d_s1x, void* d_s1m,
+                                 void* d_g_a2x, void* d_g_a2m, float* d_g_diff, float* d_g_b2x, float* d_g_w3,
+                                 float* d_g_b3, float* d_g_b2m, float* d_g_wa, float* d_g_ba);
+
 /* EquivariantGNN.forward(edge_index, h, x) -> (h_L, x_L) (:85-88): all L layers. */
 int egnn_forward(egnn_ctx* ctx, void* stream, int prec, int norm_scope,
                  const float* d_h, const float* d_x, float* d_h_out, float* d_x_out);
