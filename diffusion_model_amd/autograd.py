@@ -136,10 +136,14 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_
         # a2x / a2m now hold dL/da2: wgrad and dgrad of the second Linear layers
         g_w2x += _wgrad(ws.a2x, ws.s1x, n_pad, 16)
         g_w2m += _wgrad(ws.a2m, ws.s1m, n_pad, 32)
-        torch.mm(a2x, w2x, out=g1x)
-        torch.mm(a2m, w2m, out=g1m)
-        _lib.check(L.egcl_backward_l1_grad(st, prec, n, Wx, P(d32), P(s32), P(Px), P(Qx), P(wdx), P(d2), P(g1x)))
-        _lib.check(L.egcl_backward_l1_grad(st, prec, n, Wm, P(d32), P(s32), P(Pm), P(Qm), P(wdm), P(d2), P(g1m)))
+        if fused is not None:
+            # dgrad of the second layers with SiLU'(a1) in the epilogue, on MFMA (no [n, W] round trip in between)
+            _lib.check(L.egcl_backward_dgrad(fused[0], st, fused[1], P(x), a, n, P(a2x), P(a2m), P(g1x), P(g1m)))
+        else:
+            torch.mm(a2x, w2x, out=g1x)
+            torch.mm(a2m, w2m, out=g1m)
+            _lib.check(L.egcl_backward_l1_grad(st, prec, n, Wx, P(d32), P(s32), P(Px), P(Qx), P(wdx), P(d2), P(g1x)))
+            _lib.check(L.egcl_backward_l1_grad(st, prec, n, Wm, P(d32), P(s32), P(Pm), P(Qm), P(wdm), P(d2), P(g1m)))
         # first Linear layers: wgrad against in = [h_i | h_j | d2 | 1], dgrad back to the gathered inputs
         g_w1x += _wgrad(ws.g1x, ws.inp, n_pad, 32)
         g_w1m += _wgrad(ws.g1m, ws.inp, n_pad, 32)

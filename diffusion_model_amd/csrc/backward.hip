@@ -437,6 +437,16 @@ int egcl_backward_edge_recompute(egnn_ctx* c, void* stream, int layer, const flo
   return EGNN_OK;
 }
 
+int egcl_backward_dgrad(egnn_ctx* c, void* stream, int layer, const float* x, int e_first, int n_edges, const void* g_a2x,
+                        const void* g_a2m, void* g_a1x, void* g_a1m) {
+  if (!c || c->L == 0 || c->N == 0 || layer < 0 || layer >= c->L) { set_error("bad egcl_backward_dgrad context/layer"); return EGNN_EINVAL; }
+  if (e_first < 0 || n_edges < 0 || e_first + n_edges > c->E) { set_error("edge range [%d, %d) outside the graph", e_first, e_first + n_edges); return EGNN_EINVAL; }
+  if (n_edges == 0) return EGNN_OK;
+  if (!x || !g_a2x || !g_a2m || !g_a1x || !g_a1m) { set_error("bad egcl_backward_dgrad arguments"); return EGNN_EINVAL; }
+  if (!backward_recompute_supported(c)) { set_error("fused backward is not available for these widths"); return EGNN_EINVAL; }
+  return backward_dgrad(c, reinterpret_cast<hipStream_t>(stream), layer, x, e_first, n_edges, g_a2x, g_a2m, g_a1x, g_a1m);
+}
+
 static int bwd_l1(void* stream, int prec, int grad, int n_edges, int C, const int32_t* dst, const int32_t* src,
                   const float* P, const float* Q, const float* wd, const float* d2, void* buf) {
   if (n_edges < 0 || C <= 0 || (n_edges > 0 && (!dst || !src || !P || !Q || !wd || !d2 || !buf))) {

@@ -53,6 +53,8 @@ struct LayerPack {
   float* sc = nullptr;       // [w1catT_s | b1cat_s | wdx_s | wdm_s | b2x_s | w3x_s | b2m_s | wa_s]
   void* w2x_bf16s = nullptr;
   void* w2m_bf16s = nullptr;
+  void* w2xT_bf16 = nullptr;  // mlp_x.2 TRANSPOSED bf16 fragments for the backward dgrad (k = output n, column = hidden k)
+  void* w2mT_bf16 = nullptr;  // mlp_m.2 transposed (K = MP, N = WmP)
   void* w1h_bf16 = nullptr;   // mlp_h.0 bf16 fragments (N = WhP, K = K1Q)
   void* w2h_bf16p = nullptr;  // mlp_h.2 bf16 fragments, k in accumulator-row order
 };
@@ -124,4 +126,9 @@ int backward_table(egnn_ctx* c, hipStream_t st, int layer, const float* h);
 int backward_recompute(egnn_ctx* c, hipStream_t st, int layer, const float* x, const float* g_sum_x, const float* g_sum_m,
                        int e_first, int n_edges, void* s1x, void* s1m, void* g_a2x, void* g_a2m, float* s_halves,
                        float* g_b2x, float* g_w3, float* g_b3, float* g_b2m, float* g_wa, float* g_ba);
+int backward_dgrad(egnn_ctx* c, hipStream_t st, int layer, const float* x, int e_first, int n_edges, const void* g_a2x,
+                   const void* g_a2m, void* g_a1x, void* g_a1m);
+int init_edge_dgrad_attributes();
+int launch_edge_dgrad(int N, int E, const int* dst, const int* src, const float* x, const void* table, int TC, int offP, int offQ,
+                      const float* wd, const void* g_a2, int Kd, const void* w2t, int KP, void* g_a1_out, hipStream_t st);
 }  // namespace egnn

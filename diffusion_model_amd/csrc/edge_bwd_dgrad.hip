@@ -1,0 +1,204 @@
+// Training backward, second half of the edge chain on MFMA (gfx950): dgrad of the second Linear layers fused with the
+// first layer's SiLU derivative,
+//
+//     dL/da1[e][k] = ( sum_n dL/da2[e][n] * W2[n][k] ) * SiLU'(a1[e][k]),     a1 = P[dst e] + Q[src e] + wd * d2_e
+//
+// for mlp_x (n, k < Wx) and mlp_m (n < M, k < Wm) (reference EquivariantGraphNeuralNetwork.py:13-25 under autograd).
+// It replaces  GEMM (g_a2 . W2) -> egcl_backward_l1_grad : the [edges, W] gradient is written once, already multiplied.
+//
+// Same tiling as the forward edge kernels: 128 edges x 512 output columns per workgroup (8 wave64, 4 x 2 accumulator
+// tiles of 32 x 32 per wave), 64-deep K chunks.  The A operand is dL/da2 as the recompute kernels left it (row-major bf16):
+// every thread copies two 16-byte pieces per chunk HBM -> registers -> LDS fragment image (no vector arithmetic at all in
+// the K loop), through the 3-deep ring of edge_bf16_v4.hip: chunk c is multiplied while chunk c+2 is written and chunk c+3
+// is in flight; the B operand streams from W2 packed TRANSPOSED (k = second-layer output n, column = hidden unit k).
+// Epilogue: SiLU'(a1) from the forward's fp16 first-layer table (two 2-byte gathers per element, 64 contiguous bytes per
+// half-wave), product, row-major bf16 store through the per-wave LDS transpose.
+#include "kernels.h"
+
+namespace egnn {
+namespace {
+
+constexpr int kTD = 512, kRD = 128, kRBD = 4, kRPADD = kRD + 1, kKCD = 64;
+constexpr size_t kA1D = (size_t)8 * kRPADD * 16;   // one A chunk [8 k-groups][129][8 bf16]
+constexpr int kRingD = 3;
+constexpr size_t kOffDstD = 0;                      // int[R]
+constexpr size_t kOffSrcD = kOffDstD + kRD * 4;     // int[R]
+constexpr size_t kOffD2D = kOffSrcD + kRD * 4;      // float[R]
+constexpr size_t kOffA1D = kOffD2D + kRD * 4;       // ring
+constexpr size_t kSmemD = kOffA1D + kRingD * kA1D;
+
+struct DgradParams {
+  int N, E;                 // nodes; edges of the chunk
+  const int *edge_dst, *edge_src;
+  const float* x;           // [N][3]
+  const void* table;        // fp16 [N][TC] (scaled by -log2 e)
+  int TC, offP, offQ;       // table columns of this MLP's P / Q blocks
+  const float* wd;          // [KP] scaled
+  const void* g_a2;         // bf16 [E][Kd]
+  int Kd;                   // reduction length (second-layer outputs)
+  const void* w2t;          // bf16 fragments, transposed pack [KP/32][Kd/16][64][8]
+  int KP;                   // output columns (hidden units of the first layer)
+  void* g_a1_out;           // bf16 [E][KP]
+};
+
+template <int CB>
+__global__ __launch_bounds__(kTD, 2) void edge_dgrad_kernel(const DgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* s_dst = reinterpret_cast<int*>(smem + kOffDstD);
+  int* s_src = reinterpret_cast<int*>(smem + kOffSrcD);
+  float* s_d2 = reinterpret_cast<float*>(smem + kOffD2D);
+  char* s_a1 = smem + kOffA1D;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int nsplit = p.KP / (256 * CB);
+  const int j = xcd_tile(blockIdx.x, gridDim.x);
+  const int tile = j / nsplit, half = j - tile * nsplit;
+  const int e0 = tile * kRD;
+  const int nvalid = min(kRD, p.E - e0);
+  if (tid < kRD) {
+    int d = 0, s = 0;
+    float dd = 0.f;
+    if (tid < nvalid) {
+      d = p.edge_dst[e0 + tid];
+      s = p.edge_src[e0 + tid];
+      const float dx = p.x[3 * d] - p.x[3 * s], dy = p.x[3 * d + 1] - p.x[3 * s + 1], dz = p.x[3 * d + 2] - p.x[3 * s + 2];
+      const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);   // norm(...)**2 as in the forward (:56)
+      dd = nrm * nrm;
+    }
+    s_dst[tid] = d; s_src[tid] = s; s_d2[tid] = dd;
+  }
+  const int NC = p.Kd / kKCD, KS = p.Kd / 16;
+  const int brow = tid >> 3, kg = tid & 7;   // this thread copies rows brow and brow + 64, k-group kg of every chunk
+  const rsrc_t rs_g = make_rsrc(p.g_a2, (unsigned)((size_t)p.E * p.Kd * 2));   // rows past the chunk read as zero
+  const rsrc_t rs_w = make_rsrc(p.w2t, (unsigned)((size_t)p.KP * p.Kd * 2));
+  const unsigned vrow0 = (unsigned)(e0 + brow) * (unsigned)p.Kd * 2u + (unsigned)kg * 16u;
+  const unsigned vrow1 = vrow0 + 64u * (unsigned)p.Kd * 2u;
+  char* slot0 = s_a1 + ((size_t)kg * kRPADD + brow) * 16;
+  char* slot1 = slot0 + 64 * 16;
+  const unsigned lane16 = lane * 16u;
+  const unsigned lds_a1_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(s_a1 + ((size_t)hh * kRPADD + r) * 16);
+  const int colblk0 = half * 8 * CB + wave * CB;
+  const unsigned w0off = (unsigned)colblk0 * KS * 1024u;
+
+  f32x16 acc[kRBD][CB];
+#pragma unroll
+  for (int rb = 0; rb < kRBD; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[rb][cb][i] = 0.f;
+
+  auto gload = [&](const unsigned vrow, const int cq) {
+    const int c = cq < NC ? cq : NC - 1;   // past the end: a harmless repeat of the last chunk
+    return ldbuf_bf16x8(rs_g, vrow, (unsigned)c * kKCD * 2u);
+  };
+  bf16x8 g0 = gload(vrow0, 0), g1 = gload(vrow1, 0);
+  *reinterpret_cast<bf16x8*>(slot0) = g0;
+  *reinterpret_cast<bf16x8*>(slot1) = g1;
+  g0 = gload(vrow0, 1); g1 = gload(vrow1, 1);
+  *reinterpret_cast<bf16x8*>(slot0 + kA1D) = g0;
+  *reinterpret_cast<bf16x8*>(slot1 + kA1D) = g1;
+  g0 = gload(vrow0, 2); g1 = gload(vrow1, 2);
+  bf16x8 bq[4][CB];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) bq[s][cb] = ldbuf_bf16x8(rs_w, lane16, w0off + ((unsigned)cb * KS + s) * 1024u);
+  __syncthreads();
+
+  unsigned off_cur = 0u, off_nxt = (unsigned)kA1D, off_wr = 2u * (unsigned)kA1D;
+  bf16x8 a[kRBD];
+#define LDS_RD(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(off))
+#define LDS_WAIT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
+  LDS_RD(a[0], lds_a1_base, 0); LDS_RD(a[1], lds_a1_base, 512); LDS_RD(a[2], lds_a1_base, 1024); LDS_RD(a[3], lds_a1_base, 1536);
+
+  auto chunk = [&](const int c, const bool copy, const bool last) {
+    const unsigned abase = lds_a1_base + off_cur, nbase = lds_a1_base + off_nxt;
+#define GROUP(S, RB)                                                                                          \
+    {                                                                                                         \
+      if (!last || (S) < 3 || (RB) == 0) LDS_WAIT(3);                                                         \
+      else if ((RB) == 1) LDS_WAIT(2);                                                                        \
+      else if ((RB) == 2) LDS_WAIT(1);                                                                        \
+      else LDS_WAIT(0);                                                                                       \
+      asm volatile("" : "+v"(a[RB]));                                                                         \
+      _Pragma("unroll") for (int cb = 0; cb < CB; ++cb)                                                       \
+        acc[RB][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[RB], bq[S][cb], acc[RB][cb], 0, 0, 0);        \
+      if ((S) < 3) LDS_RD(a[RB], abase, ((S) + 1) * 4128 + (RB) * 512);                                       \
+      else if (!last) LDS_RD(a[RB], nbase, (RB) * 512);                                                       \
+    }
+#define KSTEP(S)                                                                                              \
+    GROUP(S, 0) GROUP(S, 1) GROUP(S, 2) GROUP(S, 3)                                                           \
+    if (copy && (S) == 1) { *reinterpret_cast<bf16x8*>(slot0 + off_wr) = g0; g0 = gload(vrow0, c + 3); }      \
+    if (copy && (S) == 3) { *reinterpret_cast<bf16x8*>(slot1 + off_wr) = g1; g1 = gload(vrow1, c + 3); }      \
+    if (!last) {                                                                                              \
+      const unsigned ksn = (unsigned)((c + 1) * 4 + (S)) * 1024u;                                             \
+      _Pragma("unroll") for (int cb = 0; cb < CB; ++cb)                                                       \
+        bq[S][cb] = ldbuf_bf16x8(rs_w, lane16, w0off + (unsigned)cb * KS * 1024u + ksn);                      \
+    }
+    KSTEP(0) KSTEP(1) KSTEP(2) KSTEP(3)
+#undef KSTEP
+#undef GROUP
+    const unsigned tmp = off_cur; off_cur = off_nxt; off_nxt = off_wr; off_wr = tmp;
+  };
+  for (int c = 0; c < NC - 2; ++c) { chunk(c, true, false); __syncthreads(); }
+  chunk(NC - 2, false, false);
+  __syncthreads();
+  chunk(NC - 1, false, true);
+  __syncthreads();
+#undef LDS_WAIT
+#undef LDS_RD
+
+  // ---- epilogue: times SiLU'(a1) from the first-layer table, row-major bf16 store ----
+  const _Float16* tab = static_cast<const _Float16*>(p.table);
+  __bf16* stg = reinterpret_cast<__bf16*>(s_a1) + (size_t)wave * 32 * 72;
+  __bf16* gout = static_cast<__bf16*>(p.g_a1_out) + (size_t)e0 * p.KP + 32 * colblk0;
+#pragma unroll
+  for (int rb = 0; rb < kRBD; ++rb) {
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+      const int col = 32 * (colblk0 + cb) + r;
+      const float wdc = p.wd[col];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = 32 * rb + acc_row(i, lane);
+        const float pq = (float)tab[(size_t)s_dst[row] * p.TC + p.offP + col] + (float)tab[(size_t)s_src[row] * p.TC + p.offQ + col];
+        float sv, ds;
+        silu_grad_s(fmaf(wdc, s_d2[row], pq), sv, ds);
+        acc[rb][cb][i] *= ds;
+      }
+    }
+    f32x16 blk[2];
+    blk[0] = acc[rb][0];
+    blk[1] = acc[rb][CB - 1];
+    store_block_bf16(blk, CB, stg, gout + (size_t)(32 * rb) * p.KP, (size_t)p.KP, nvalid - 32 * rb, lane);
+  }
+}
+
+}  // namespace
+
+int init_edge_dgrad_attributes() {
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_dgrad_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               160 * 1024));
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_dgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               160 * 1024));
+  return EGNN_OK;
+}
+
+// one MLP: g_a1 [E][KP] = (g_a2 [E][Kd] . W2) * SiLU'(a1);  needs Kd % 64 == 0, Kd >= 256, KP in {256, 512, 1024, ...}
+int launch_edge_dgrad(int N, int E, const int* dst, const int* src, const float* x, const void* table, int TC, int offP, int offQ,
+                      const float* wd, const void* g_a2, int Kd, const void* w2t, int KP, void* g_a1_out, hipStream_t st) {
+  static_assert(8 * 32 * 72 * 2 <= kRingD * kA1D, "store staging must fit the K-loop buffers");
+  if (Kd % 64 != 0 || Kd < 256 || KP % 256 != 0) { set_error("edge dgrad: unsupported widths Kd=%d KP=%d", Kd, KP); return EGNN_EINVAL; }
+  if ((size_t)E * Kd * 2 >= ((size_t)1 << 32) || (size_t)E * KP * 2 >= ((size_t)1 << 33)) { set_error("edge dgrad: chunk too large"); return EGNN_EINVAL; }
+  DgradParams p;
+  p.N = N; p.E = E; p.edge_dst = dst; p.edge_src = src; p.x = x; p.table = table; p.TC = TC; p.offP = offP; p.offQ = offQ;
+  p.wd = wd; p.g_a2 = g_a2; p.Kd = Kd; p.w2t = w2t; p.KP = KP; p.g_a1_out = g_a1_out;
+  const int tiles = (E + kRD - 1) / kRD;
+  if (KP >= 512) hipLaunchKernelGGL(edge_dgrad_kernel<2>, dim3(tiles * (KP / 512)), dim3(kTD), kSmemD, st, p);
+  else hipLaunchKernelGGL(edge_dgrad_kernel<1>, dim3(tiles), dim3(kTD), kSmemD, st, p);
+  EGNN_HIP(hipGetLastError());
+  return EGNN_OK;
+}
+
+}  // namespace egnn

@@ -81,6 +81,19 @@ __global__ void pack_frags_bf16_accperm(const float* __restrict__ W, int Nout, i
     out[i] = (__bf16)((n < Nout && k < K) ? W[(size_t)n * ldw + k] : 0.f);
   }
 }
+// the same fragment layout for B[k][n] = W[k][n] (the transposed use of an nn.Linear weight: dgrad g . W)
+__global__ void pack_frags_bf16_T(const float* __restrict__ W, int Krows, int Ncols, int ldw, int NP, int KP,
+                                  __bf16* __restrict__ out) {
+  const int KS = KP / 16;
+  const size_t total = (size_t)(NP / 32) * KS * 64 * 8;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int j = i & 7, lane = (i >> 3) & 63;
+    const size_t f = i >> 9;
+    const int ks = f % KS, nb = f / KS;
+    const int n = 32 * nb + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + j;
+    out[i] = (__bf16)((n < Ncols && k < Krows) ? W[(size_t)k * ldw + n] : 0.f);
+  }
+}
 __global__ void scale_copy(const float* __restrict__ src, size_t n, float scale, float* __restrict__ dst) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i] * scale;
 }
@@ -824,6 +837,7 @@ int init_kernel_attributes() {
   if ((rc = init_edge_bf16_v3_attributes())) return rc;
   if ((rc = init_edge_bf16_v4_attributes())) return rc;
   if ((rc = init_node_bf16_attributes())) return rc;
+  if ((rc = init_edge_dgrad_attributes())) return rc;
   done = true;
   return EGNN_OK;
 }
@@ -914,6 +928,18 @@ int backward_recompute(egnn_ctx* c, hipStream_t st, int layer, const float* x, c
   p.s1_out = s1m; p.g_a2_out = g_a2m; p.s_half_out = nullptr;
   p.g_col_a = g_b2m; p.g_col_b = g_wa; p.g_scalar = g_ba;
   return launch_edge_bf16_v4_m_bwd(p, st);
+}
+
+int backward_dgrad(egnn_ctx* c, hipStream_t st, int layer, const float* x, int e_first, int n_edges, const void* g_a2x,
+                   const void* g_a2m, void* g_a1x, void* g_a1m) {
+  const LayerPack& lp = c->layers[layer];
+  const float* wdx_s = lp.sc + (size_t)(c->H + 1) * c->TC;   // scaled copies: [w1catT | b1cat | wdx | wdm | ...]
+  const float* wdm_s = wdx_s + c->WxP;
+  int rc = launch_edge_dgrad(c->N, n_edges, c->edge_dst + e_first, c->edge_src + e_first, x, c->table, c->TC, 0, c->WxP, wdx_s,
+                             g_a2x, c->WxP, lp.w2xT_bf16, c->WxP, g_a1x, st);
+  if (rc) return rc;
+  return launch_edge_dgrad(c->N, n_edges, c->edge_dst + e_first, c->edge_src + e_first, x, c->table, c->TC, 2 * c->WxP,
+                           2 * c->WxP + c->WmP, wdm_s, g_a2m, c->MP, lp.w2mT_bf16, c->WmP, g_a1m, st);
 }
 
 // Stage 1 of a layer: node_pre, squared-distance sums and the fused edge pass.  gsum (c->gscale) then holds the
@@ -1092,7 +1118,8 @@ int egnn_create(egnn_ctx** out, int device) {
 
 static void free_layer(LayerPack& lp) {
   void* ptrs[] = {lp.w1catT, lp.b1cat, lp.wdx, lp.wdm, lp.w2x_f32, lp.w2x_bf16, lp.b2x, lp.w3x, lp.w2m_f32,
-                  lp.w2m_bf16, lp.b2m, lp.wa, lp.scal, lp.w1h_f32, lp.b1h, lp.w2h_f32, lp.b2h, lp.sc, lp.w2x_bf16s, lp.w2m_bf16s, lp.w1h_bf16, lp.w2h_bf16p};
+                  lp.w2m_bf16, lp.b2m, lp.wa, lp.scal, lp.w1h_f32, lp.b1h, lp.w2h_f32, lp.b2h, lp.sc, lp.w2x_bf16s, lp.w2m_bf16s, lp.w1h_bf16, lp.w2h_bf16p,
+                  lp.w2xT_bf16, lp.w2mT_bf16};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   lp = LayerPack();
@@ -1191,7 +1218,11 @@ int egnn_pack_layer(egnn_ctx* c, void* stream, int l, const float* m0_w, const f
     if ((rc = dev_alloc(&tmp, (size_t)WxP * WxP))) return rc;
     lp.w2x_bf16s = tmp; tmp = nullptr;
     if ((rc = dev_alloc(&tmp, (size_t)MP * WmP))) return rc;
-    lp.w2m_bf16s = tmp;
+    lp.w2m_bf16s = tmp; tmp = nullptr;
+    if ((rc = dev_alloc(&tmp, (size_t)WxP * WxP))) return rc;
+    lp.w2xT_bf16 = tmp; tmp = nullptr;
+    if ((rc = dev_alloc(&tmp, (size_t)MP * WmP))) return rc;
+    lp.w2mT_bf16 = tmp;
   }
   const dim3 g(256), b(256);
   hipLaunchKernelGGL(pack_first, g, b, 0, st, x0_w, x0_b, m0_w, m0_b, H, Wx, Wm, WxP, WmP, lp.w1catT, lp.b1cat);
@@ -1227,6 +1258,9 @@ int egnn_pack_layer(egnn_ctx* c, void* stream, int l, const float* m0_w, const f
     hipLaunchKernelGGL(pack_frags_bf16, g, b, 0, st, m2_w, M, Wm, Wm, MP, WmP, reinterpret_cast<__bf16*>(lp.w2m_bf16s), s2);
     hipLaunchKernelGGL(pack_frags_bf16, g, b, 0, st, h0_w, Wh, H + M, H + M, WhP, c->K1Q, reinterpret_cast<__bf16*>(lp.w1h_bf16), 1.0f);
     hipLaunchKernelGGL(pack_frags_bf16_accperm, g, b, 0, st, h2_w, H, Wh, Wh, HP, WhP, reinterpret_cast<__bf16*>(lp.w2h_bf16p));
+    // transposed packs for the backward dgrad: B[k = second-layer output][column = hidden unit]
+    hipLaunchKernelGGL(pack_frags_bf16_T, g, b, 0, st, x2_w, Wx, Wx, Wx, WxP, WxP, reinterpret_cast<__bf16*>(lp.w2xT_bf16));
+    hipLaunchKernelGGL(pack_frags_bf16_T, g, b, 0, st, m2_w, M, Wm, Wm, WmP, MP, reinterpret_cast<__bf16*>(lp.w2mT_bf16));
   }
   EGNN_HIP(hipGetLastError());
   lp.packed = true;

@@ -159,6 +159,13 @@ int egcl_backward_edge_recompute(egnn_ctx* ctx, void* stream, int layer, const f
                                  void* d_g_a2x, void* d_g_a2m, float* d_g_diff, float* d_g_b2x, float* d_g_w3,
                                  float* d_g_b3, float* d_g_b2m, float* d_g_wa, float* d_g_ba);
 
+/* Fused second half for the same path: g_a1 = (g_a2 . W2) * SiLU'(a1) for mlp_x ([n_edges, Wx] from [n_edges, Wx]) and
+ * mlp_m ([n_edges, Wm] from [n_edges, M]) on MFMA, i.e. the dgrad GEMMs of mlp_x.2 / mlp_m.2 with egcl_backward_l1_grad
+ * in their epilogue (the first-layer pre-activations come from the table egcl_backward_table left on ctx).  bf16 row-major
+ * in and out. */
+int egcl_backward_dgrad(egnn_ctx* ctx, void* stream, int layer, const float* d_x, int e_first, int n_edges,
+                        const void* d_g_a2x, const void* d_g_a2m, void* d_g_a1x_out, void* d_g_a1m_out);
+
 /* EquivariantGNN.forward(edge_index, h, x) -> (h_L, x_L) (:85-88): all L layers. */
 int egnn_forward(egnn_ctx* ctx, void* stream, int prec, int norm_scope,
                  const float* d_h, const float* d_x, float* d_h_out, float* d_x_out);
