@@ -64,7 +64,7 @@ __host__ __device__ inline size_t v4_smem_bytes(int KP, int MP, bool is_m) {
 }
 
 #ifndef EGNN_V4_M_WAVES
-#define EGNN_V4_M_WAVES 3   // waves per SIMD the message kernel is compiled for (4 would allow two workgroups per CU, but spills)
+#define EGNN_V4_M_WAVES 4   // waves per SIMD the message kernel is compiled for (4 = two workgroups per CU)
 #endif
 // BWD = true (message kernel): the training backward's recompute pass over a chunk of edges: the activation chunks are
 // also written to HBM (s1_out) and the epilogue produces dL/d(a2m) through the gate instead of the segment sums.
@@ -233,9 +233,12 @@ __global__ __launch_bounds__(kT3, ((IS_M && !BWD) ? EGNN_V4_M_WAVES : 2)) void e
     if constexpr (BWD) { s1_store(o0, brow, 1); s1_store(o1, brow + 64, 1); }
   }
   uload(u0, vdst0, vsrc0, 2); uload(u1, vdst1, vsrc1, 2);
-  bf16x8 bq[4][CB];   // weight fragments of the 4 k-steps of the current chunk
+  // weight fragments, requested BQD k-steps ahead of their use (a whole chunk for the coordinate kernel; the message
+  // kernel, compiled for <= 128 VGPRs so that two workgroups share a CU, keeps 2 -- its other workgroup covers the rest)
+  constexpr int BQD = (IS_M && !BWD && EGNN_V4_M_WAVES >= 4) ? 2 : 4;
+  bf16x8 bq[BQD][CB];
 #pragma unroll
-  for (int s = 0; s < 4; ++s)
+  for (int s = 0; s < BQD; ++s)
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) bq[s][cb] = ldbuf_bf16x8(rs_w, lane16, w0off + ((unsigned)cb * KS + s) * 1024u);
   __syncthreads();
@@ -255,14 +258,9 @@ __global__ __launch_bounds__(kT3, ((IS_M && !BWD) ? EGNN_V4_M_WAVES : 2)) void e
   auto chunk = [&](const int c, const bool build, const bool last) {
     STAMP(c, 0);
     const unsigned abase = lds_a1_base + off_cur, nbase = lds_a1_base + off_nxt;
-    f32x4 wv0, wv1;
     f16x8 t;
     bf16x8 o;
-    if (build) {
-      const float* wd = s_wd + (c + 2) * kKC3 + kg * 8;
-      wv0 = *reinterpret_cast<const f32x4*>(wd);
-      wv1 = *reinterpret_cast<const f32x4*>(wd + 4);
-    }
+    const float* wdc = s_wd + (c + 2) * kKC3 + kg * 8;   // d^2 column of the first layer for this thread's 8 hidden units
     // The 16 activations a thread owes to chunk c+2 are finished 4 per k-step, as a software pipeline over the 8 MFMA
     // gaps of the k-step: every gap issues ~16 cycles of INDEPENDENT vector instructions whose operands were produced at
     // least one gap earlier (an in-order wave stalls on a dependent transcendental otherwise), between two MFMAs in
@@ -276,8 +274,9 @@ __global__ __launch_bounds__(kT3, ((IS_M && !BWD) ? EGNN_V4_M_WAVES : 2)) void e
       if ((Q) == 0) {                                                                                         \
         if ((S) == 0) t = u0.p + u0.q;                                                                        \
         if ((S) == 2) t = u1.p + u1.q;                                                                        \
+        const f32x4 wv_ = *reinterpret_cast<const f32x4*>(wdc + e0_);                                         \
         _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                         \
-          pu[k] = fmaf(e0_ ? wv1[k] : wv0[k], (S) < 2 ? d2r0 : d2r1, (float)t[e0_ + k]);                      \
+          pu[k] = fmaf(wv_[k], (S) < 2 ? d2r0 : d2r1, (float)t[e0_ + k]);                                     \
       }                                                                                                       \
       if ((Q) == 1) { pe[0] = __builtin_amdgcn_exp2f(pu[0]); pe[1] = __builtin_amdgcn_exp2f(pu[1]); }         \
       if ((Q) == 2) { pe[2] = __builtin_amdgcn_exp2f(pu[2]); pe[3] = __builtin_amdgcn_exp2f(pu[3]); }         \
@@ -300,12 +299,12 @@ __global__ __launch_bounds__(kT3, ((IS_M && !BWD) ? EGNN_V4_M_WAVES : 2)) void e
       else if ((RB) == 2) LDS_WAIT(1);                                                                        \
       else LDS_WAIT(0);                                                                                       \
       asm volatile("" : "+v"(a[RB]));                                                                         \
-      acc[RB][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[RB], bq[S][0], acc[RB][0], 0, 0, 0);             \
+      acc[RB][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[RB], bq[(S) % BQD][0], acc[RB][0], 0, 0, 0);     \
       __builtin_amdgcn_sched_barrier(0);                                                                      \
       STAGE(S, 2 * (RB))                                                                                      \
       __builtin_amdgcn_sched_barrier(0);                                                                      \
       _Pragma("unroll") for (int cb = 1; cb < CB; ++cb)                                                       \
-        acc[RB][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[RB], bq[S][cb], acc[RB][cb], 0, 0, 0);        \
+        acc[RB][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[RB], bq[(S) % BQD][cb], acc[RB][cb], 0, 0, 0); \
       if ((S) < 3) LDS_RD(a[RB], abase, ((S) + 1) * 4128 + (RB) * 512);                                       \
       else if (!last) LDS_RD(a[RB], nbase, (RB) * 512);                                                       \
       __builtin_amdgcn_sched_barrier(0);                                                                      \
@@ -320,10 +319,10 @@ __global__ __launch_bounds__(kT3, ((IS_M && !BWD) ? EGNN_V4_M_WAVES : 2)) void e
 #define KSTEP(S)                                                                                              \
     KPRIO(S)                                                                                                  \
     GROUP(S, 0) GROUP(S, 1) GROUP(S, 2) GROUP(S, 3)                                                           \
-    if (!last) {                                                                                              \
-      const unsigned ksn = (unsigned)((c + 1) * 4 + (S)) * 1024u;                                             \
+    if (!last || (S) + BQD < 4) {   /* k-step c*4 + S + BQD: this chunk's or the next one's */                \
+      const unsigned ksn = (unsigned)(c * 4 + (S) + BQD) * 1024u;                                             \
       _Pragma("unroll") for (int cb = 0; cb < CB; ++cb)                                                       \
-        bq[S][cb] = ldbuf_bf16x8(rs_w, lane16, w0off + (unsigned)cb * KS * 1024u + ksn);                      \
+        bq[(S) % BQD][cb] = ldbuf_bf16x8(rs_w, lane16, w0off + (unsigned)cb * KS * 1024u + ksn);              \
     }
     KSTEP(0) KSTEP(1)
     STAMP(c, 1);
