@@ -359,7 +359,11 @@ __global__ __launch_bounds__(kT3, ((IS_M && !BWD) ? EGNN_V4_M_WAVES : 2)) void e
     static_assert(!(BWD && IS_M) || CB == 1, "message epilogue assumes one 32-column block per wave");
     const int ncol = 32 * wave + r;
     const float bb = p.b2m[ncol], wan = p.wa[ncol] * kNegLog2e;   // packed vectors carry the -log2(e) / -1/log2(e) scales
-    const float* gm = p.g_sum_m + ncol;
+    const rsrc_t rs_gm = make_rsrc(p.g_sum_m, (unsigned)((size_t)p.N * p.MP * 4));
+    const unsigned gcol = 4u * (unsigned)ncol, gld = 4u * (unsigned)p.MP;
+    auto gm_at = [&](const int row) {   // dL/d(sum_m)[dst(row)][ncol]
+      return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_gm, (unsigned)s_dst[row] * gld + gcol, 0, 0));
+    };
     // pass 1: row sums z = wa . m and d = g . m (two halves of 64 rows to bound the live registers)
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
@@ -370,7 +374,7 @@ __global__ __launch_bounds__(kT3, ((IS_M && !BWD) ? EGNN_V4_M_WAVES : 2)) void e
         float m, ds;
         silu_grad_s(fmaf(acc[rb][0][i], kNegLog2e, bb), m, ds);
         vz[q] = wan * m;
-        vd[q] = gm[(size_t)s_dst[row] * p.MP] * m;
+        vd[q] = gm_at(row) * m;
       }
       const float tz = butterfly32(vz, lane), td = butterfly32(vd, lane);
       s_part[wave * kR3 + 64 * hf + row_of(r)] = tz;
@@ -403,7 +407,7 @@ __global__ __launch_bounds__(kT3, ((IS_M && !BWD) ? EGNN_V4_M_WAVES : 2)) void e
         float m, ds;
         silu_grad_s(fmaf(acc[rb][0][i], kNegLog2e, bb), m, ds);
         const float coef = s_d2[row];
-        const float g = row < nvalid ? fmaf(gm[(size_t)s_dst[row] * p.MP], s_val[row], coef * wan) * ds : 0.f;
+        const float g = row < nvalid ? fmaf(gm_at(row), s_val[row], coef * wan) * ds : 0.f;
         cs_b += g;
         cs_w = fmaf(coef, m, cs_w);
         acc[rb][0][i] = g;

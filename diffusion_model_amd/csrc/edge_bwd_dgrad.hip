@@ -66,7 +66,10 @@ __global__ __launch_bounds__(kTD, 2) void edge_dgrad_kernel(const DgradParams p)
       const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);   // norm(...)**2 as in the forward (:56)
       dd = nrm * nrm;
     }
-    s_dst[tid] = d; s_src[tid] = s; s_d2[tid] = dd;
+    // byte offsets of this row's P / Q blocks in the fp16 table (32-bit: N * TC * 2 < 4 GB is checked on the host)
+    s_dst[tid] = (int)(((unsigned)d * (unsigned)p.TC + (unsigned)p.offP) * 2u);
+    s_src[tid] = (int)(((unsigned)s * (unsigned)p.TC + (unsigned)p.offQ) * 2u);
+    s_d2[tid] = dd;
   }
   const int NC = p.Kd / kKCD, KS = p.Kd / 16;
   const int brow = tid >> 3, kg = tid & 7;   // this thread copies rows brow and brow + 64, k-group kg of every chunk
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(kTD, 2) void edge_dgrad_kernel(const DgradParams p)
 #undef LDS_RD
 
   // ---- epilogue: times SiLU'(a1) from the first-layer table, row-major bf16 store ----
-  const _Float16* tab = static_cast<const _Float16*>(p.table);
+  const rsrc_t rs_tab = make_rsrc(p.table, (unsigned)((size_t)p.N * p.TC * 2));
   __bf16* stg = reinterpret_cast<__bf16*>(s_a1) + (size_t)wave * 32 * 72;
   __bf16* gout = static_cast<__bf16*>(p.g_a1_out) + (size_t)e0 * p.KP + 32 * colblk0;
 #pragma unroll
@@ -159,12 +162,19 @@ __global__ __launch_bounds__(kTD, 2) void edge_dgrad_kernel(const DgradParams p)
     for (int cb = 0; cb < CB; ++cb) {
       const int col = 32 * (colblk0 + cb) + r;
       const float wdc = p.wd[col];
+      const unsigned col2 = 2u * (unsigned)col;
+      _Float16 tp[16], tq[16];   // all 32 two-byte gathers of the block in flight before the first use
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = 32 * rb + acc_row(i, lane);
-        const float pq = (float)tab[(size_t)s_dst[row] * p.TC + p.offP + col] + (float)tab[(size_t)s_src[row] * p.TC + p.offQ + col];
+        tp[i] = __builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(rs_tab, (unsigned)s_dst[row] + col2, 0, 0));
+        tq[i] = __builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(rs_tab, (unsigned)s_src[row] + col2, 0, 0));
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = 32 * rb + acc_row(i, lane);
         float sv, ds;
-        silu_grad_s(fmaf(wdc, s_d2[row], pq), sv, ds);
+        silu_grad_s(fmaf(wdc, s_d2[row], (float)tp[i] + (float)tq[i]), sv, ds);
         acc[rb][cb][i] *= ds;
       }
     }

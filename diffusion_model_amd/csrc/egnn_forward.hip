@@ -1,7 +1,9 @@
 // EGNN denoiser forward path for MI355X (gfx950 / CDNA4).
 //
-// One EGCL layer (reference: EquivariantGraphNeuralNetwork.py:55-71) is three launches:
+// One EGCL layer (reference: EquivariantGraphNeuralNetwork.py:55-71) is three stages:
 //
+// (bf16 default path: 4 launches per layer -- node_pre, coordinate edge kernel, message edge kernel, node_post; the
+//  normaliser's d^2 sums ride in component 3 of the coordinate sums.  Other paths add node_d2 + graph_sum.)
 //   node_pre   per node: first-layer partial pre-activations of BOTH edge MLPs.  The reference
 //              feeds [h_i | h_j | d^2] (2H+1 wide) through Linear(2H+1, W) per EDGE (:56-57,:63-64);
 //              because that layer is linear in its input, W1.[h_i|h_j|d2] + b =
@@ -14,9 +16,10 @@
 //   node_post  per node: gather the segment sums, mlp_h on MFMA (hidden never leaves the CU),
 //              coordinate update x' = x + sum_x / (G + 1).
 //
-// Precision: EGNN_PREC_F32 uses v_mfma_f32_32x32x2_f32 (exact fp32 fma chains); EGNN_PREC_BF16 uses
-// v_mfma_f32_32x32x16_bf16 with fp32 accumulation for the two big per-edge GEMMs.  Geometry (d^2,
-// coordinate differences), SiLU/sigmoid, all segment sums and the node MLP stay fp32 in both.
+// Precision: EGNN_PREC_F32 uses v_mfma_f32_32x32x2_f32 (exact fp32 fma chains) everywhere.  EGNN_PREC_BF16 uses
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation for the two big per-edge GEMMs AND for the node MLP mlp_h
+// (node_post_bf16_kernel, csrc/node_bf16.hip), and a half-precision first-layer table; geometry (d^2, coordinate
+// differences), SiLU / sigmoid, all segment sums and the first-layer table's arithmetic stay fp32 in both.
 #include <stdarg.h>
 #include <stdlib.h>
 
