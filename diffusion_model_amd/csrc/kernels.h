@@ -79,10 +79,33 @@ __device__ __forceinline__ float node_sq_sum(int n, const int* __restrict__ row_
 }
 // Sum over the nodes [lo, hi) of one graph by an aligned group of 8 lanes (g8 = lane's index in the group): every
 // group that sums the same graph produces the same bits (fixed stride, fixed butterfly order).
+// (graphs of <= 64 nodes: at most 8 nodes per lane, written as two unrolled passes so that the 8 CSR reads and then the
+// 8 sum reads are in flight together -- at B = 1 nothing else hides their latency)
 __device__ __forceinline__ float graph_sq_sum8(int lo, int hi, int g8, const int* __restrict__ row_ptr, int R,
                                                const float* __restrict__ agg_x, const float* __restrict__ part_x) {
+  int rp0[8], rp1[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int m = lo + g8 + 8 * k;
+    const bool ok = m < hi;
+    rp0[k] = ok ? row_ptr[m] : 0;
+    rp1[k] = ok ? row_ptr[m + 1] : 0;
+  }
   float s = 0.f;
-  for (int m = lo + g8; m < hi; m += 8) s += node_sq_sum(m, row_ptr, R, agg_x, part_x);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int m = lo + g8 + 8 * k;
+    float v = 0.f;
+    if (rp1[k] > rp0[k]) {
+      const int t0 = rp0[k] / R, t1 = (rp1[k] - 1) / R;
+      if (t0 == t1) v = agg_x[(size_t)m * 4 + 3];
+      else {
+        v = part_x[((size_t)t0 * 2 + 1) * 4 + 3];
+        for (int t = t0 + 1; t <= t1; ++t) v += part_x[((size_t)t * 2) * 4 + 3];
+      }
+    }
+    s += v;
+  }
   s += __shfl_xor(s, 1);
   s += __shfl_xor(s, 2);
   s += __shfl_xor(s, 4);

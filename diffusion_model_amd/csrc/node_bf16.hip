@@ -29,18 +29,32 @@ __global__ __launch_bounds__(kThreadsN) void node_post_bf16_kernel(const PostPar
   const int KS1 = p.K1Q / 16, OB = p.HP / 32;
   float* red = reinterpret_cast<float*>(smem + (size_t)(p.K1Q / 8) * 33 * 16);
 
-  // gather [h | sum_m] (tile partials added in tile order), pack to bf16 in the fragment image
+  // gather [h | sum_m] (tile partials added in tile order), pack to bf16 in the fragment image.  The CSR lookups of the
+  // 32 nodes go through LDS first and the item loop is unrolled: independent loads in flight instead of a chain of
+  // dependent ones per item (which nothing hides when the layer has one or two of these workgroups).
+  int* s_t0 = reinterpret_cast<int*>(red);          // [kNodes] first tile of the node's edges, -1 = no edges
+  int* s_t1 = s_t0 + kNodes;                        // [kNodes] last tile
+  if (tid < kNodes) {
+    const int n = n0 + tid;
+    int t0 = -1, t1 = -1;
+    if (n < p.N) {
+      const int rp0 = p.row_ptr[n], rp1 = p.row_ptr[n + 1];
+      if (rp1 > rp0) { t0 = rp0 / p.R; t1 = (rp1 - 1) / p.R; }
+    }
+    s_t0[tid] = t0; s_t1[tid] = t1;
+  }
+  __syncthreads();
+#pragma unroll 4
   for (int i = tid; i < kNodes * (p.K1Q / 2); i += kThreadsN) {
     const int node = i / (p.K1Q / 2), kp = i % (p.K1Q / 2), n = n0 + node;
     float v[2] = {0.f, 0.f};
     if (n < p.N) {
-      const int rp0 = p.row_ptr[n], rp1 = p.row_ptr[n + 1];
-      const int t0 = rp1 > rp0 ? rp0 / p.R : 0, t1 = rp1 > rp0 ? (rp1 - 1) / p.R : 0;
+      const int t0 = s_t0[node], t1 = s_t1[node];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int k = 2 * kp + u;
         if (k < p.H) v[u] = p.h[(size_t)n * p.H + k];
-        else if (k - p.H < p.MP && rp1 > rp0) {
+        else if (k - p.H < p.MP && t0 >= 0) {
           const int c = k - p.H;
           if (t0 == t1) v[u] = p.agg_m[(size_t)n * p.MP + c];
           else {
@@ -93,10 +107,9 @@ __global__ __launch_bounds__(kThreadsN) void node_post_bf16_kernel(const PostPar
   if (tid < kNodes * 3) {
     const int node = tid / 3, d = tid % 3, n = n0 + node;
     if (n < p.N) {
-      const int rp0 = p.row_ptr[n], rp1 = p.row_ptr[n + 1];
+      const int t0 = s_t0[node], t1 = s_t1[node];
       float v = 0.f;
-      if (rp1 > rp0) {
-        const int t0 = rp0 / p.R, t1 = (rp1 - 1) / p.R;
+      if (t0 >= 0) {
         for (int hs = 0; hs < p.nsplit_x; ++hs) {
           const float* ax = p.agg_x + (size_t)hs * p.agg_x_stride;
           const float* px = p.part_x + (size_t)hs * p.part_x_stride;
