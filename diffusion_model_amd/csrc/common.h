@@ -55,6 +55,7 @@ struct LayerPack {
   void* w2m_bf16s = nullptr;
   void* w2xT_bf16 = nullptr;  // mlp_x.2 TRANSPOSED bf16 fragments for the backward dgrad (k = output n, column = hidden k)
   void* w2mT_bf16 = nullptr;  // mlp_m.2 transposed (K = MP, N = WmP)
+  void* w1hl_bf16 = nullptr;  // scaled first layers as bf16 hi/lo B fragments [TC/32][3][hi|lo][64][8] (node_pre_hilo_kernel)
   void* w1h_bf16 = nullptr;   // mlp_h.0 bf16 fragments (N = WhP, K = K1Q)
   void* w2h_bf16p = nullptr;  // mlp_h.2 bf16 fragments, k in accumulator-row order
 };

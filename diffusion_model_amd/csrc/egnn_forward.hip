@@ -241,6 +241,100 @@ __global__ __launch_bounds__(kThreads) void node_pre_mfma_kernel(const float* __
   }
 }
 
+// ---- node_pre for the half-precision table on bf16 MFMA with a hi/lo split -------------------------------------------
+// The f32-input MFMA runs at 1/16 of the bf16 rate and made node_pre MFMA-bound at ~3x its HBM-write time.  Here both
+// operands are split h = h_hi + h_lo, W = W_hi + W_lo (bf16 each, lo = bf16(v - hi)) and the product is
+// h_hi.W_hi + h_hi.W_lo + h_lo.W_hi: three v_mfma_f32_32x32x16_bf16 per 16-deep k-step with fp32 accumulation.  The dropped
+// h_lo.W_lo term and the 16-bit representation bound the error at ~2^-16 relative -- 30x below the half-precision rounding
+// of the table entry itself (2^-11); K = H <= 48 is 3 k-steps, so a 32 x 32 tile costs 9 x 32 = 288 MFMA cycles
+// instead of 18 x 64 = 1152.
+// B fragments of the (pre-scaled) first-layer weights: [TC/32 column blocks][3 k-steps][hi|lo][64 lanes][8 bf16].
+__global__ void pack_w1_hilo(const float* __restrict__ w1catT, int H, int TC, __bf16* __restrict__ out) {
+  const size_t total = (size_t)(TC / 32) * 3 * 64 * 8;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int j = i & 7, lane = (i >> 3) & 63;
+    const size_t f = i >> 9;
+    const int ks = f % 3, nb = f / 3;
+    const int n = 32 * nb + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + j;
+    const float v = k < H ? w1catT[(size_t)k * TC + n] : 0.f;
+    const __bf16 hi = (__bf16)v;
+    const __bf16 lo = (__bf16)(v - (float)hi);
+    const size_t base = (f * 2) * 512 + (size_t)lane * 8 + j;
+    out[base] = hi;
+    out[base + 512] = lo;
+  }
+}
+
+constexpr int kPre3Nodes = 32, kPre3Cols = 1024;   // workgroup = 32 nodes x 1024 columns, wave w owns 8 column blocks
+__global__ __launch_bounds__(kThreads) void node_pre_hilo_kernel(const float* __restrict__ h, int N, int H,
+                                                                 const bf16x8* __restrict__ w1hl,
+                                                                 const float* __restrict__ b1cat, int TC,
+                                                                 _Float16* __restrict__ table) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* hs = reinterpret_cast<float*>(smem_raw);   // [48][33] transposed h tile, zero-padded to K = 48
+  const int n0 = blockIdx.x * kPre3Nodes;
+  for (int i = threadIdx.x; i < kPre3Nodes * 48; i += kThreads) {
+    const int node = i / 48, k = i % 48, n = n0 + node;
+    hs[k * 33 + node] = (n < N && k < H) ? h[(size_t)n * H + k] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+  // A fragments (node r, k = 16 ks + 8 hh + j), hi and lo parts
+  bf16x8 ahi[3], alo[3];
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = hs[(16 * ks + 8 * hh + j) * 33 + r];
+      const __bf16 hi = (__bf16)v;
+      ahi[ks][j] = hi;
+      alo[ks][j] = (__bf16)(v - (float)hi);
+    }
+  const int cb0 = (blockIdx.y * kPre3Cols) / 32 + wave * 8;   // first column block of this wave
+  constexpr int kLd = 128 + 8;   // halves per staged row (4 column blocks = 128 columns at a time)
+  _Float16* stg = reinterpret_cast<_Float16*>(smem_raw + 48 * 33 * 4) + (size_t)wave * 32 * kLd;
+  for (int half8 = 0; half8 < 2; ++half8) {
+#pragma unroll
+    for (int pair = 0; pair < 2; ++pair) {   // 2 column blocks = 12 fragment loads in flight
+      bf16x8 bf[2][3][2];
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) {
+        const int cb = cb0 + 4 * half8 + 2 * pair + jb;
+        const bool ok = 32 * cb < TC;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) bf[jb][ks][q] = ok ? w1hl[(((size_t)cb * 3 + ks) * 2 + q) * 64 + lane] : bf16x8{};
+      }
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) {
+        const int cb = cb0 + 4 * half8 + 2 * pair + jb, col = 32 * cb + r;
+        const float b = col < TC ? b1cat[col] : 0.f;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = b;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[ks], bf[jb][ks][0], acc, 0, 0, 0);   // small terms first
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[ks], bf[jb][ks][1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[ks], bf[jb][ks][0], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) table_store(stg + acc_row(i, lane) * kLd + 32 * (2 * pair + jb) + r, acc[i]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // this wave's 32 rows x 128 columns as 16-byte pieces: 256 contiguous bytes per row
+    const int cbase = 32 * (cb0 + 4 * half8);
+    for (int q = lane; q < 32 * 16; q += 64) {
+      const int row = q >> 4, piece = q & 15, n = n0 + row, col = cbase + 8 * piece;
+      if (n < N && col < TC)
+        *reinterpret_cast<f32x4*>(table + (size_t)n * TC + col) = *reinterpret_cast<const f32x4*>(stg + row * kLd + 8 * piece);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // node_d2[n] = sum over the edges received by n of |x_n - x_src|^2 (fixed order -> deterministic)
 __global__ void node_d2_kernel(const float* __restrict__ x, const int* __restrict__ row_ptr,
                                const int* __restrict__ edge_src, int N, float* __restrict__ node_d2) {
@@ -835,6 +929,8 @@ int init_kernel_attributes() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&node_post_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&node_pre_hilo_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   int rc = init_edge_bf16_v2_attributes();
   if (rc) return rc;
   if ((rc = init_edge_bf16_v3_attributes())) return rc;
@@ -885,9 +981,17 @@ static void use_scaled_pack(egnn_ctx* c, int layer, EdgeParams& p, const float*&
   p.w2x = lp.w2x_bf16s; p.w2m = lp.w2m_bf16s;
 }
 // first-layer table of the v3 / v4 kernels (fp16, pre-scaled) for node features h
-static int launch_node_pre_f16(egnn_ctx* c, hipStream_t st, const float* h, const float* w1catT, const float* b1cat) {
+static int launch_node_pre_f16(egnn_ctx* c, hipStream_t st, int layer, const float* h, const float* w1catT,
+                               const float* b1cat) {
   const int N = c->N;
-  if (c->H <= 64) {
+  static const int pre_sel = getenv("EGNN_PRE") ? atoi(getenv("EGNN_PRE")) : 3;   // A/B switch: 1 VALU, 2 f32 MFMA, 3 bf16 hi/lo
+  if (pre_sel >= 3 && c->H <= 48) {
+    dim3 grid((N + kPre3Nodes - 1) / kPre3Nodes, (c->TC + kPre3Cols - 1) / kPre3Cols);
+    const size_t sm = (size_t)48 * 33 * 4 + (size_t)4 * 32 * (128 + 8) * 2;
+    hipLaunchKernelGGL(node_pre_hilo_kernel, grid, dim3(kThreads), sm, st, h, N, c->H,
+                       reinterpret_cast<const bf16x8*>(c->layers[layer].w1hl_bf16), b1cat, c->TC,
+                       reinterpret_cast<_Float16*>(c->table));
+  } else if (pre_sel >= 2 && c->H <= 64) {
     dim3 grid((N + kPre2Nodes - 1) / kPre2Nodes, (c->TC + kPre2Cols - 1) / kPre2Cols);
     const size_t sm = (size_t)((c->H + 1) & ~1) * 33 * sizeof(float);
     const size_t sm16 = (size_t)kPre2Nodes * (kPre2Cols + 8) * 2;   // output staging tile of the fp16 variant
@@ -913,7 +1017,7 @@ int backward_table(egnn_ctx* c, hipStream_t st, int layer, const float* h) {
   fill_edge_params(c, layer, EGNN_PREC_BF16, nullptr, p);
   const float *w1catT, *b1cat;
   use_scaled_pack(c, layer, p, w1catT, b1cat);
-  return launch_node_pre_f16(c, st, h, w1catT, b1cat);
+  return launch_node_pre_f16(c, st, layer, h, w1catT, b1cat);
 }
 int backward_recompute(egnn_ctx* c, hipStream_t st, int layer, const float* x, const float* g_sum_x, const float* g_sum_m,
                        int e_first, int n_edges, void* s1x, void* s1m, void* g_a2x, void* g_a2m, float* s_halves,
@@ -969,26 +1073,20 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
 
   prof_begin(c, st, 1);
   {
-    static const int pre_sel = getenv("EGNN_PRE") ? atoi(getenv("EGNN_PRE")) : 2;   // A/B switch
-    if (pre_sel >= 2 && c->H <= 64) {
+    static const int pre_sel = getenv("EGNN_PRE") ? atoi(getenv("EGNN_PRE")) : 3;   // A/B switch
+    if (path >= 3) {   // the v3 / v4 edge kernels read a half-precision table
+      int rc = launch_node_pre_f16(c, st, layer, h, w1catT, b1cat);
+      if (rc) return rc;
+    } else if (pre_sel >= 2 && c->H <= 64) {
       dim3 grid((N + kPre2Nodes - 1) / kPre2Nodes, (c->TC + kPre2Cols - 1) / kPre2Cols);
       const size_t sm = (size_t)((c->H + 1) & ~1) * 33 * sizeof(float);
-      const size_t sm16 = (size_t)kPre2Nodes * (kPre2Cols + 8) * 2;   // output staging tile of the fp16 variant
-      if (path >= 3)   // the v3 / v4 edge kernels read a half-precision table
-        hipLaunchKernelGGL(node_pre_mfma_kernel<_Float16>, grid, dim3(kThreads), sm > sm16 ? sm : sm16, st, h, N, c->H,
-                           w1catT, b1cat, c->TC, reinterpret_cast<_Float16*>(c->table));
-      else
-        hipLaunchKernelGGL(node_pre_mfma_kernel<float>, grid, dim3(kThreads), sm, st, h, N, c->H, w1catT, b1cat, c->TC,
-                           c->table);
+      hipLaunchKernelGGL(node_pre_mfma_kernel<float>, grid, dim3(kThreads), sm, st, h, N, c->H, w1catT, b1cat, c->TC,
+                         c->table);
     } else {
       dim3 grid((N + kPreNodes - 1) / kPreNodes, (c->TC + kThreads - 1) / kThreads);
       const size_t sm = (size_t)kPreNodes * c->H * sizeof(float);
-      if (path >= 3)
-        hipLaunchKernelGGL(node_pre_kernel<_Float16>, grid, dim3(kThreads), sm, st, h, N, c->H, w1catT, b1cat, c->TC,
-                           reinterpret_cast<_Float16*>(c->table));
-      else
-        hipLaunchKernelGGL(node_pre_kernel<float>, grid, dim3(kThreads), sm, st, h, N, c->H, w1catT, b1cat, c->TC,
-                           c->table);
+      hipLaunchKernelGGL(node_pre_kernel<float>, grid, dim3(kThreads), sm, st, h, N, c->H, w1catT, b1cat, c->TC,
+                         c->table);
     }
     if (path != 4) {   // the v4 edge kernels sum d^2 per receiving node themselves
       hipLaunchKernelGGL(node_d2_kernel, dim3((N + 255) / 256), dim3(256), 0, st, x, c->row_ptr, c->edge_src, N,
@@ -1122,7 +1220,7 @@ int egnn_create(egnn_ctx** out, int device) {
 static void free_layer(LayerPack& lp) {
   void* ptrs[] = {lp.w1catT, lp.b1cat, lp.wdx, lp.wdm, lp.w2x_f32, lp.w2x_bf16, lp.b2x, lp.w3x, lp.w2m_f32,
                   lp.w2m_bf16, lp.b2m, lp.wa, lp.scal, lp.w1h_f32, lp.b1h, lp.w2h_f32, lp.b2h, lp.sc, lp.w2x_bf16s, lp.w2m_bf16s, lp.w1h_bf16, lp.w2h_bf16p,
-                  lp.w2xT_bf16, lp.w2mT_bf16};
+                  lp.w2xT_bf16, lp.w2mT_bf16, lp.w1hl_bf16};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   lp = LayerPack();
@@ -1225,7 +1323,9 @@ int egnn_pack_layer(egnn_ctx* c, void* stream, int l, const float* m0_w, const f
     if ((rc = dev_alloc(&tmp, (size_t)WxP * WxP))) return rc;
     lp.w2xT_bf16 = tmp; tmp = nullptr;
     if ((rc = dev_alloc(&tmp, (size_t)MP * WmP))) return rc;
-    lp.w2mT_bf16 = tmp;
+    lp.w2mT_bf16 = tmp; tmp = nullptr;
+    if ((rc = dev_alloc(&tmp, (size_t)(TC / 32) * 3 * 2 * 512))) return rc;
+    lp.w1hl_bf16 = tmp;
   }
   const dim3 g(256), b(256);
   hipLaunchKernelGGL(pack_first, g, b, 0, st, x0_w, x0_b, m0_w, m0_b, H, Wx, Wm, WxP, WmP, lp.w1catT, lp.b1cat);
@@ -1261,6 +1361,8 @@ int egnn_pack_layer(egnn_ctx* c, void* stream, int l, const float* m0_w, const f
     hipLaunchKernelGGL(pack_frags_bf16, g, b, 0, st, m2_w, M, Wm, Wm, MP, WmP, reinterpret_cast<__bf16*>(lp.w2m_bf16s), s2);
     hipLaunchKernelGGL(pack_frags_bf16, g, b, 0, st, h0_w, Wh, H + M, H + M, WhP, c->K1Q, reinterpret_cast<__bf16*>(lp.w1h_bf16), 1.0f);
     hipLaunchKernelGGL(pack_frags_bf16_accperm, g, b, 0, st, h2_w, H, Wh, Wh, HP, WhP, reinterpret_cast<__bf16*>(lp.w2h_bf16p));
+    if (H <= 48)   // hi/lo bf16 fragments of the scaled first-layer weights (node_pre_hilo_kernel)
+      hipLaunchKernelGGL(pack_w1_hilo, g, b, 0, st, lp.sc, H, TC, reinterpret_cast<__bf16*>(lp.w1hl_bf16));
     // transposed packs for the backward dgrad: B[k = second-layer output][column = hidden unit]
     hipLaunchKernelGGL(pack_frags_bf16_T, g, b, 0, st, x2_w, Wx, Wx, Wx, WxP, WxP, reinterpret_cast<__bf16*>(lp.w2xT_bf16));
     hipLaunchKernelGGL(pack_frags_bf16_T, g, b, 0, st, m2_w, M, Wm, Wm, WmP, MP, reinterpret_cast<__bf16*>(lp.w2mT_bf16));
