@@ -7,6 +7,8 @@
 // happen on the accumulator registers (the k order inside a 16-deep step is the accumulator's row order; W2h is
 // packed with the same permutation).  Each wave owns a quarter of the hidden units; the four partial out^T
 // tiles are added through LDS in a fixed order.
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace egnn {
@@ -21,7 +23,13 @@ __host__ __device__ inline size_t nb_smem_bytes(int K1Q, int OB) {
   return xs + red;
 }
 
-__global__ __launch_bounds__(kThreadsN) void node_post_bf16_kernel(const PostParams p) {
+// OBT = compile-time bound of the output column blocks (H <= 32 OBT).  The accumulators of absent blocks cost registers:
+// with a single H <= 256 instantiation the kernel took 464 registers per lane = ONE workgroup per CU, and a layer's 512
+// workgroups ran as two serial rounds of a latency-bound chain (88-98 us); at OBT = 2 (H <= 64, 224 VGPRs) two workgroups
+// share a CU: 49 us.
+template <int OBT>
+__global__ __launch_bounds__(kThreadsN, (OBT > 2 ? 1 : 2)) void node_post_bf16_kernel(const PostParams p) {
+  constexpr bool PF = true;   // the W1h fragments of the next hidden block are requested while this one is multiplied
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Xb = smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
@@ -131,9 +139,9 @@ __global__ __launch_bounds__(kThreadsN) void node_post_bf16_kernel(const PostPar
   const bf16x8* w2 = reinterpret_cast<const bf16x8*>(p.w2h_bf16p);   // [OB][WhP/16][64], k permuted
   const int KS2 = p.WhP / 16;
   const int nhb = p.WhP / 32, hb_per_wave = nhb / 4;   // WhP is a multiple of 128
-  f32x16 oacc[kPostMaxOB];
+  f32x16 oacc[OBT];
 #pragma unroll
-  for (int ob = 0; ob < kPostMaxOB; ++ob)
+  for (int ob = 0; ob < OBT; ++ob)
 #pragma unroll
     for (int i = 0; i < 16; ++i) oacc[ob][i] = 0.f;
 
@@ -149,11 +157,15 @@ __global__ __launch_bounds__(kThreadsN) void node_post_bf16_kernel(const PostPar
   }
   for (int q = 0; q < hb_per_wave; ++q) {
     const int hb = wave * hb_per_wave + q;
-    {
+    if constexpr (PF) {
       const int hbn = q + 1 < hb_per_wave ? hb + 1 : hb;
       const bf16x8* w1b = w1 + ((size_t)hbn * KS1) * 64 + lane;
 #pragma unroll
       for (int s = 0; s < kMaxKS1; ++s) wn[s] = w1b[(size_t)(s < KS1 ? s : 0) * 64];
+    } else if (q > 0) {
+      const bf16x8* w1b = w1 + ((size_t)hb * KS1) * 64 + lane;
+#pragma unroll
+      for (int s = 0; s < kMaxKS1; ++s) wf[s] = w1b[(size_t)(s < KS1 ? s : 0) * 64];
     }
     f32x16 acc;
 #pragma unroll
@@ -172,7 +184,7 @@ __global__ __launch_bounds__(kThreadsN) void node_post_bf16_kernel(const PostPar
       hf[i >> 3][i & 7] = (__bf16)silu_f(acc[i] + bias);
     }
 #pragma unroll
-    for (int ob = 0; ob < kPostMaxOB; ++ob)
+    for (int ob = 0; ob < OBT; ++ob)
       if (ob < OB) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -180,12 +192,14 @@ __global__ __launch_bounds__(kThreadsN) void node_post_bf16_kernel(const PostPar
           oacc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hf[s], oacc[ob], 0, 0, 0);
         }
       }
+    if constexpr (PF) {
 #pragma unroll
-    for (int s = 0; s < kMaxKS1; ++s) wf[s] = wn[s];
+      for (int s = 0; s < kMaxKS1; ++s) wf[s] = wn[s];
+    }
   }
   // cross-wave sum (fixed order) and store: oacc[ob][i] = out^T[o = 32ob + acc_row(i), node = r]
 #pragma unroll
-  for (int ob = 0; ob < kPostMaxOB; ++ob)
+  for (int ob = 0; ob < OBT; ++ob)
     if (ob < OB) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) red[((size_t)(wave * OB + ob) * 16 + i) * 64 + lane] = oacc[ob][i];
@@ -204,8 +218,9 @@ __global__ __launch_bounds__(kThreadsN) void node_post_bf16_kernel(const PostPar
 }  // namespace
 
 int init_node_bf16_attributes() {
-  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&node_post_bf16_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  const void* fns[] = {reinterpret_cast<const void*>(&node_post_bf16_kernel<2>),
+                       reinterpret_cast<const void*>(&node_post_bf16_kernel<kPostMaxOB>)};
+  for (const void* f : fns) EGNN_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   return EGNN_OK;
 }
 
@@ -215,8 +230,10 @@ bool node_post_bf16_supported(const PostParams& q) {
 }
 
 int launch_node_post_bf16(const PostParams& q, hipStream_t st) {
-  hipLaunchKernelGGL(node_post_bf16_kernel, dim3((q.N + kNodes - 1) / kNodes), dim3(kThreadsN),
-                     nb_smem_bytes(q.K1Q, q.HP / 32) + (kNodes + kThreadsN) * 4, st, q);
+  const dim3 grid((q.N + kNodes - 1) / kNodes);
+  const size_t sm = nb_smem_bytes(q.K1Q, q.HP / 32) + (kNodes + kThreadsN) * 4;
+  if (q.HP <= 64) hipLaunchKernelGGL(node_post_bf16_kernel<2>, grid, dim3(kThreadsN), sm, st, q);
+  else hipLaunchKernelGGL(node_post_bf16_kernel<kPostMaxOB>, grid, dim3(kThreadsN), sm, st, q);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }
