@@ -109,6 +109,8 @@ struct egnn_ctx {
   float* h_tmp[2] = {nullptr, nullptr};  // [N][H] ping-pong between layers
   float* x_tmp[2] = {nullptr, nullptr};  // [N][3]
   egnn::Sampler smp;
+  hipStream_t side = nullptr;                       // small graphs: the message edge kernel runs beside the coordinate kernel
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // profiling
   bool prof = false;
   std::vector<hipEvent_t> ev;  // pairs

@@ -919,6 +919,17 @@ static void prof_end(egnn_ctx* c, hipStream_t st) {
   c->ev_used += 2;
 }
 
+// side stream + fork / join events of a context (created on first use, outside any capture: egnn_set_graph)
+static int fork_streams(egnn_ctx* c) {
+  if (c->side) return EGNN_OK;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  (void)cs;
+  if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { c->side = nullptr; return EGNN_EHIP; }
+  if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) return EGNN_EHIP;
+  return EGNN_OK;
+}
+
 int init_kernel_attributes() {
   // raise the dynamic-LDS limit of every big kernel once, outside any stream capture
   static bool done = false;
@@ -1109,8 +1120,20 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
       // coordinate kernels with the phase-opposed K loop of edge_bf16_v3.hip, message kernel with the in-wave pipeline
       // of edge_bf16_v4.hip: each the faster one for its shape (EGNN_V4_X=1 selects the v4 coordinate kernel, A/B)
       static const int v4x = getenv("EGNN_V4_X") ? atoi(getenv("EGNN_V4_X")) : 0;
+      // Small graphs (fewer workgroups than CUs): the coordinate and the message kernel are independent of each other --
+      // the message kernel goes to a side stream between two events (fork / join; under capture they become graph edges)
+      // so that the layer waits for the longer of the two instead of their sum.
+      static const int fork_sel = getenv("EGNN_FORK") ? atoi(getenv("EGNN_FORK")) : 1;   // A/B switch
+      const bool fork = fork_sel && !v4x && !c->prof && st != nullptr && (size_t)E * 3 <= (size_t)256 * 128 /* all workgroups of both kernels resident at once */ && fork_streams(c) == EGNN_OK;
       if (v4x) rc = launch_edge_bf16_v4(p, st);
-      else {
+      else if (fork) {
+        EGNN_HIP(hipEventRecord(c->ev_fork, st));
+        EGNN_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+        rc = launch_edge_bf16_v3_x(p, st);
+        if (!rc) rc = launch_edge_bf16_v4_m(p, c->side);
+        EGNN_HIP(hipEventRecord(c->ev_join, c->side));
+        EGNN_HIP(hipStreamWaitEvent(st, c->ev_join, 0));
+      } else {
         rc = launch_edge_bf16_v3_x(p, st);
         if (!rc) rc = launch_edge_bf16_v4_m(p, st);
       }
@@ -1238,6 +1261,9 @@ int egnn_destroy(egnn_ctx* c) {
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   sampler_free(c);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->side) (void)hipStreamDestroy(c->side);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   delete c;
   return EGNN_OK;
@@ -1384,6 +1410,7 @@ int egnn_set_graph(egnn_ctx* c, int N, int E, int B, const int32_t* edge_dst, co
   c->edge_dst = edge_dst; c->edge_src = edge_src; c->row_ptr = row_ptr; c->graph_ptr = graph_ptr;
   c->node_graph = node_graph;
   c->smp.ready = false;
+  (void)fork_streams(c);   // not inside a later stream capture
   return reserve(c);
 }
 
