@@ -103,6 +103,7 @@ struct egnn_ctx {
   float* gscale = nullptr;   // [B] sum of d^2 per graph (G^2); node_post applies 1/(G+1)
   int last_R = 64, last_nsplit_x = 1;   // edge path chosen by the last launch_layer_begin
   bool sq_from_agg = false;             // node_post takes the d^2 sums from the coordinate sums' component 3
+  float* h_partial = nullptr;  // [8][N][H] partial node-MLP outputs (hidden-split node_post at small N)
   float* bwd_s = nullptr;    // [nsplit][chunk edges] column-split shares of s_e (backward recompute)
   size_t cap_bwd_s = 0;
   unsigned long long* stamps = nullptr;  // [2 kernels][8 waves][32 chunks][4] diagnostic time stamps

@@ -265,7 +265,10 @@ __global__ void pack_w1_hilo(const float* __restrict__ w1catT, int H, int TC, __
   }
 }
 
-constexpr int kPre3Nodes = 32, kPre3Cols = 1024;   // workgroup = 32 nodes x 1024 columns, wave w owns 8 column blocks
+// workgroup = 32 nodes x (4 waves x NBW column blocks): NBW = 8 (1024 columns) to amortise the h tile at large N,
+// NBW = 2 (256 columns) when the whole launch is a handful of workgroups and their serial length is the layer's latency
+constexpr int kPre3Nodes = 32;
+template <int NBW>
 __global__ __launch_bounds__(kThreads) void node_pre_hilo_kernel(const float* __restrict__ h, int N, int H,
                                                                  const bf16x8* __restrict__ w1hl,
                                                                  const float* __restrict__ b1cat, int TC,
@@ -290,12 +293,13 @@ __global__ __launch_bounds__(kThreads) void node_pre_hilo_kernel(const float* __
       ahi[ks][j] = hi;
       alo[ks][j] = (__bf16)(v - (float)hi);
     }
-  const int cb0 = (blockIdx.y * kPre3Cols) / 32 + wave * 8;   // first column block of this wave
-  constexpr int kLd = 128 + 8;   // halves per staged row (4 column blocks = 128 columns at a time)
+  const int cb0 = (blockIdx.y * 4 + wave) * NBW;   // first column block of this wave
+  constexpr int kLd = 128 + 8;   // halves per staged row (up to 4 column blocks = 128 columns at a time)
+  constexpr int kPairs = NBW >= 4 ? 2 : NBW / 2;   // pairs of column blocks per staging round
   _Float16* stg = reinterpret_cast<_Float16*>(smem_raw + 48 * 33 * 4) + (size_t)wave * 32 * kLd;
-  for (int half8 = 0; half8 < 2; ++half8) {
+  for (int half8 = 0; half8 < (NBW + 3) / 4; ++half8) {
 #pragma unroll
-    for (int pair = 0; pair < 2; ++pair) {   // 2 column blocks = 12 fragment loads in flight
+    for (int pair = 0; pair < kPairs; ++pair) {   // 2 column blocks = 12 fragment loads in flight
       bf16x8 bf[2][3][2];
 #pragma unroll
       for (int jb = 0; jb < 2; ++jb) {
@@ -324,10 +328,11 @@ __global__ __launch_bounds__(kThreads) void node_pre_hilo_kernel(const float* __
       }
     }
     __builtin_amdgcn_wave_barrier();
-    // this wave's 32 rows x 128 columns as 16-byte pieces: 256 contiguous bytes per row
+    // this wave's 32 rows x (64 kPairs) columns as 16-byte pieces: up to 256 contiguous bytes per row
     const int cbase = 32 * (cb0 + 4 * half8);
-    for (int q = lane; q < 32 * 16; q += 64) {
-      const int row = q >> 4, piece = q & 15, n = n0 + row, col = cbase + 8 * piece;
+    constexpr int kPieces = 8 * kPairs;   // 16-byte pieces per row
+    for (int q = lane; q < 32 * kPieces; q += 64) {
+      const int row = q / kPieces, piece = q % kPieces, n = n0 + row, col = cbase + 8 * piece;
       if (n < N && col < TC)
         *reinterpret_cast<f32x4*>(table + (size_t)n * TC + col) = *reinterpret_cast<const f32x4*>(stg + row * kLd + 8 * piece);
     }
@@ -877,6 +882,7 @@ int reserve(egnn_ctx* c) {
     if ((rc = dev_alloc(&c->agg_m, n * c->MP))) return rc;
     if ((rc = dev_alloc(&c->agg_x, 2 * n * 4))) return rc;
     if ((rc = dev_alloc(&c->node_d2, n))) return rc;
+    if ((rc = dev_alloc(&c->h_partial, n <= 1024 ? (size_t)8 * n * c->H : 0))) return rc;
     for (int i = 0; i < 2; ++i) {
       if ((rc = dev_alloc(&c->h_tmp[i], n * c->H))) return rc;
       if ((rc = dev_alloc(&c->x_tmp[i], n * 3))) return rc;
@@ -940,7 +946,9 @@ int init_kernel_attributes() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&node_post_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&node_pre_hilo_kernel),
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&node_pre_hilo_kernel<8>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&node_pre_hilo_kernel<2>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   int rc = init_edge_bf16_v2_attributes();
   if (rc) return rc;
@@ -997,11 +1005,16 @@ static int launch_node_pre_f16(egnn_ctx* c, hipStream_t st, int layer, const flo
   const int N = c->N;
   static const int pre_sel = getenv("EGNN_PRE") ? atoi(getenv("EGNN_PRE")) : 3;   // A/B switch: 1 VALU, 2 f32 MFMA, 3 bf16 hi/lo
   if (pre_sel >= 3 && c->H <= 48) {
-    dim3 grid((N + kPre3Nodes - 1) / kPre3Nodes, (c->TC + kPre3Cols - 1) / kPre3Cols);
+    const int ntile = (N + kPre3Nodes - 1) / kPre3Nodes;
     const size_t sm = (size_t)48 * 33 * 4 + (size_t)4 * 32 * (128 + 8) * 2;
-    hipLaunchKernelGGL(node_pre_hilo_kernel, grid, dim3(kThreads), sm, st, h, N, c->H,
-                       reinterpret_cast<const bf16x8*>(c->layers[layer].w1hl_bf16), b1cat, c->TC,
-                       reinterpret_cast<_Float16*>(c->table));
+    const bf16x8* w1hl = reinterpret_cast<const bf16x8*>(c->layers[layer].w1hl_bf16);
+    _Float16* tab = reinterpret_cast<_Float16*>(c->table);
+    if (ntile * (c->TC / 1024) >= 256)
+      hipLaunchKernelGGL(node_pre_hilo_kernel<8>, dim3(ntile, (c->TC + 1023) / 1024), dim3(kThreads), sm, st, h, N, c->H, w1hl,
+                         b1cat, c->TC, tab);
+    else
+      hipLaunchKernelGGL(node_pre_hilo_kernel<2>, dim3(ntile, (c->TC + 255) / 256), dim3(kThreads), sm, st, h, N, c->H, w1hl,
+                         b1cat, c->TC, tab);
   } else if (pre_sel >= 2 && c->H <= 64) {
     dim3 grid((N + kPre2Nodes - 1) / kPre2Nodes, (c->TC + kPre2Cols - 1) / kPre2Cols);
     const size_t sm = (size_t)((c->H + 1) & ~1) * 33 * sizeof(float);
@@ -1183,6 +1196,7 @@ int launch_layer_end(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_
     q.w1h = reinterpret_cast<const f32x4*>(lp.w1h_f32); q.w2h = reinterpret_cast<const f32x4*>(lp.w2h_f32);
     q.b1h = lp.b1h; q.b2h = lp.b2h; q.h_out = h_out; q.x_out = x_out;
     q.w1h_bf16 = lp.w1h_bf16; q.w2h_bf16p = lp.w2h_bf16p; q.K1Q = c->K1Q;
+    q.h_partial = c->h_partial;
     static const int post_sel = getenv("EGNN_POST") ? atoi(getenv("EGNN_POST")) : 2;   // A/B switch
     prof_begin(c, st, 1);
     if (prec == EGNN_PREC_BF16 && post_sel >= 2 && node_post_bf16_supported(q)) {
@@ -1256,7 +1270,7 @@ int egnn_destroy(egnn_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   for (auto& lp : c->layers) free_layer(lp);
-  void* ptrs[] = {c->table, c->agg_m, c->agg_x, c->part_m, c->part_x, c->node_d2, c->gscale, c->bwd_s,
+  void* ptrs[] = {c->table, c->agg_m, c->agg_x, c->part_m, c->part_x, c->node_d2, c->gscale, c->bwd_s, c->h_partial,
                   c->h_tmp[0], c->h_tmp[1], c->x_tmp[0], c->x_tmp[1]};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);

@@ -268,6 +268,7 @@ struct PostParams {
   int K1Q;                            // H + MP rounded up to 16
   const float *b1h, *b2h;
   float *h_out, *x_out;
+  float* h_partial;   // [8][N][H] scratch of the hidden-split form (small N), or null
 };
 int launch_node_post_bf16(const PostParams& q, hipStream_t st);
 bool node_post_bf16_supported(const PostParams& q);

@@ -37,6 +37,21 @@ __global__ __launch_bounds__(kThreadsN, (OBT > 2 ? 1 : 2)) void node_post_bf16_k
   const int KS1 = p.K1Q / 16, OB = p.HP / 32;
   float* red = reinterpret_cast<float*>(smem + (size_t)(p.K1Q / 8) * 33 * 16);
 
+  const bf16x8* w1 = reinterpret_cast<const bf16x8*>(p.w1h_bf16);    // [WhP/32][KS1][64]
+  const bf16x8* w2 = reinterpret_cast<const bf16x8*>(p.w2h_bf16p);   // [OB][WhP/16][64], k permuted
+  const int KS2 = p.WhP / 16;
+  // hidden units: split over the gridDim.y workgroups of a node tile (1 = all here), then over the 4 waves
+  const int hsplit = gridDim.y, hsi = blockIdx.y;
+  const int nhb = p.WhP / 32, hb_per_wave = nhb / (4 * hsplit), hb0 = hsi * (nhb / hsplit);
+  // the first hidden block's W1h fragments depend on nothing: requested before the gather so that their L2 / HBM round
+  // trip runs under it (at B = 1 a layer's node_post is a chain of such round trips and little else)
+  bf16x8 wf[kMaxKS1];
+  {
+    const bf16x8* w1b = w1 + ((size_t)(hb0 + wave * hb_per_wave) * KS1) * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < kMaxKS1; ++s) wf[s] = w1b[(size_t)(s < KS1 ? s : 0) * 64];
+  }
+
   // gather [h | sum_m] (tile partials added in tile order), pack to bf16 in the fragment image.  The CSR lookups of the
   // 32 nodes go through LDS first and the item loop is unrolled: independent loads in flight instead of a chain of
   // dependent ones per item (which nothing hides when the layer has one or two of these workgroups).
@@ -83,7 +98,7 @@ __global__ __launch_bounds__(kThreadsN, (OBT > 2 ? 1 : 2)) void node_post_bf16_k
   // 32 nodes (a latency-bound loop of dependent loads otherwise).  Either way every workgroup that needs a graph's
   // sum adds the same values in the same order: the result is bitwise the same everywhere.
   float* gsq = reinterpret_cast<float*>(smem + nb_smem_bytes(p.K1Q, p.HP / 32));   // [kNodes] then [kThreadsN] scratch
-  if (p.sq_from_agg) {
+  if (p.sq_from_agg && blockIdx.y == 0) {
     float* red = gsq + kNodes;
     const int node = tid >> 3, n = n0 + node;
     int g = -1, lo = 0, hi = 0;
@@ -111,8 +126,8 @@ __global__ __launch_bounds__(kThreadsN, (OBT > 2 ? 1 : 2)) void node_post_bf16_k
     }
     __syncthreads();
   }
-  // coordinate update
-  if (tid < kNodes * 3) {
+  // coordinate update (by the first of the workgroups that share this node tile)
+  if (blockIdx.y == 0 && tid < kNodes * 3) {
     const int node = tid / 3, d = tid % 3, n = n0 + node;
     if (n < p.N) {
       const int t0 = s_t0[node], t1 = s_t1[node];
@@ -135,10 +150,6 @@ __global__ __launch_bounds__(kThreadsN, (OBT > 2 ? 1 : 2)) void node_post_bf16_k
   }
   __syncthreads();
 
-  const bf16x8* w1 = reinterpret_cast<const bf16x8*>(p.w1h_bf16);    // [WhP/32][KS1][64]
-  const bf16x8* w2 = reinterpret_cast<const bf16x8*>(p.w2h_bf16p);   // [OB][WhP/16][64], k permuted
-  const int KS2 = p.WhP / 16;
-  const int nhb = p.WhP / 32, hb_per_wave = nhb / 4;   // WhP is a multiple of 128
   f32x16 oacc[OBT];
 #pragma unroll
   for (int ob = 0; ob < OBT; ++ob)
@@ -149,14 +160,9 @@ __global__ __launch_bounds__(kThreadsN, (OBT > 2 ? 1 : 2)) void node_post_bf16_k
   // The W1h fragments of a hidden block (KS1 <= kMaxKS1 k-steps, 1 KiB each) are all requested before the
   // block's MFMA chain, and the next block's while this one is multiplied: one exposed L2 round trip per
   // wave instead of one per k-step.
-  bf16x8 wf[kMaxKS1], wn[kMaxKS1];
-  {
-    const bf16x8* w1b = w1 + ((size_t)(wave * hb_per_wave) * KS1) * 64 + lane;
-#pragma unroll
-    for (int s = 0; s < kMaxKS1; ++s) wf[s] = w1b[(size_t)(s < KS1 ? s : 0) * 64];
-  }
+  bf16x8 wn[kMaxKS1];
   for (int q = 0; q < hb_per_wave; ++q) {
-    const int hb = wave * hb_per_wave + q;
+    const int hb = hb0 + wave * hb_per_wave + q;
     if constexpr (PF) {
       const int hbn = q + 1 < hb_per_wave ? hb + 1 : hb;
       const bf16x8* w1b = w1 + ((size_t)hbn * KS1) * 64 + lane;
@@ -211,8 +217,21 @@ __global__ __launch_bounds__(kThreadsN, (OBT > 2 ? 1 : 2)) void node_post_bf16_k
 #pragma unroll
     for (int w = 0; w < 4; ++w) v += red[((size_t)(w * OB + ob) * 16 + i) * 64 + l];
     const int o = 32 * ob + acc_row(i, l), n = n0 + (l & 31);
-    if (n < p.N && o < p.H) p.h_out[(size_t)n * p.H + o] = v + p.b2h[o];
+    if (n < p.N && o < p.H) {
+      if (hsplit == 1) p.h_out[(size_t)n * p.H + o] = v + p.b2h[o];
+      else p.h_partial[((size_t)hsi * p.N + n) * p.H + o] = v;   // summed (+ bias) by node_post_finish_kernel
+    }
   }
+}
+
+// second launch of the hidden-split form: h'[n][o] = b2[o] + sum over the splits, in split order (deterministic)
+__global__ void node_post_finish_kernel(int N, int H, int hsplit, const float* __restrict__ partial,
+                                        const float* __restrict__ b2h, float* __restrict__ h_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * H) return;
+  float v = b2h[i % H];
+  for (int s = 0; s < hsplit; ++s) v += partial[(size_t)s * N * H + i];
+  h_out[i] = v;
 }
 
 }  // namespace
@@ -230,10 +249,19 @@ bool node_post_bf16_supported(const PostParams& q) {
 }
 
 int launch_node_post_bf16(const PostParams& q, hipStream_t st) {
-  const dim3 grid((q.N + kNodes - 1) / kNodes);
+  const int tiles = (q.N + kNodes - 1) / kNodes;
+  // Few node tiles (small graphs): a layer would wait for ONE workgroup's serial chain over all hidden blocks (40 us).
+  // Split the hidden units over `hs` workgroups per tile (partial h' to scratch) and add them up in a second tiny launch:
+  // the kernel boundary is the synchronisation, no cross-workgroup fences.
+  int hs = 1;
+  if (q.h_partial && tiles * 8 <= 256 && (q.WhP / 32) % 32 == 0) hs = 8;
+  const dim3 grid(tiles, hs);
   const size_t sm = nb_smem_bytes(q.K1Q, q.HP / 32) + (kNodes + kThreadsN) * 4;
   if (q.HP <= 64) hipLaunchKernelGGL(node_post_bf16_kernel<2>, grid, dim3(kThreadsN), sm, st, q);
   else hipLaunchKernelGGL(node_post_bf16_kernel<kPostMaxOB>, grid, dim3(kThreadsN), sm, st, q);
+  if (hs > 1)
+    hipLaunchKernelGGL(node_post_finish_kernel, dim3((q.N * q.H + 255) / 256), dim3(256), 0, st, q.N, q.H, hs, q.h_partial,
+                       q.b2h, q.h_out);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }
