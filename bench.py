@@ -372,17 +372,21 @@ def slab_leg(args, rk, steps, warmup):
         out.update({"value": n * steps / el, "ms_per_step": el * 1e3 / steps, "nonfinite_graphs": bad,
                     "implementation": "DeviceSampler on one GPU, hipGraph replay"})
         return out
-    single_ms = None
-    if rank == 0:
-        el1, _ = time_single()
-        single_ms = el1 * 1e3 / steps
     smp = dma.PartitionedSampler(net, proc, [n], cond, ei, rank, world, atom_type_size=A, seed=0, norm_scope="graph", device=dev)
     smp.init()
     smp.run(nsteps=warmup)
     el = rk.timed(lambda: smp.run(nsteps=steps))
-    out.update({"value": n * steps / el, "ms_per_step": el * 1e3 / steps, "nonfinite_graphs": int(smp.bad.sum()),
+    nonfinite = int(smp.bad.sum())
+    local_edges = smp.plan.E
+    del smp
+    single_ms = None
+    if rank == 0:     # the unpartitioned sampler on the same graph, after the collective part
+        el1, _ = time_single()
+        single_ms = el1 * 1e3 / steps
+    rk.barrier()
+    out.update({"value": n * steps / el, "ms_per_step": el * 1e3 / steps, "nonfinite_graphs": nonfinite,
                 "implementation": f"PartitionedSampler, receiving nodes over {world} ranks, 2 collectives per layer "
-                                  f"({rk.backend})", "local_edges_rank0": smp.plan.E,
+                                  f"({rk.backend})", "local_edges_rank0": local_edges,
                 "single_gpu_ms_per_step": single_ms,
                 "note": "at 40 k edges one GPU runs a step in about the time of the 2 x L latency-bound collectives a "
                         "partitioned step adds; the partition pays for graphs two orders of magnitude larger"})

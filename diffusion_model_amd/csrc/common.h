@@ -133,6 +133,7 @@ int backward_recompute(egnn_ctx* c, hipStream_t st, int layer, const float* x, c
 int backward_dgrad(egnn_ctx* c, hipStream_t st, int layer, const float* x, int e_first, int n_edges, const void* g_a2x,
                    const void* g_a2m, void* g_a1x, void* g_a1m);
 int init_edge_dgrad_attributes();
+int fork_streams(egnn_ctx* c);
 int launch_edge_dgrad(int N, int E, const int* dst, const int* src, const float* x, const void* table, int TC, int offP, int offQ,
                       const float* wd, const void* g_a2, int Kd, const void* w2t, int KP, void* g_a1_out, hipStream_t st);
 }  // namespace egnn

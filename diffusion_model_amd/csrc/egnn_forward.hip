@@ -925,11 +925,13 @@ static void prof_end(egnn_ctx* c, hipStream_t st) {
   c->ev_used += 2;
 }
 
-// side stream + fork / join events of a context (created on first use, outside any capture: egnn_set_graph)
-static int fork_streams(egnn_ctx* c) {
+// Side stream + fork / join events of a context.  Created only for the sampler of a SMALL graph (egnn_sampler_prepare, i.e.
+// outside any stream capture), never for training contexts: with two ranks sharing one GPU over gloo, the mere existence
+// of one more HIP stream in the process made every gradient all-reduce take seconds (round-2 rehearsal, blocking or
+// non-blocking flag alike) -- the workloads that fork never run a collective.
+int fork_streams(egnn_ctx* c) {
   if (c->side) return EGNN_OK;
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  (void)cs;
+  if ((size_t)c->E * 3 > (size_t)256 * 128) return EGNN_OK;   // not a fork candidate
   if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { c->side = nullptr; return EGNN_EHIP; }
   if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) return EGNN_EHIP;
@@ -1137,7 +1139,8 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
       // the message kernel goes to a side stream between two events (fork / join; under capture they become graph edges)
       // so that the layer waits for the longer of the two instead of their sum.
       static const int fork_sel = getenv("EGNN_FORK") ? atoi(getenv("EGNN_FORK")) : 1;   // A/B switch
-      const bool fork = fork_sel && !v4x && !c->prof && st != nullptr && (size_t)E * 3 <= (size_t)256 * 128 /* all workgroups of both kernels resident at once */ && fork_streams(c) == EGNN_OK;
+      const bool fork = fork_sel && !v4x && !c->prof && st != nullptr && c->side != nullptr &&
+                        (size_t)E * 3 <= (size_t)256 * 128;   // all workgroups of both kernels resident at once
       if (v4x) rc = launch_edge_bf16_v4(p, st);
       else if (fork) {
         EGNN_HIP(hipEventRecord(c->ev_fork, st));
@@ -1424,7 +1427,6 @@ int egnn_set_graph(egnn_ctx* c, int N, int E, int B, const int32_t* edge_dst, co
   c->edge_dst = edge_dst; c->edge_src = edge_src; c->row_ptr = row_ptr; c->graph_ptr = graph_ptr;
   c->node_graph = node_graph;
   c->smp.ready = false;
-  (void)fork_streams(c);   // not inside a later stream capture
   return reserve(c);
 }
 

@@ -500,6 +500,7 @@ int egnn_sampler_prepare(egnn_ctx* c, int T, int A, float onehot_scale, const fl
   EGNN_HIP(hipSetDevice(c->device));
   EGNN_HIP(hipDeviceSynchronize());
   sampler_free(c);
+  (void)fork_streams(c);   // small graphs: the message edge kernel runs beside the coordinate kernel
   Sampler& s = c->smp;
   const size_t N = c->N;
   EGNN_HIP(hipMalloc((void**)&s.pos, N * 3 * sizeof(float)));
