@@ -193,3 +193,50 @@ def test_checkpoint_contract(tmp_path):
     raw["GammaNetwork"] = raw.pop("gamma")                       # layout written by train.py:358-366
     torch.save(raw, path)
     dma.load_model_state(dst, path, params)
+
+
+# ---------------- host logic: property tests (hypothesis) ----------------
+from hypothesis import given, settings, strategies as st  # noqa: E402
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.integers(1, 500), st.integers(1, 17))
+def test_node_ranges_partition_every_node_once(n, world):
+    from diffusion_model_amd.partition import node_ranges
+    rg = node_ranges(n, world)
+    assert len(rg) == world and rg[0][0] == 0 and rg[-1][1] == n
+    assert all(a[1] == b[0] for a, b in zip(rg, rg[1:]))            # contiguous, in rank order
+    sizes = [hi - lo for lo, hi in rg]
+    assert max(sizes) - min(sizes) <= 1 and sum(sizes) == n          # near-equal
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.lists(st.integers(1, 9), min_size=1, max_size=5), st.integers(0, 60), st.integers(0, 2 ** 31 - 1))
+def test_graph_plan_is_a_csr_view_of_any_edge_list(sizes, n_edges, seed):
+    """GraphPlan on an arbitrary (unsorted, duplicated, self-looped) intra-graph edge list: CSR by receiving node, the
+    caller's order kept inside a node, graph ranges from the sizes; local_plan keeps exactly the rows of a node range."""
+    from diffusion_model_amd.graph import GraphPlan
+    from diffusion_model_amd.partition import local_plan, node_ranges
+    g = torch.Generator().manual_seed(seed)
+    n = sum(sizes)
+    gid = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    off = torch.tensor([0] + list(np.cumsum(sizes)))
+    which = torch.randint(0, len(sizes), (n_edges,), generator=g)
+    lo, sz = off[which], torch.tensor(sizes)[which]
+    dst = lo + (torch.rand(n_edges, generator=g) * sz).long().clamp(max=sz - 1) if n_edges else torch.zeros(0, dtype=torch.long)
+    src = lo + (torch.rand(n_edges, generator=g) * sz).long().clamp(max=sz - 1) if n_edges else torch.zeros(0, dtype=torch.long)
+    ei = torch.stack((dst, src))
+    plan = GraphPlan(ei, n, sizes=sizes)
+    assert plan.N == n and plan.E == n_edges and plan.B == len(sizes)
+    rp = plan.row_ptr.long()
+    assert rp[0] == 0 and rp[-1] == n_edges and bool((rp[1:] >= rp[:-1]).all())
+    assert torch.equal(torch.bincount(dst, minlength=n), rp[1:] - rp[:-1])
+    assert bool((plan.edge_dst[1:] >= plan.edge_dst[:-1]).all()) if n_edges > 1 else True
+    for node in range(n):                                           # stable: the caller's order inside a node
+        assert torch.equal(plan.edge_src[rp[node]:rp[node + 1]].long(), src[dst == node])
+    assert torch.equal(plan.graph_ptr.long(), off) and torch.equal(plan.node_graph.long(), gid)
+    for lo_, hi_ in node_ranges(n, 3):
+        lp = local_plan(ei, n, lo_, hi_, sizes=sizes)
+        keep = (dst >= lo_) & (dst < hi_)
+        assert lp.E == int(keep.sum()) and lp.N == n
+        assert torch.equal(lp.row_ptr.long()[lo_ + 1:hi_ + 1] - lp.row_ptr.long()[lo_:hi_], (rp[1:] - rp[:-1])[lo_:hi_])
