@@ -13,6 +13,8 @@
 // is in flight; the B operand streams from W2 packed TRANSPOSED (k = second-layer output n, column = hidden unit k).
 // Epilogue: SiLU'(a1) from the forward's fp16 first-layer table (two 2-byte gathers per element, 64 contiguous bytes per
 // half-wave), product, row-major bf16 store through the per-wave LDS transpose.
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace egnn {
@@ -41,8 +43,11 @@ struct DgradParams {
   void* g_a1_out;           // bf16 [E][KP]
 };
 
+// CB = 32-column blocks per wave: 2 = 512 output columns per workgroup (252 VGPRs, one workgroup per CU); 1 = 256 columns
+// (<= 128 VGPRs, TWO workgroups per CU: one's SiLU' epilogue runs under the other's K loop; the dL/da2 tile is then
+// copied by four workgroups instead of two, which costs L2 reads only -- there is no vector arithmetic to duplicate).
 template <int CB>
-__global__ __launch_bounds__(kTD, 2) void edge_dgrad_kernel(const DgradParams p) {
+__global__ __launch_bounds__(kTD, (CB == 1 ? 4 : 2)) void edge_dgrad_kernel(const DgradParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* s_dst = reinterpret_cast<int*>(smem + kOffDstD);
   int* s_src = reinterpret_cast<int*>(smem + kOffSrcD);
@@ -205,8 +210,9 @@ int launch_edge_dgrad(int N, int E, const int* dst, const int* src, const float*
   p.N = N; p.E = E; p.edge_dst = dst; p.edge_src = src; p.x = x; p.table = table; p.TC = TC; p.offP = offP; p.offQ = offQ;
   p.wd = wd; p.g_a2 = g_a2; p.Kd = Kd; p.w2t = w2t; p.KP = KP; p.g_a1_out = g_a1_out;
   const int tiles = (E + kRD - 1) / kRD;
-  if (KP >= 512) hipLaunchKernelGGL(edge_dgrad_kernel<2>, dim3(tiles * (KP / 512)), dim3(kTD), kSmemD, st, p);
-  else hipLaunchKernelGGL(edge_dgrad_kernel<1>, dim3(tiles), dim3(kTD), kSmemD, st, p);
+  static const int cb_sel = getenv("EGNN_DGRAD_CB") ? atoi(getenv("EGNN_DGRAD_CB")) : 2;   // A/B switch (1: equal time, twice the L2 reads)
+  if (KP >= 512 && cb_sel >= 2) hipLaunchKernelGGL(edge_dgrad_kernel<2>, dim3(tiles * (KP / 512)), dim3(kTD), kSmemD, st, p);
+  else hipLaunchKernelGGL(edge_dgrad_kernel<1>, dim3(tiles * (KP / 256)), dim3(kTD), kSmemD, st, p);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }
