@@ -13,6 +13,7 @@ from .preprocessor import SpectrumCompressor  # noqa: F401
 from .snr import GammaNetwork, PositiveLinear  # noqa: F401
 from .training import GradAllReducer, diffuse_as_batch, eval_epoch, train_epoch, train_step, training_loss  # noqa: F401
 from .checkpoint import load_model_state, save_model_state  # noqa: F401
+from .data import Batch, GraphData, GraphLoader, collate, load_dataset, make_graph, save_dataset  # noqa: F401
 
 __all__ = ["EGCL", "EquivariantGNN", "E3DiffusionProcess", "remove_mean", "GraphPlan",
            "fully_connected_edge_index", "DeviceSampler", "generate", "SpectrumCompressor",

@@ -186,6 +186,8 @@ def train_step(nn_dict, data, params, diffusion_process, optimizer, reducer: Opt
     egnn = nn_dict["egnn"]
     dev = data.pos.device
     optimizer.zero_grad()
+    if num_graphs is None:
+        num_graphs = getattr(data, "num_graphs", None)   # collated by data.collate: known on the host
     nb = int(data.batch.max().item()) + 1 if num_graphs is None else int(num_graphs)
     noised = diffuse_as_batch(data.pos, data.x, data.batch, diffusion_process, times=times, num_graphs=nb)
     cols = []
@@ -218,7 +220,8 @@ def _epoch(nn_dict, loader, params, diffusion_process, optimizer, train: bool, r
         nn_dict["spectrum_compressor"].train(train)
     total, nodes = 0.0, 0
     for data in loader:
-        nb = int(data.batch.max().item()) + 1
+        nb = getattr(data, "num_graphs", None)
+        nb = int(data.batch.max().item()) + 1 if nb is None else int(nb)
         nodes += data.pos.shape[0]
         if train:
             loss = train_step(nn_dict, data, params, diffusion_process, optimizer, reducer)
