@@ -69,7 +69,7 @@ __host__ __device__ inline size_t v4_smem_bytes(int KP, int MP, bool is_m) {
 // BWD = true (message kernel): the training backward's recompute pass over a chunk of edges: the activation chunks are
 // also written to HBM (s1_out) and the epilogue produces dL/d(a2m) through the gate instead of the segment sums.
 template <int CB, bool IS_M, bool BWD = false>
-__global__ __launch_bounds__(kT3, ((IS_M && !BWD) ? EGNN_V4_M_WAVES : 2)) void edge_kernel_bf16_v4(const EdgeParams p) {
+__global__ __launch_bounds__(kT3, ((CB == 1 && !BWD) ? EGNN_V4_M_WAVES : 2)) void edge_kernel_bf16_v4(const EdgeParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* s_dst = reinterpret_cast<int*>(smem + kOffDst);
   int* s_src = reinterpret_cast<int*>(smem + kOffSrc);
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(kT3, ((IS_M && !BWD) ? EGNN_V4_M_WAVES : 2)) void e
   uload(u0, vdst0, vsrc0, 2); uload(u1, vdst1, vsrc1, 2);
   // weight fragments, requested BQD k-steps ahead of their use (a whole chunk for the coordinate kernel; the message
   // kernel, compiled for <= 128 VGPRs so that two workgroups share a CU, keeps 2 -- its other workgroup covers the rest)
-  constexpr int BQD = (IS_M && !BWD && EGNN_V4_M_WAVES >= 4) ? 2 : 4;
+  constexpr int BQD = (CB == 1 && !BWD && EGNN_V4_M_WAVES >= 4) ? 2 : 4;
   bf16x8 bq[BQD][CB];
 #pragma unroll
   for (int s = 0; s < BQD; ++s)
@@ -593,6 +593,12 @@ int launch_edge_bf16_v4_m_bwd(const EdgeParams& p, hipStream_t st) {
   const int tiles = (p.E + kR3 - 1) / kR3;
   static_assert(8 * 32 * 72 * 2 <= kRing * kA1_3, "store staging must fit the K-loop buffers");
   return launch_v4<1, true, true>(p, tiles, v4_smem_bytes(p.WmP, p.MP, true), st);
+}
+
+// coordinate kernel as 256-column workgroups (two per CU), WxP / 256 column shares per tile
+int launch_edge_bf16_v4_x1(const EdgeParams& p, hipStream_t st) {
+  const int tiles = (p.E + kR3 - 1) / kR3;
+  return launch_v4<1, false>(p, tiles * (p.WxP / 256), v4_smem_bytes(p.WxP, p.MP, false), st);
 }
 
 // message kernel only

@@ -880,7 +880,7 @@ int reserve(egnn_ctx* c) {
     const size_t n = c->N;
     if ((rc = dev_alloc(&c->table, n * c->TC))) return rc;
     if ((rc = dev_alloc(&c->agg_m, n * c->MP))) return rc;
-    if ((rc = dev_alloc(&c->agg_x, 2 * n * 4))) return rc;
+    if ((rc = dev_alloc(&c->agg_x, 4 * n * 4))) return rc;   // up to 4 column-split copies
     if ((rc = dev_alloc(&c->node_d2, n))) return rc;
     if ((rc = dev_alloc(&c->h_partial, n <= 1024 ? (size_t)8 * n * c->H : 0))) return rc;
     for (int i = 0; i < 2; ++i) {
@@ -891,7 +891,7 @@ int reserve(egnn_ctx* c) {
   }
   if (tiles > c->cap_tiles) {
     if ((rc = dev_alloc(&c->part_m, (tiles + 1) * 2 * c->MP))) return rc;
-    if ((rc = dev_alloc(&c->part_x, 2 * (tiles + 1) * 2 * 4))) return rc;
+    if ((rc = dev_alloc(&c->part_x, 4 * (tiles + 1) * 2 * 4))) return rc;
     c->cap_tiles = tiles;
   }
   if (!c->stamps) {
@@ -1141,7 +1141,12 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
       static const int fork_sel = getenv("EGNN_FORK") ? atoi(getenv("EGNN_FORK")) : 1;   // A/B switch
       const bool fork = fork_sel && !v4x && !c->prof && st != nullptr && c->side != nullptr &&
                         (size_t)E * 3 <= (size_t)256 * 128;   // all workgroups of both kernels resident at once
-      if (v4x) rc = launch_edge_bf16_v4(p, st);
+      static const int x4 = getenv("EGNN_X4") ? atoi(getenv("EGNN_X4")) : 0;   // A/B: 256-column coordinate workgroups
+      if (x4 && p.WxP >= 512) {
+        nsplit_x = p.WxP / 256;
+        rc = launch_edge_bf16_v4_x1(p, st);
+        if (!rc) rc = launch_edge_bf16_v4_m(p, st);
+      } else if (v4x) rc = launch_edge_bf16_v4(p, st);
       else if (fork) {
         EGNN_HIP(hipEventRecord(c->ev_fork, st));
         EGNN_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));

@@ -280,6 +280,7 @@ bool edge_bf16_v3_supported(const EdgeParams& p);
 int edge_v3_rows();
 int launch_edge_bf16_v4(const EdgeParams& p, hipStream_t st);
 int launch_edge_bf16_v4_m(const EdgeParams& p, hipStream_t st);
+int launch_edge_bf16_v4_x1(const EdgeParams& p, hipStream_t st);   // 256-column coordinate workgroups (A/B switch EGNN_X4)
 int launch_edge_bf16_v3_x(const EdgeParams& p, hipStream_t st);
 int launch_edge_bf16_v3_x_bwd(const EdgeParams& p, hipStream_t st);
 int launch_edge_bf16_v4_m_bwd(const EdgeParams& p, hipStream_t st);
