@@ -252,11 +252,13 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
         if (s == 1) { if (rb == 0) LDS_RD(a[0], 8256); if (rb == 1) LDS_RD(a[1], 8256 + 512); if (rb == 2) LDS_RD(a[2], 8256 + 1024); if (rb == 3) LDS_RD(a[3], 8256 + 1536); }
         if (s == 2) { if (rb == 0) LDS_RD(a[0], 12384); if (rb == 1) LDS_RD(a[1], 12384 + 512); if (rb == 2) LDS_RD(a[2], 12384 + 1024); if (rb == 3) LDS_RD(a[3], 12384 + 1536); }
       }
+#ifndef EGNN_EXP_W_ONCE   // timing experiment: keep the first chunk's weight fragments (real data, no weight stream)
       if (!last) {
         const unsigned ksn = (unsigned)((c + 1) * 4 + s) * 1024u;
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) bq[s][cb] = ldbuf_bf16x8(rs_w, lane16, w0 + (unsigned)cb * KS * 1024u + ksn);
       }
+#endif
       if (s == 0) STAMP2(c, 2, wave < 4);
     }
 #undef LDS_WAIT
