@@ -13,6 +13,11 @@ sums the edge pass produced (egcl_read_aggregates) are kept.  Backward, per laye
              dgrad / wgrad products of the four Linear layers, run by the BLAS library through torch.mm.
              bf16 mode stores the [edges, W] buffers and runs the GEMMs in bf16 (fp32 accumulate, fp32 master
              gradients); fp32 mode is fp32 end to end.
+             bf16 at the reference widths: the recompute half runs on the forward's own MFMA edge kernels
+             (egcl_backward_edge_recompute) and the dgrad half on egcl_backward_dgrad; and when HBM allows (default), the
+             forward runs as egcl_forward_save, which keeps the first-layer activations and the second-layer
+             pre-activations of every edge (7 GB per layer at 2^20 edges), so that the backward has NO recompute pass:
+             egcl_backward_heads_saved turns the kept pre-activations into dL/da2 in place at HBM speed.
 
 Math (reference EquivariantGraphNeuralNetwork.py:55-71), per edge e = (i <- j):
   in = [h_i | h_j | d2],  d2 = |x_i - x_j|^2
@@ -48,12 +53,14 @@ def _round_up(v, m):
 class _Workspace:
     """[chunk, width] buffers of the edge part, allocated once per backward call"""
 
-    def __init__(self, rows, H, Wx, Wm, M, dtype, device):
+    def __init__(self, rows, H, Wx, Wm, M, dtype, device, saved_activations=False):
         rows = _round_up(rows, 64)
         e = lambda *shape, dt=dtype: torch.empty(*shape, dtype=dt, device=device)
         self.K1P = _round_up(2 * H + 2, 8)
-        self.s1x, self.s1m = e(rows, Wx), e(rows, Wm)
-        self.a2x, self.a2m = e(rows, Wx), e(rows, M)
+        self.rows, self.dtype = rows, dtype
+        if not saved_activations:   # (the saved-activation backward reads s1 / a2 from what the forward kept)
+            self.s1x, self.s1m = e(rows, Wx), e(rows, Wm)
+            self.a2x, self.a2m = e(rows, Wx), e(rows, M)
         self.g1x, self.g1m = e(rows, Wx), e(rows, Wm)
         self.inp, self.g_in = e(rows, self.K1P), e(rows, self.K1P)
         self.d2 = e(rows, dt=torch.float32)
@@ -72,14 +79,16 @@ def _wgrad(g, a, n_pad, splits):
     return torch.bmm(gv.transpose(1, 2), av).float().sum(0)
 
 
-def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_S, g_h, g_x, grads, fused=None):
+def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_S, g_h, g_x, grads, fused=None, kept=None):
     """adds the edge part's contributions to g_h, g_x and to the parameter gradients in `grads`.
     ``fused`` = (context handle, layer index) when the bf16 recompute runs on the forward's own MFMA edge kernels
-    (egcl_backward_edge_recompute) instead of l1_act -> GEMM -> heads."""
+    (egcl_backward_edge_recompute) instead of l1_act -> GEMM -> heads.
+    ``kept`` = (s1x, s1m, t2x, t2m, s_shares) of this layer when the forward ran as egcl_forward_save: no recompute pass,
+    egcl_backward_heads_saved turns the kept pre-activations into dL/da2 in place."""
     L = _lib.lib()
     st = _lib.stream_ptr()
     P = _lib.ptr
-    dt = ws.s1x.dtype
+    dt = ws.dtype
     H, K1P = h.shape[1], ws.K1P
     lin_x0, lin_x2, lin_x4 = layer.mlp_x[0], layer.mlp_x[2], layer.mlp_x[4]
     lin_m0, lin_m2, att = layer.mlp_m[0], layer.mlp_m[2], layer.attention[0]
@@ -107,20 +116,29 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_
     g_b2m, g_wa, g_ba = torch.zeros(M, **f32), torch.zeros(M, **f32), torch.zeros(1, **f32)
     g_am, g_ax = g_am.contiguous(), g_ax.contiguous()
     E = dst32.numel()
-    rows = ws.s1x.shape[0]
+    rows = ws.rows
     if fused is not None:
         _lib.check(L.egcl_backward_table(fused[0], st, fused[1], P(h)))
     for a in range(0, E, rows):
         n = min(rows, E - a)
         n_pad = _round_up(n, 64)
         d32, s32 = dst32[a:a + n], src32[a:a + n]
-        s1x, s1m, a2x, a2m, g1x, g1m = ws.s1x[:n], ws.s1m[:n], ws.a2x[:n], ws.a2m[:n], ws.g1x[:n], ws.g1m[:n]
+        if kept is not None:   # chunk views of the layer-long buffers (their rows beyond E are zero)
+            S1X, S1M, A2X, A2M = (t[a:a + n_pad] for t in kept[:4])
+        else:
+            S1X, S1M, A2X, A2M = ws.s1x, ws.s1m, ws.a2x, ws.a2m
+        s1x, s1m, a2x, a2m, g1x, g1m = S1X[:n], S1M[:n], A2X[:n], A2M[:n], ws.g1x[:n], ws.g1m[:n]
         inp, g_in, d2, g_diff = ws.inp[:n], ws.g_in[:n], ws.d2[:n], ws.g_diff[:n]
         if n_pad > n:   # rows the split wgrad products read beyond the chunk
-            for t in (ws.s1x, ws.s1m, ws.a2x, ws.a2m, ws.g1x, ws.g1m, ws.inp):
+            for t in ((ws.g1x, ws.g1m, ws.inp) if kept is not None else (ws.s1x, ws.s1m, ws.a2x, ws.a2m, ws.g1x, ws.g1m, ws.inp)):
                 t[n:n_pad].zero_()
         _lib.check(L.egcl_backward_gather_in(st, prec, n, H, K1P, P(d32), P(s32), P(h), P(x), P(inp), P(d2)))
-        if fused is not None:
+        if kept is not None:
+            # dL/da2 in place over the kept pre-activations, g_diff and the bias / w3 / wa column sums: one element-wise pass
+            _lib.check(L.egcl_backward_heads_saved(fused[0], st, fused[1], P(x), P(g_ax), P(g_am), a, n, P(a2x), P(a2m),
+                                                   P(kept[4]), P(g_diff), P(g_b2x), P(g_w3), P(g_b3), P(g_b2m), P(g_wa),
+                                                   P(g_ba)))
+        elif fused is not None:
             # s1 (scaled by -log2 e), dL/da2, g_diff and the bias / w3 / wa column sums in one pass of the MFMA edge kernels
             _lib.check(L.egcl_backward_edge_recompute(fused[0], st, fused[1], P(x), P(g_ax), P(g_am), a, n, P(s1x), P(s1m),
                                                       P(a2x), P(a2m), P(g_diff), P(g_b2x), P(g_w3), P(g_b3), P(g_b2m),
@@ -134,8 +152,8 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_
                                              P(b2x), P(w3), P(b3), P(b2m), P(wa), P(ba), P(g_diff), P(g_b2x), P(g_w3),
                                              P(g_b3), P(g_b2m), P(g_wa), P(g_ba)))
         # a2x / a2m now hold dL/da2: wgrad and dgrad of the second Linear layers
-        g_w2x += _wgrad(ws.a2x, ws.s1x, n_pad, 16)
-        g_w2m += _wgrad(ws.a2m, ws.s1m, n_pad, 32)
+        g_w2x += _wgrad(A2X, S1X, n_pad, 16)
+        g_w2m += _wgrad(A2M, S1M, n_pad, 32)
         if fused is not None:
             # dgrad of the second layers with SiLU'(a1) in the epilogue, on MFMA (no [n, W] round trip in between)
             _lib.check(L.egcl_backward_dgrad(fused[0], st, fused[1], P(x), a, n, P(a2x), P(a2m), P(g1x), P(g1m)))
@@ -178,10 +196,32 @@ class _EGNNFunction(torch.autograd.Function):
         nseg = plan.B if scope == _lib.NORM_GRAPH else 1
         saved = []
         hc, xc = h.detach().float().contiguous(), x.detach().float().contiguous()
+        # Keep the edge activations instead of recomputing them in the backward (EGNN_BWD_SAVE=0 turns it off) when the
+        # bf16 fast path runs and the buffers -- E x (2 Wx + Wm + M) bf16 per layer -- take less than half of the free HBM
+        kept, E = None, plan.E
+        d0 = layers[0].dims
+        Wx, Wm, M = layers[0].mlp_x[0].out_features, layers[0].mlp_m[0].out_features, d0["M"]
+        if (E > 0 and prec == _lib.PREC_BF16 and os.environ.get("EGNN_BWD_SAVE", "1") != "0" and
+                os.environ.get("EGNN_BWD_FUSED", "1") != "0" and bool(L.egcl_backward_fused_supported(c.handle))):
+            Epad = _round_up(E, 64)
+            need = len(layers) * Epad * (2 * Wx + Wm + M) * 2
+            if need < 0.5 * torch.cuda.mem_get_info(hc.device)[0]:
+                kept = []
         for l in range(len(layers)):
             ho, xo = torch.empty_like(hc), torch.empty_like(xc)
-            _lib.check(L.egcl_forward(c.handle, _lib.stream_ptr(), l, prec, scope, _lib.ptr(hc), _lib.ptr(xc),
-                                      _lib.ptr(ho), _lib.ptr(xo)))
+            if kept is not None:
+                bf = dict(dtype=torch.bfloat16, device=hc.device)
+                bufs = [torch.empty(Epad, Wx, **bf), torch.empty(Epad, Wm, **bf), torch.empty(Epad, Wx, **bf),
+                        torch.empty(Epad, M, **bf), torch.empty(max(Wx // 512, 1), E, device=hc.device)]
+                if Epad > E:
+                    for t in bufs[:4]:
+                        t[E:].zero_()
+                _lib.check(L.egcl_forward_save(c.handle, _lib.stream_ptr(), l, scope, _lib.ptr(hc), _lib.ptr(xc), _lib.ptr(ho),
+                                               _lib.ptr(xo), *[_lib.ptr(t) for t in bufs]))
+                kept.append(bufs)
+            else:
+                _lib.check(L.egcl_forward(c.handle, _lib.stream_ptr(), l, prec, scope, _lib.ptr(hc), _lib.ptr(xc),
+                                          _lib.ptr(ho), _lib.ptr(xo)))
             sum_m = torch.empty(hc.shape[0], layers[l].dims["M"], device=hc.device)
             sum_x = torch.empty(hc.shape[0], 3, device=hc.device)
             S = torch.empty(nseg, device=hc.device)
@@ -189,7 +229,7 @@ class _EGNNFunction(torch.autograd.Function):
                                               _lib.ptr(S)))
             saved += [hc, xc, sum_m, sum_x, S]
             hc, xc = ho, xo
-        ctx.layers, ctx.plan, ctx.scope, ctx.prec, ctx.egnn_ctx = layers, plan, scope, prec, c
+        ctx.layers, ctx.plan, ctx.scope, ctx.prec, ctx.egnn_ctx, ctx.kept = layers, plan, scope, prec, c, kept
         ctx.save_for_backward(*saved)
         return hc, xc
 
@@ -207,12 +247,16 @@ class _EGNNFunction(torch.autograd.Function):
         d0 = layers[0].dims
         E = dst32.numel()
         ws = None
+        # the kept activations are spent by the first backward (dL/da2 is written over them): a second backward through
+        # the same graph (retain_graph=True) falls back to the recompute path
+        kept = ctx.kept if ctx.kept is not None and all(k is not None for k in ctx.kept) else None
         if E > 0:
             ws = _Workspace(min(EDGE_CHUNK, E), d0["H"], layers[0].mlp_x[0].out_features, layers[0].mlp_m[0].out_features, d0["M"],
-                            torch.bfloat16 if prec == _lib.PREC_BF16 else torch.float32, gh.device)
+                            torch.bfloat16 if prec == _lib.PREC_BF16 else torch.float32, gh.device,
+                            saved_activations=kept is not None)
         # bf16 at the reference widths: the recompute half of the edge backward runs on the forward's MFMA edge kernels
         c = ctx.egnn_ctx
-        use_fused = (E > 0 and prec == _lib.PREC_BF16 and os.environ.get("EGNN_BWD_FUSED", "1") != "0")
+        use_fused = kept is not None or (E > 0 and prec == _lib.PREC_BF16 and os.environ.get("EGNN_BWD_FUSED", "1") != "0")
         if use_fused:
             c.set_graph(plan)
             c.pack(layers)
@@ -240,7 +284,10 @@ class _EGNNFunction(torch.autograd.Function):
             # edge part
             if E > 0:
                 _edge_backward(layer, prec, ws, h_l, x_l, dst32, src32, node_seg, g_am, g_ax, g_S.contiguous(), g_h, g_x, grads,
-                               fused=(c.handle, l) if use_fused else None)
+                               fused=(c.handle, l) if use_fused else None,
+                               kept=kept[l] if kept is not None else None)
+                if kept is not None:
+                    ctx.kept[l] = None   # this layer's buffers are spent
             gh, gx = g_h, g_x
             red = ACTIVE_REDUCER
             if red is not None and id(layer) in red.bucket_of:

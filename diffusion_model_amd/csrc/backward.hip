@@ -327,12 +327,13 @@ __global__ __launch_bounds__(kThreads) void bwd_scatter_kernel(int n_edges, int 
 }
 
 // g_diff[e] = dL/d(sum_x[i]) * s_e with s_e = sum of the column-split shares the coordinate recompute kernels wrote
-__global__ void bwd_gdiff_kernel(int n_edges, int nsplit, const int* __restrict__ dst, const float* __restrict__ g_sum_x,
-                                 const float* __restrict__ s_halves, float* __restrict__ g_diff) {
+__global__ void bwd_gdiff_kernel(int n_edges, int nsplit, size_t share_stride, const int* __restrict__ dst,
+                                 const float* __restrict__ g_sum_x, const float* __restrict__ s_halves,
+                                 float* __restrict__ g_diff) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_edges) return;
   float sv = 0.f;
-  for (int hs = 0; hs < nsplit; ++hs) sv += s_halves[(size_t)hs * n_edges + e];
+  for (int hs = 0; hs < nsplit; ++hs) sv += s_halves[(size_t)hs * share_stride + e];
   const int i = dst[e];
   g_diff[3 * (size_t)e] = g_sum_x[3 * i] * sv;
   g_diff[3 * (size_t)e + 1] = g_sum_x[3 * i + 1] * sv;
@@ -431,8 +432,28 @@ int egcl_backward_edge_recompute(egnn_ctx* c, void* stream, int layer, const flo
   int rc = backward_recompute(c, st, layer, x, g_sum_x, g_sum_m, e_first, n_edges, s1x, s1m, g_a2x, g_a2m, c->bwd_s, g_b2x,
                               g_w3, g_b3, g_b2m, g_wa, g_ba);
   if (rc) return rc;
-  hipLaunchKernelGGL(bwd_gdiff_kernel, dim3((n_edges + 255) / 256), dim3(256), 0, st, n_edges, nsplit, c->edge_dst + e_first,
-                     g_sum_x, c->bwd_s, g_diff);
+  hipLaunchKernelGGL(bwd_gdiff_kernel, dim3((n_edges + 255) / 256), dim3(256), 0, st, n_edges, nsplit, (size_t)n_edges,
+                     c->edge_dst + e_first, g_sum_x, c->bwd_s, g_diff);
+  EGNN_HIP(hipGetLastError());
+  return EGNN_OK;
+}
+
+int egcl_backward_heads_saved(egnn_ctx* c, void* stream, int layer, const float* x, const float* g_sum_x, const float* g_sum_m,
+                              int e_first, int n_edges, void* t2x, void* t2m, const float* s_shares, float* g_diff,
+                              float* g_b2x, float* g_w3, float* g_b3, float* g_b2m, float* g_wa, float* g_ba) {
+  if (!c || c->L == 0 || c->N == 0 || layer < 0 || layer >= c->L) { set_error("bad egcl_backward_heads_saved context/layer"); return EGNN_EINVAL; }
+  if (e_first < 0 || n_edges < 0 || e_first + n_edges > c->E) { set_error("edge range [%d, %d) outside the graph", e_first, e_first + n_edges); return EGNN_EINVAL; }
+  if (n_edges == 0) return EGNN_OK;
+  if (!x || !g_sum_x || !g_sum_m || !t2x || !t2m || !s_shares || !g_diff || !g_b2x || !g_w3 || !g_b3 || !g_b2m || !g_wa ||
+      !g_ba) { set_error("bad egcl_backward_heads_saved arguments"); return EGNN_EINVAL; }
+  if (!backward_recompute_supported(c)) { set_error("the saved-activation backward is not available for these widths"); return EGNN_EINVAL; }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int rc = backward_heads_saved(c, st, layer, x, g_sum_x, g_sum_m, e_first, n_edges, t2x, t2m, g_b2x, g_w3, g_b3, g_b2m, g_wa, g_ba);
+  if (rc) return rc;
+  const int nsplit = c->WxP >= 512 ? c->WxP / 512 : 1;
+  // s_shares: [nsplit][E] shares of s_e of the WHOLE layer as egcl_forward_save left them
+  hipLaunchKernelGGL(bwd_gdiff_kernel, dim3((n_edges + 255) / 256), dim3(256), 0, st, n_edges, nsplit, (size_t)c->E,
+                     c->edge_dst + e_first, g_sum_x, s_shares + e_first, g_diff);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }

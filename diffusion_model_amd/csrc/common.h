@@ -106,6 +106,9 @@ struct egnn_ctx {
   float* h_partial = nullptr;  // [8][N][H] partial node-MLP outputs (hidden-split node_post at small N)
   float* bwd_s = nullptr;    // [nsplit][chunk edges] column-split shares of s_e (backward recompute)
   size_t cap_bwd_s = 0;
+  // egcl_forward_save: where the running layer's edge kernels leave what the backward needs (null = plain forward)
+  void *save_s1x = nullptr, *save_s1m = nullptr, *save_t2x = nullptr, *save_t2m = nullptr;
+  float* save_s = nullptr;   // [nsplit][E] column-split shares of s_e
   unsigned long long* stamps = nullptr;  // [2 kernels][8 waves][32 chunks][4] diagnostic time stamps
   float* h_tmp[2] = {nullptr, nullptr};  // [N][H] ping-pong between layers
   float* x_tmp[2] = {nullptr, nullptr};  // [N][3]
@@ -132,6 +135,13 @@ int backward_recompute(egnn_ctx* c, hipStream_t st, int layer, const float* x, c
                        float* g_b2x, float* g_w3, float* g_b3, float* g_b2m, float* g_wa, float* g_ba);
 int backward_dgrad(egnn_ctx* c, hipStream_t st, int layer, const float* x, int e_first, int n_edges, const void* g_a2x,
                    const void* g_a2m, void* g_a1x, void* g_a1m);
+int backward_heads_saved(egnn_ctx* c, hipStream_t st, int layer, const float* x, const float* g_sum_x, const float* g_sum_m,
+                         int e_first, int n_edges, void* t2x, void* t2m, float* g_b2x, float* g_w3, float* g_b3, float* g_b2m,
+                         float* g_wa, float* g_ba);
+bool heads_saved_supported(int WxP, int MP);
+int launch_heads_saved(int n_edges, const int* dst, const int* src, const float* x, const float* g_sum_x, const float* g_sum_m,
+                       int WxP, int MP, const float* w3s, const float* was, const float* scal, void* t2x, void* t2m,
+                       float* g_b2x, float* g_w3, float* g_b3, float* g_b2m, float* g_wa, float* g_ba, hipStream_t st);
 int init_edge_dgrad_attributes();
 int fork_streams(egnn_ctx* c);
 int launch_edge_dgrad(int N, int E, const int* dst, const int* src, const float* x, const void* table, int TC, int offP, int offQ,

@@ -54,7 +54,10 @@ __host__ __device__ inline size_t v3_smem_bytes(int KP, int MP, bool is_m) {
 // BWD = true: the training backward's recompute pass over a chunk of edges (egcl_backward_edge_recompute).  Same
 // prologue and K loop; the activation chunks are also written to HBM (s1_out: the wgrad of mlp_x.2 needs them as a GEMM
 // operand over ALL edges), and the epilogue turns the accumulators into dL/d(a2) instead of segment sums.
-template <int CB, bool IS_M, bool BWD = false>
+// SAVE = true: the training FORWARD (egcl_forward_save): the forward kernel as it is, which also leaves the activation
+// chunks (s1_out) and the scaled second-layer pre-activations -log2(e) * (a2 + b2) (g_a2_out) in HBM, so that the backward
+// needs no recompute pass (egcl_backward_heads_saved turns the pre-activations into dL/da2 in place).
+template <int CB, bool IS_M, bool BWD = false, bool SAVE = false>
 __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* s_dst = reinterpret_cast<int*>(smem + kOffDst);
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
     const bf16x8 o0 = unith_finish(u, s_wd + kg * 8, d2r0, slot0);
     unith_load(u, rs_tab, vdst1, vsrc1, offP, offQ);
     const bf16x8 o1 = unith_finish(u, s_wd + kg * 8, d2r1, slot1);
-    if constexpr (BWD) s1_store(o0, o1, 0);
+    if constexpr (BWD || SAVE) s1_store(o0, o1, 0);
   }
   bf16x8 bq[4][CB];   // weight fragments of the 4 k-steps of the current chunk
 #pragma unroll
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
     const bf16x8 o1 = unith_finish(x1, s_wd + c * kKC3 + kg * 8, d2r1, slot1 + nbuf);
     STAMP2(c - 1, 2, wave >= 4);
     __builtin_amdgcn_s_setprio(0);
-    if constexpr (BWD) s1_store(o0, o1, c);
+    if constexpr (BWD || SAVE) s1_store(o0, o1, c);
   };
   STAMP(30, 2);   // chunk 0 built, first weights requested
   RSTAMP(31, 1);
@@ -460,6 +463,26 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
     float part[64];
 #pragma unroll
     for (int q = 0; q < 64; ++q) part[q] = 0.f;
+    if constexpr (SAVE) {   // the scaled pre-activations go to HBM first (the K-loop buffers are free: every wave passed
+                            // the barrier behind the last matrix phase), the accumulators then hold them for the SiLU
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        const float bb = p.b2x[32 * (colblk0 + cb) + r];
+#pragma unroll
+        for (int rb = 0; rb < kRB3; ++rb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[rb][cb][i] = fmaf(acc[rb][cb][i], kNegLog2e, bb);
+      }
+      __bf16* stg = reinterpret_cast<__bf16*>(s_a1) + (size_t)wave * 32 * 72;
+      __bf16* tout = static_cast<__bf16*>(p.g_a2_out) + (size_t)e0 * p.WxP + 32 * colblk0;
+#pragma unroll
+      for (int rb = 0; rb < kRB3; ++rb) {
+        f32x16 blk[2];
+        blk[0] = acc[rb][0];
+        blk[1] = acc[rb][CB - 1];
+        store_block_bf16(blk, CB, stg, tout + (size_t)(32 * rb) * p.WxP, (size_t)p.WxP, nvalid - 32 * rb, lane);
+      }
+    }
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) {
       const int n = 32 * (colblk0 + cb) + r;
@@ -467,7 +490,8 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
 #pragma unroll
       for (int rb = 0; rb < kRB3; ++rb)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) part[rb * 16 + i] = fmaf(w, silu_s(fmaf(acc[rb][cb][i], kNegLog2e, bb)), part[rb * 16 + i]);
+        for (int i = 0; i < 16; ++i)
+          part[rb * 16 + i] = fmaf(w, silu_s(SAVE ? acc[rb][cb][i] : fmaf(acc[rb][cb][i], kNegLog2e, bb)), part[rb * 16 + i]);
     }
     {
       float lo[32], hi[32];
@@ -483,6 +507,7 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
 #pragma unroll
       for (int w = 0; w < 8; ++w) v += s_part[w * kR3 + tid];
       s_val[tid] = v;
+      if constexpr (SAVE) { if (tid < nvalid) p.s_half_out[(size_t)half * p.E + e0 + tid] = v; }   // share of s_e (backward: g_diff)
     }
     __syncthreads();
     float* aggx = p.agg_x + (size_t)half * p.agg_x_stride;
@@ -605,9 +630,9 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
   STAMP(31, 0);   // epilogue done
 }
 
-template <int CB, bool IS_M, bool BWD = false>
+template <int CB, bool IS_M, bool BWD = false, bool SAVE = false>
 int launch_v3(const EdgeParams& p, int blocks, size_t smem, hipStream_t st) {
-  hipLaunchKernelGGL((edge_kernel_bf16_v3<CB, IS_M, BWD>), dim3(blocks), dim3(kT3), smem, st, p);
+  hipLaunchKernelGGL((edge_kernel_bf16_v3<CB, IS_M, BWD, SAVE>), dim3(blocks), dim3(kT3), smem, st, p);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }
@@ -624,6 +649,10 @@ int init_edge_bf16_v3_attributes() {
   EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v3<2, false, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v3<1, false, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v3<2, false, false, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v3<1, false, false, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   return EGNN_OK;
 }
@@ -650,6 +679,13 @@ int launch_edge_bf16_v3_x_bwd(const EdgeParams& p, hipStream_t st) {
   static_assert(8 * 32 * 72 * 2 <= 2 * kA1_3 + 1024 * 4, "store staging must fit the K-loop buffers");
   if (p.WxP >= 512) return launch_v3<2, false, true>(p, tiles * (p.WxP / 512), v3_smem_bytes(p.WxP, p.MP, false), st);
   return launch_v3<1, false, true>(p, tiles, v3_smem_bytes(p.WxP, p.MP, false), st);
+}
+
+// training forward of the coordinate branch: p.s1_out / p.g_a2_out receive the activations and the scaled pre-activations
+int launch_edge_bf16_v3_x_save(const EdgeParams& p, hipStream_t st) {
+  const int tiles = (p.E + kR3 - 1) / kR3;
+  if (p.WxP >= 512) return launch_v3<2, false, false, true>(p, tiles * (p.WxP / 512), v3_smem_bytes(p.WxP, p.MP, false), st);
+  return launch_v3<1, false, false, true>(p, tiles, v3_smem_bytes(p.WxP, p.MP, false), st);
 }
 
 int launch_edge_bf16_v3(const EdgeParams& p, hipStream_t st) {

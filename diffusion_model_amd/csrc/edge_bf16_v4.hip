@@ -68,7 +68,9 @@ __host__ __device__ inline size_t v4_smem_bytes(int KP, int MP, bool is_m) {
 #endif
 // BWD = true (message kernel): the training backward's recompute pass over a chunk of edges: the activation chunks are
 // also written to HBM (s1_out) and the epilogue produces dL/d(a2m) through the gate instead of the segment sums.
-template <int CB, bool IS_M, bool BWD = false>
+// SAVE = true (message kernel): the training forward: also leaves the activation chunks (s1_out) and the scaled
+// second-layer pre-activations (g_a2_out) in HBM (see edge_bf16_v3.hip).
+template <int CB, bool IS_M, bool BWD = false, bool SAVE = false>
 __global__ __launch_bounds__(kT3, ((CB == 1 && !BWD) ? EGNN_V4_M_WAVES : 2)) void edge_kernel_bf16_v4(const EdgeParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* s_dst = reinterpret_cast<int*>(smem + kOffDst);
@@ -224,13 +226,13 @@ __global__ __launch_bounds__(kT3, ((CB == 1 && !BWD) ? EGNN_V4_M_WAVES : 2)) voi
   {
     const bf16x8 o0 = unith_finish(u0, s_wd + kg * 8, d2r0, slot0);
     const bf16x8 o1 = unith_finish(u1, s_wd + kg * 8, d2r1, slot1);
-    if constexpr (BWD) { s1_store(o0, brow, 0); s1_store(o1, brow + 64, 0); }
+    if constexpr (BWD || SAVE) { s1_store(o0, brow, 0); s1_store(o1, brow + 64, 0); }
   }
   uload(u0, vdst0, vsrc0, 1); uload(u1, vdst1, vsrc1, 1);
   {
     const bf16x8 o0 = unith_finish(u0, s_wd + kKC3 + kg * 8, d2r0, slot0 + kA1_3);
     const bf16x8 o1 = unith_finish(u1, s_wd + kKC3 + kg * 8, d2r1, slot1 + kA1_3);
-    if constexpr (BWD) { s1_store(o0, brow, 1); s1_store(o1, brow + 64, 1); }
+    if constexpr (BWD || SAVE) { s1_store(o0, brow, 1); s1_store(o1, brow + 64, 1); }
   }
   uload(u0, vdst0, vsrc0, 2); uload(u1, vdst1, vsrc1, 2);
   // weight fragments, requested BQD k-steps ahead of their use (a whole chunk for the coordinate kernel; the message
@@ -287,9 +289,9 @@ __global__ __launch_bounds__(kT3, ((CB == 1 && !BWD) ? EGNN_V4_M_WAVES : 2)) voi
       if ((Q) == 7) {                                                                                         \
         _Pragma("unroll") for (int k = 0; k < 4; ++k) o[e0_ + k] = (__bf16)pu[k];                             \
         if ((S) == 1) { *reinterpret_cast<bf16x8*>(slot0 + off_wr) = o; uload(u0, vdst0, vsrc0, c + 3);       \
-                        if constexpr (BWD) s1_store(o, brow, c + 2); }                                        \
+                        if constexpr (BWD || SAVE) s1_store(o, brow, c + 2); }                                        \
         if ((S) == 3) { *reinterpret_cast<bf16x8*>(slot1 + off_wr) = o; uload(u1, vdst1, vsrc1, c + 3);       \
-                        if constexpr (BWD) s1_store(o, brow + 64, c + 2); }                                   \
+                        if constexpr (BWD || SAVE) s1_store(o, brow + 64, c + 2); }                                   \
       }                                                                                                       \
     }
 #define GROUP(S, RB)                                                                                          \
@@ -506,6 +508,22 @@ __global__ __launch_bounds__(kT3, ((CB == 1 && !BWD) ? EGNN_V4_M_WAVES : 2)) voi
     static_assert(!IS_M || CB == 1, "message epilogue assumes one 32-column block per wave");
     float mval[64];
     const int ncol = 32 * wave + r;
+    if constexpr (SAVE) {   // scaled pre-activations to HBM first (the ring is free behind the last chunk's barrier)
+      const float bb = p.b2m[ncol];
+#pragma unroll
+      for (int rb = 0; rb < kRB3; ++rb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[rb][0][i] = fmaf(acc[rb][0][i], kNegLog2e, bb);
+      __bf16* stg = reinterpret_cast<__bf16*>(s_a1) + (size_t)wave * 32 * 72;
+      __bf16* tout = static_cast<__bf16*>(p.g_a2_out) + (size_t)e0 * p.MP + 32 * wave;
+#pragma unroll
+      for (int rb = 0; rb < kRB3; ++rb) {
+        f32x16 blk[2];
+        blk[0] = acc[rb][0];
+        blk[1] = acc[rb][0];
+        store_block_bf16(blk, 1, stg, tout + (size_t)(32 * rb) * p.MP, (size_t)p.MP, nvalid - 32 * rb, lane);
+      }
+    }
     {
       const float bb = p.b2m[ncol], wa = p.wa[ncol];
       float lo[32], hi[32];
@@ -513,7 +531,7 @@ __global__ __launch_bounds__(kT3, ((CB == 1 && !BWD) ? EGNN_V4_M_WAVES : 2)) voi
       for (int rb = 0; rb < kRB3; ++rb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const float m = silu_s(fmaf(acc[rb][0][i], kNegLog2e, bb));   // = -log2(e) * m
+          const float m = silu_s(SAVE ? acc[rb][0][i] : fmaf(acc[rb][0][i], kNegLog2e, bb));   // = -log2(e) * m
           mval[rb * 16 + i] = m;
           if (rb < 2) lo[rb * 16 + i] = wa * m; else hi[(rb - 2) * 16 + i] = wa * m;
         }
@@ -559,9 +577,9 @@ __global__ __launch_bounds__(kT3, ((CB == 1 && !BWD) ? EGNN_V4_M_WAVES : 2)) voi
   STAMP(31, 0);   // epilogue done
 }
 
-template <int CB, bool IS_M, bool BWD = false>
+template <int CB, bool IS_M, bool BWD = false, bool SAVE = false>
 int launch_v4(const EdgeParams& p, int blocks, size_t smem, hipStream_t st) {
-  hipLaunchKernelGGL((edge_kernel_bf16_v4<CB, IS_M, BWD>), dim3(blocks), dim3(kT3), smem, st, p);
+  hipLaunchKernelGGL((edge_kernel_bf16_v4<CB, IS_M, BWD, SAVE>), dim3(blocks), dim3(kT3), smem, st, p);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }
@@ -576,6 +594,8 @@ int init_edge_bf16_v4_attributes() {
   EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v4<1, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v4<1, true, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v4<1, true, false, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   return EGNN_OK;
 }
@@ -599,6 +619,12 @@ int launch_edge_bf16_v4_m_bwd(const EdgeParams& p, hipStream_t st) {
 int launch_edge_bf16_v4_x1(const EdgeParams& p, hipStream_t st) {
   const int tiles = (p.E + kR3 - 1) / kR3;
   return launch_v4<1, false>(p, tiles * (p.WxP / 256), v4_smem_bytes(p.WxP, p.MP, false), st);
+}
+
+// training forward of the message branch: p.s1_out / p.g_a2_out receive the activations and the scaled pre-activations
+int launch_edge_bf16_v4_m_save(const EdgeParams& p, hipStream_t st) {
+  const int tiles = (p.E + kR3 - 1) / kR3;
+  return launch_v4<1, true, false, true>(p, tiles, v4_smem_bytes(p.WmP, p.MP, true), st);
 }
 
 // message kernel only

@@ -1063,6 +1063,18 @@ int backward_recompute(egnn_ctx* c, hipStream_t st, int layer, const float* x, c
   return launch_edge_bf16_v4_m_bwd(p, st);
 }
 
+// dL/da2 of both edge MLPs from the pre-activations egcl_forward_save left (in place), see edge_bwd_heads.hip
+int backward_heads_saved(egnn_ctx* c, hipStream_t st, int layer, const float* x, const float* g_sum_x, const float* g_sum_m,
+                         int e_first, int n_edges, void* t2x, void* t2m, float* g_b2x, float* g_w3, float* g_b3, float* g_b2m,
+                         float* g_wa, float* g_ba) {
+  EdgeParams p;
+  fill_edge_params(c, layer, EGNN_PREC_BF16, x, p);
+  const float *w1catT, *b1cat;
+  use_scaled_pack(c, layer, p, w1catT, b1cat);
+  return launch_heads_saved(n_edges, c->edge_dst + e_first, c->edge_src + e_first, x, g_sum_x, g_sum_m, c->WxP, c->MP, p.w3x, p.wa,
+                            p.scal, t2x, t2m, g_b2x, g_w3, g_b3, g_b2m, g_wa, g_ba, st);
+}
+
 int backward_dgrad(egnn_ctx* c, hipStream_t st, int layer, const float* x, int e_first, int n_edges, const void* g_a2x,
                    const void* g_a2m, void* g_a1x, void* g_a1m) {
   const LayerPack& lp = c->layers[layer];
@@ -1093,6 +1105,7 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
   if (prec == EGNN_PREC_BF16 && edge_sel >= 4 && edge_bf16_v4_supported(p) && edge_bf16_v3_supported(p)) path = 4;
   else if (prec == EGNN_PREC_BF16 && edge_sel >= 3 && edge_bf16_v3_supported(p)) path = 3;
   else if (prec == EGNN_PREC_BF16 && edge_sel >= 2 && edge_bf16_v2_supported(p)) path = 2;
+  if (c->save_s1x && path != 4) { set_error("egcl_forward_save needs the 128-row bf16 edge kernels (EGNN_EDGE=4)"); return EGNN_EINVAL; }
   const float* w1catT = lp.w1catT;
   const float* b1cat = lp.b1cat;
   if (path >= 2) use_scaled_pack(c, layer, p, w1catT, b1cat);
@@ -1142,7 +1155,12 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
       const bool fork = fork_sel && !v4x && !c->prof && st != nullptr && c->side != nullptr &&
                         (size_t)E * 3 <= (size_t)256 * 128;   // all workgroups of both kernels resident at once
       static const int x4 = getenv("EGNN_X4") ? atoi(getenv("EGNN_X4")) : 0;   // A/B: 256-column coordinate workgroups
-      if (x4 && p.WxP >= 512) {
+      if (c->save_s1x) {   // training forward (egcl_forward_save): the same kernels, which also store what the backward needs
+        p.s1_out = c->save_s1x; p.g_a2_out = c->save_t2x; p.s_half_out = c->save_s;
+        rc = launch_edge_bf16_v3_x_save(p, st);
+        p.s1_out = c->save_s1m; p.g_a2_out = c->save_t2m; p.s_half_out = nullptr;
+        if (!rc) rc = launch_edge_bf16_v4_m_save(p, st);
+      } else if (x4 && p.WxP >= 512) {
         nsplit_x = p.WxP / 256;
         rc = launch_edge_bf16_v4_x1(p, st);
         if (!rc) rc = launch_edge_bf16_v4_m(p, st);
@@ -1452,6 +1470,22 @@ int egcl_forward(egnn_ctx* c, void* stream, int layer, int prec, int norm_scope,
   }
   // the single-layer entry keeps the per-graph sums of d^2 available for egcl_read_aggregates
   return launch_layer(c, reinterpret_cast<hipStream_t>(stream), layer, prec, norm_scope, h, x, h_out, x_out, true);
+}
+
+int egcl_forward_save(egnn_ctx* c, void* stream, int layer, int norm_scope, const float* h, const float* x, float* h_out,
+                      float* x_out, void* s1x, void* s1m, void* t2x, void* t2m, float* s_shares) {
+  int rc = check_ready(c, EGNN_PREC_BF16, norm_scope);
+  if (rc) return rc;
+  if (layer < 0 || layer >= c->L || !h || !x || !h_out || !x_out || h == h_out || x == x_out || !s1x || !s1m || !t2x || !t2m ||
+      !s_shares) {
+    set_error("bad egcl_forward_save arguments");
+    return EGNN_EINVAL;
+  }
+  if (c->E == 0 || !backward_recompute_supported(c)) { set_error("egcl_forward_save is not available for these widths"); return EGNN_EINVAL; }
+  c->save_s1x = s1x; c->save_s1m = s1m; c->save_t2x = t2x; c->save_t2m = t2m; c->save_s = s_shares;
+  rc = launch_layer(c, reinterpret_cast<hipStream_t>(stream), layer, EGNN_PREC_BF16, norm_scope, h, x, h_out, x_out, true);
+  c->save_s1x = c->save_s1m = c->save_t2x = c->save_t2m = nullptr; c->save_s = nullptr;
+  return rc;
 }
 
 int egcl_forward_begin(egnn_ctx* c, void* stream, int layer, int prec, int norm_scope, const float* h, const float* x,

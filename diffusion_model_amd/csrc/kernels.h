@@ -284,6 +284,8 @@ int launch_edge_bf16_v4_x1(const EdgeParams& p, hipStream_t st);   // 256-column
 int launch_edge_bf16_v3_x(const EdgeParams& p, hipStream_t st);
 int launch_edge_bf16_v3_x_bwd(const EdgeParams& p, hipStream_t st);
 int launch_edge_bf16_v4_m_bwd(const EdgeParams& p, hipStream_t st);
+int launch_edge_bf16_v3_x_save(const EdgeParams& p, hipStream_t st);
+int launch_edge_bf16_v4_m_save(const EdgeParams& p, hipStream_t st);
 bool edge_bf16_v4_supported(const EdgeParams& p);
 int edge_v4_rows();
 int init_edge_bf16_v4_attributes();

@@ -159,6 +159,24 @@ int egcl_backward_edge_recompute(egnn_ctx* ctx, void* stream, int layer, const f
                                  void* d_g_a2x, void* d_g_a2m, float* d_g_diff, float* d_g_b2x, float* d_g_w3,
                                  float* d_g_b3, float* d_g_b2m, float* d_g_wa, float* d_g_ba);
 
+/* The same first half WITHOUT the recompute pass, for a training process that can afford E x (2 Wx + Wm + M) bf16 per
+ * layer (7 GB at 2^20 edges and the reference widths): egcl_forward_save is egcl_forward in bf16 mode whose edge kernels
+ * also leave in HBM, for ALL E edges of the layer,
+ *   s1x [E, Wx], s1m [E, Wm]  bf16 as above (scaled by -log2(e)),
+ *   t2x [E, Wx], t2m [E, M]   bf16 = -log2(e) * (second-layer pre-activation incl. bias),
+ *   s_shares [Wx / 512][E]    fp32 column-split shares of s_e = w3 . SiLU(a2) + b3 (their sum is s_e);
+ * (h_out, x_out) are bitwise those of egcl_forward, and the per-graph sums of d^2 stay readable (egcl_read_aggregates).
+ * egcl_backward_heads_saved then turns rows [e_first, e_first + n_edges) of t2x / t2m into dL/d(a2) IN PLACE (an
+ * element-wise pass at HBM speed: loss.backward() of parts/train_per_iretation.py:172 for the two heads, :57-65) and adds
+ * the column sums / writes g_diff exactly as egcl_backward_edge_recompute does.  d_t2x / d_t2m point at row e_first. */
+int egcl_forward_save(egnn_ctx* ctx, void* stream, int layer, int norm_scope, const float* d_h, const float* d_x,
+                      float* d_h_out, float* d_x_out, void* d_s1x, void* d_s1m, void* d_t2x, void* d_t2m,
+                      float* d_s_shares);
+int egcl_backward_heads_saved(egnn_ctx* ctx, void* stream, int layer, const float* d_x, const float* d_g_sum_x,
+                              const float* d_g_sum_m, int e_first, int n_edges, void* d_t2x, void* d_t2m,
+                              const float* d_s_shares, float* d_g_diff, float* d_g_b2x, float* d_g_w3, float* d_g_b3,
+                              float* d_g_b2m, float* d_g_wa, float* d_g_ba);
+
 /* Fused second half for the same path: g_a1 = (g_a2 . W2) * SiLU'(a1) for mlp_x ([n_edges, Wx] from [n_edges, Wx]) and
  * mlp_m ([n_edges, Wm] from [n_edges, M]) on MFMA, i.e. the dgrad GEMMs of mlp_x.2 / mlp_m.2 with egcl_backward_l1_grad
  * in their epilogue (the first-layer pre-activations come from the table egcl_backward_table left on ctx).  bf16 row-major

@@ -334,3 +334,40 @@ def test_bf16_training_gradients_close_to_fp32():
         grads[prec] = {k: p.grad.detach().cpu() for k, p in net.named_parameters()}
     for k in grads["fp32"]:
         assert rel_err(grads["bf16"][k], grads["fp32"][k]) <= 8e-2, k
+
+
+@pytest.mark.gpu
+def test_saved_activation_backward_matches_recompute(monkeypatch):
+    """bf16 training at the reference widths: the forward that keeps the edge activations (egcl_forward_save, default) and the
+    backward that recomputes them (EGNN_BWD_SAVE=0) see the same loss bitwise and gradients that differ only by the bf16
+    rounding of the kept pre-activations (3e-2); ragged sizes so that E is not a multiple of the 64-row padding and a layer
+    spans several backward chunks.  A second backward through a retained graph falls back to the recompute path."""
+    from diffusion_model_amd import autograd as _ag
+    H, A, T = 36, 2, 50
+    d = dims_for(H, 256, 1024, 1024, 1024)
+    sizes = (64, 63, 62)
+    pos0, x0, cond, batch, ei, npos, nh, times = _problem(seed=4, sizes=sizes)
+    assert ei.shape[1] % 64 != 0
+    dev = "cuda"
+    proc = dma.E3DiffusionProcess(1e-5, 2.0, T)
+    monkeypatch.setattr(_ag, "EDGE_CHUNK", 5000)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("EGNN_BWD_SAVE", mode)
+        torch.manual_seed(8)
+        m = dma.EquivariantGNN(2, **d).to(dev).train()
+        m.precision, m.norm_scope = "bf16", "graph"
+        noised = dma.diffuse_as_batch(pos0.to(dev) * 2.0, x0.to(dev), batch.to(dev), proc, times=times, noise_pos=npos.to(dev),
+                                      noise_h=nh.to(dev), num_graphs=3)
+        loss, _, _ = dma.training_loss(m, ei.to(dev), batch.to(dev), noised, cond.to(dev), A, num_graphs=3)
+        loss.backward(retain_graph=(mode == "1"))
+        g1 = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+        out[mode] = (float(loss.detach()), g1)
+        if mode == "1":   # the kept buffers are spent: the second pass recomputes, and accumulates the same gradients again
+            loss.backward()
+            for k, p in m.named_parameters():
+                assert rel_err((p.grad - g1[k]).cpu(), g1[k].cpu()) <= 3e-2, k
+    assert out["1"][0] == out["0"][0]
+    for k in out["1"][1]:
+        assert torch.isfinite(out["1"][1][k]).all()
+        assert rel_err(out["1"][1][k].cpu(), out["0"][1][k].cpu()) <= 3e-2, k
