@@ -33,7 +33,7 @@ import torch
 
 from . import _lib
 
-EDGE_CHUNK = int(os.environ.get("EGNN_BWD_CHUNK", 1 << 19))   # edges per backward chunk (workspace = 6 bf16 [chunk, W] buffers)
+EDGE_CHUNK = int(os.environ.get("EGNN_BWD_CHUNK", 1 << 20))   # edges per backward chunk (workspace = up to 6 bf16 [chunk, W] buffers)
 
 # training.GradAllReducer.arm() puts itself here: the backward below hands it every layer's parameter gradients as soon
 # as they are final, so the bucket's all-reduce runs under the backward of the earlier layers
