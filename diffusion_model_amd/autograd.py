@@ -202,7 +202,8 @@ class _EGNNFunction(torch.autograd.Function):
         d0 = layers[0].dims
         Wx, Wm, M = layers[0].mlp_x[0].out_features, layers[0].mlp_m[0].out_features, d0["M"]
         if (E > 0 and prec == _lib.PREC_BF16 and os.environ.get("EGNN_BWD_SAVE", "1") != "0" and
-                os.environ.get("EGNN_BWD_FUSED", "1") != "0" and bool(L.egcl_backward_fused_supported(c.handle))):
+                os.environ.get("EGNN_BWD_FUSED", "1") != "0" and int(os.environ.get("EGNN_EDGE", "4")) >= 4 and
+                bool(L.egcl_backward_fused_supported(c.handle))):
             Epad = _round_up(E, 64)
             need = len(layers) * Epad * (2 * Wx + Wm + M) * 2
             if need < 0.5 * torch.cuda.mem_get_info(hc.device)[0]:

@@ -95,33 +95,35 @@ __global__ __launch_bounds__(kHT) void heads_x_kernel(int n_edges, const int* __
   }
 }
 
-// ---- message head: one wave per row, MC = M / 64 columns per lane (lane l owns columns l, l + 64, ...) ---------------
-template <int MC>
-__global__ __launch_bounds__(kHT) void heads_m_kernel(int n_edges, int M, const int* __restrict__ dst,
-                                                      const float* __restrict__ g_sum_m,   // [N][M]
+// ---- message head: one wave per row, 4 consecutive columns per lane (M = 256) ------------------------------------------
+__global__ __launch_bounds__(kHT) void heads_m_kernel(int n_edges, const int* __restrict__ dst,
+                                                      const float* __restrict__ g_sum_m,   // [N][256]
                                                       const float* __restrict__ was,        // wa * (-1 / log2 e)
                                                       const float* __restrict__ scal,       // scal[1] = ba
-                                                      __bf16* __restrict__ t2,              // [n_edges][M] in / out
+                                                      __bf16* __restrict__ t2,              // [n_edges][256] in / out
                                                       float* __restrict__ g_b2, float* __restrict__ g_wa,
                                                       float* __restrict__ g_ba) {
+  constexpr int M = 256;
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int e_base = blockIdx.x * kHRows;
   const int rows = min(kHRows, n_edges - e_base);
-  float wan[MC], cs_b[MC], cs_w[MC];
+  const int c0 = 4 * lane;
+  float wan[4], cs_b[4], cs_w[4];
 #pragma unroll
-  for (int k = 0; k < MC; ++k) { wan[k] = was[lane + 64 * k] * kNegLog2e; cs_b[k] = 0.f; cs_w[k] = 0.f; }
+  for (int k = 0; k < 4; ++k) { wan[k] = was[c0 + k] * kNegLog2e; cs_b[k] = 0.f; cs_w[k] = 0.f; }
   const float ba = scal[1];
   float gba = 0.f;
   for (int rr = wave; rr < rows; rr += kHT / 64) {
     const int e = e_base + rr;
-    __bf16* row = t2 + (size_t)e * M;
-    const float* gm = g_sum_m + (size_t)dst[e] * M;
-    float m[MC], ds[MC], g[MC];
+    bf16x4_t* row = reinterpret_cast<bf16x4_t*>(t2 + (size_t)e * M + c0);
+    const bf16x4_t tv = *row;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(g_sum_m + (size_t)dst[e] * M + c0);
+    float m[4], ds[4];
     float z = 0.f, d = 0.f;
 #pragma unroll
-    for (int k = 0; k < MC; ++k) {
-      silu_grad_s((float)row[lane + 64 * k], m[k], ds[k]);
-      g[k] = gm[lane + 64 * k];
+    for (int k = 0; k < 4; ++k) {
+      silu_grad_s((float)tv[k], m[k], ds[k]);
       z = fmaf(wan[k], m[k], z);
       d = fmaf(g[k], m[k], d);
     }
@@ -130,21 +132,23 @@ __global__ __launch_bounds__(kHT) void heads_m_kernel(int n_edges, int M, const 
     const float gate = sigmoid_f(z + ba);
     const float coef = d * gate * (1.0f - gate);
     gba += coef;
+    bf16x4_t gv;
 #pragma unroll
-    for (int k = 0; k < MC; ++k) {
+    for (int k = 0; k < 4; ++k) {
       const float ga = fmaf(g[k], gate, coef * wan[k]) * ds[k];
       cs_b[k] += ga;
       cs_w[k] = fmaf(coef, m[k], cs_w[k]);
-      row[lane + 64 * k] = (__bf16)ga;
+      gv[k] = (__bf16)ga;
     }
+    *row = gv;
   }
-  __shared__ float s_cs[2][kHT / 64][64 * MC];
+  __shared__ float s_cs[2][kHT / 64][M];
   __shared__ float s_red[kHT / 64];
 #pragma unroll
-  for (int k = 0; k < MC; ++k) { s_cs[0][wave][lane + 64 * k] = cs_b[k]; s_cs[1][wave][lane + 64 * k] = cs_w[k]; }
+  for (int k = 0; k < 4; ++k) { s_cs[0][wave][c0 + k] = cs_b[k]; s_cs[1][wave][c0 + k] = cs_w[k]; }
   if (lane == 0) s_red[wave] = gba;   // every lane of a wave holds the same coef
   __syncthreads();
-  for (int c = tid; c < 64 * MC; c += kHT) {
+  for (int c = tid; c < M; c += kHT) {
     float a = 0.f, b = 0.f;
 #pragma unroll
     for (int w = 0; w < kHT / 64; ++w) { a += s_cs[0][w][c]; b += s_cs[1][w][c]; }
@@ -172,8 +176,8 @@ int launch_heads_saved(int n_edges, const int* dst, const int* src, const float*
   else if (WxP == 512) hipLaunchKernelGGL(heads_x_kernel<512>, grid, block, 0, st, n_edges, dst, src, x, g_sum_x, w3s, tx, g_b2x, g_w3, g_b3);
   else hipLaunchKernelGGL(heads_x_kernel<256>, grid, block, 0, st, n_edges, dst, src, x, g_sum_x, w3s, tx, g_b2x, g_w3, g_b3);
   EGNN_HIP(hipGetLastError());
-  hipLaunchKernelGGL(heads_m_kernel<4>, grid, block, 0, st, n_edges, MP, dst, g_sum_m, was, scal, static_cast<__bf16*>(t2m), g_b2m,
-                     g_wa, g_ba);
+  hipLaunchKernelGGL(heads_m_kernel, grid, block, 0, st, n_edges, dst, g_sum_m, was, scal, static_cast<__bf16*>(t2m), g_b2m, g_wa,
+                     g_ba);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }
