@@ -1154,26 +1154,29 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
       static const int fork_sel = getenv("EGNN_FORK") ? atoi(getenv("EGNN_FORK")) : 1;   // A/B switch
       const bool fork = fork_sel && !v4x && !c->prof && st != nullptr && c->side != nullptr &&
                         (size_t)E * 3 <= (size_t)256 * 128;   // all workgroups of both kernels resident at once
-      static const int x4 = getenv("EGNN_X4") ? atoi(getenv("EGNN_X4")) : 0;   // A/B: 256-column coordinate workgroups
+      // A/B switch: 256-column coordinate workgroups (four per tile, two per CU, edge_bf16_v4.hip).  Slower both when the
+      // chip is full (2.37 vs 2.02 ms at C2: the mlp_x activations are built four times instead of twice) and when the
+      // layer is fewer workgroups than CUs (one 64-atom graph: 0.353 vs 0.323 ms per reverse step).
+      static const int x4_sel = getenv("EGNN_X4") ? atoi(getenv("EGNN_X4")) : 0;
+      const bool x4 = p.WxP >= 512 && !v4x && x4_sel > 0;
+      auto launch_x = [&](hipStream_t s) { return x4 ? launch_edge_bf16_v4_x1(p, s) : launch_edge_bf16_v3_x(p, s); };
+      if (x4) nsplit_x = p.WxP / 256;
       if (c->save_s1x) {   // training forward (egcl_forward_save): the same kernels, which also store what the backward needs
+        nsplit_x = p.WxP >= 512 ? p.WxP / 512 : 1;
         p.s1_out = c->save_s1x; p.g_a2_out = c->save_t2x; p.s_half_out = c->save_s;
         rc = launch_edge_bf16_v3_x_save(p, st);
         p.s1_out = c->save_s1m; p.g_a2_out = c->save_t2m; p.s_half_out = nullptr;
         if (!rc) rc = launch_edge_bf16_v4_m_save(p, st);
-      } else if (x4 && p.WxP >= 512) {
-        nsplit_x = p.WxP / 256;
-        rc = launch_edge_bf16_v4_x1(p, st);
-        if (!rc) rc = launch_edge_bf16_v4_m(p, st);
       } else if (v4x) rc = launch_edge_bf16_v4(p, st);
       else if (fork) {
         EGNN_HIP(hipEventRecord(c->ev_fork, st));
         EGNN_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-        rc = launch_edge_bf16_v3_x(p, st);
+        rc = launch_x(st);
         if (!rc) rc = launch_edge_bf16_v4_m(p, c->side);
         EGNN_HIP(hipEventRecord(c->ev_join, c->side));
         EGNN_HIP(hipStreamWaitEvent(st, c->ev_join, 0));
       } else {
-        rc = launch_edge_bf16_v3_x(p, st);
+        rc = launch_x(st);
         if (!rc) rc = launch_edge_bf16_v4_m(p, st);
       }
     } else if (path == 3) {
