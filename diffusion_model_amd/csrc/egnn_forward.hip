@@ -929,9 +929,20 @@ static void prof_end(egnn_ctx* c, hipStream_t st) {
 // outside any stream capture), never for training contexts: with two ranks sharing one GPU over gloo, the mere existence
 // of one more HIP stream in the process made every gradient all-reduce take seconds (round-2 rehearsal, blocking or
 // non-blocking flag alike) -- the workloads that fork never run a collective.
+// The coordinate and the message kernel of a layer are independent.  On one stream the message kernel starts when the LAST
+// round of coordinate workgroups has drained; when that round leaves enough CUs idle for all message workgroups (two per
+// CU), the message kernel goes to a side stream and runs in that shadow: one 64-atom graph 64 of 256 CUs busy, five graphs
+// (generate()'s default gen_num_per_spectrum) 316 coordinate workgroups = 1.23 rounds -> 0.49 -> 0.42 ms per reverse step.
+// Full rounds (16 graphs and more: measured equal eager, 2-8 % slower in graph replay) keep the single stream.
+static bool fork_candidate(int E, int WxP) {
+  const long tiles = (E + 127) / 128, xw = tiles * (WxP >= 512 ? WxP / 512 : 1);
+  const long idle = (xw + 255) / 256 * 256 - xw;
+  return E > 0 && idle >= (tiles + 1) / 2;
+}
+
 int fork_streams(egnn_ctx* c) {
   if (c->side) return EGNN_OK;
-  if ((size_t)c->E * 3 > (size_t)256 * 128) return EGNN_OK;   // not a fork candidate
+  if (!fork_candidate(c->E, c->WxP)) return EGNN_OK;
   if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { c->side = nullptr; return EGNN_EHIP; }
   if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) return EGNN_EHIP;
@@ -1148,12 +1159,10 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
       // coordinate kernels with the phase-opposed K loop of edge_bf16_v3.hip, message kernel with the in-wave pipeline
       // of edge_bf16_v4.hip: each the faster one for its shape (EGNN_V4_X=1 selects the v4 coordinate kernel, A/B)
       static const int v4x = getenv("EGNN_V4_X") ? atoi(getenv("EGNN_V4_X")) : 0;
-      // Small graphs (fewer workgroups than CUs): the coordinate and the message kernel are independent of each other --
-      // the message kernel goes to a side stream between two events (fork / join; under capture they become graph edges)
-      // so that the layer waits for the longer of the two instead of their sum.
+      // fork_candidate(): the message kernel goes to a side stream between two events (fork / join; under capture they
+      // become graph edges) and runs in the shadow of the coordinate kernel's last, partly filled round.
       static const int fork_sel = getenv("EGNN_FORK") ? atoi(getenv("EGNN_FORK")) : 1;   // A/B switch
-      const bool fork = fork_sel && !v4x && !c->prof && st != nullptr && c->side != nullptr &&
-                        (size_t)E * 3 <= (size_t)256 * 128;   // all workgroups of both kernels resident at once
+      const bool fork = fork_sel && !v4x && !c->prof && st != nullptr && c->side != nullptr && fork_candidate(E, p.WxP);
       // A/B switch: 256-column coordinate workgroups (four per tile, two per CU, edge_bf16_v4.hip).  Slower both when the
       // chip is full (2.37 vs 2.02 ms at C2: the mlp_x activations are built four times instead of twice) and when the
       // layer is fewer workgroups than CUs (one 64-atom graph: 0.353 vs 0.323 ms per reverse step).
