@@ -473,6 +473,38 @@ def test_generate_interface():
         assert torch.isfinite(g.pos).all() and bool((g.x.sum(1) == 1).all())
 
 
+def test_generate_batches_across_data():
+    """generate() draws the samples of several conditioning data (different atom counts) as one device batch; the lists
+    come back datum by datum as in the reference whatever the batch size, and with one datum per batch the result is the
+    per-datum loop of the reference (same seeds -> same samples as a call on that datum alone)."""
+    from types import SimpleNamespace
+    params = dict(num_diffusion_timestep=8, conditional=True, atom_type_size=2, spectrum_size=200,
+                  onehot_scaling_factor=1.0, to_compress_spectrum=True, give_exO=True, noise_schedule="predefined",
+                  seed=7)
+    d = dims_for(36, 128, 256, 256, 256)
+    torch.manual_seed(0)
+    nn_dict = {"egnn": _tame(dma.EquivariantGNN(2, **d)), "spectrum_compressor": dma.SpectrumCompressor(200, [150, 100, 50], 32)}
+    proc = dma.E3DiffusionProcess(0.2, 2.0, 8)
+    data = []
+    for n in (5, 9, 4, 7):
+        spec = torch.zeros(n, 200)
+        spec[0] = torch.rand(200)
+        exo = torch.zeros(n, 1)
+        exo[0] = 1
+        data.append(SimpleNamespace(x=torch.zeros(n, 2), pos=torch.zeros(n, 3), spectrum=spec, exO=exo))
+    for gpb in (256, 4, 1):
+        orig, gen = dma.generate(nn_dict, data, params, proc, gen_num_per_spectrum=2, graphs_per_batch=gpb)
+        assert [o.x.shape[0] for o in orig] == [5, 5, 9, 9, 4, 4, 7, 7]
+        for o, gl in zip(orig, gen):
+            g = gl[-1]
+            assert g.pos.shape == (o.x.shape[0], 3) and torch.isfinite(g.pos).all() and bool((g.x.sum(1) == 1).all())
+            assert g.spectrum is o.spectrum
+    # one datum per batch == that datum generated alone (the batch seed is keyed by the first datum of the batch)
+    _, gen_all = dma.generate(nn_dict, data, params, proc, gen_num_per_spectrum=2, graphs_per_batch=2)
+    _, gen_one = dma.generate(nn_dict, data[:1], params, proc, gen_num_per_spectrum=2, graphs_per_batch=2)
+    assert torch.equal(gen_all[0][-1].pos, gen_one[0][-1].pos) and torch.equal(gen_all[1][-1].pos, gen_one[1][-1].pos)
+
+
 # every bf16 edge-kernel variant: v3 <2,false> (x_hidden >= 512), v3 <1,false> (x_hidden = 256), v3 <1,true>,
 # and the generic fallbacks taken when the widths do not fit the v3 tiling (m_size != 256, odd widths)
 @pytest.mark.parametrize("H,m_size,wm,wx,wh", [
