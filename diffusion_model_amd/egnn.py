@@ -129,7 +129,8 @@ class EquivariantGNN(nn.Module):
 
     def forward(self, edge_index, h, x, batch=None):
         """EquivariantGNN.forward(edge_index, h, x) -> (h, x) (:85-88).  ``batch`` (PyG's node->graph
-        vector) is only needed for norm_scope='graph' on batched calls."""
+        vector) is only needed for norm_scope='graph' on batched calls.  ``edge_index`` may also be a ready
+        ``GraphPlan`` (e.g. ``data.Batch.plan()``: built on the device, no sort and no host sync per batch)."""
         return _run(self, list(self.egcl_list), edge_index, h, x, batch, single_layer=False)
 
     # -- helpers used by the sampler / trainer -------------------------------------------------------
@@ -152,6 +153,10 @@ def _context(owner, layers, device) -> _Context:
 
 
 def _plan_for(owner, edge_index, n, batch) -> GraphPlan:
+    if isinstance(edge_index, GraphPlan):   # a ready plan (data.Batch.plan(), fully_connected_plan, radius_plan) in place of edge_index
+        if edge_index.N != n:
+            raise ValueError(f"the graph plan has {edge_index.N} nodes, h has {n}")
+        return edge_index
     key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), n,
            None if batch is None else (batch.data_ptr(), batch._version))
     plan = owner._plans.get(key)
@@ -165,7 +170,7 @@ def _plan_for(owner, edge_index, n, batch) -> GraphPlan:
 
 
 def _run(owner, layers, edge_index, h, x, batch, single_layer):
-    if not (h.is_cuda and x.is_cuda and edge_index.is_cuda):
+    if not (h.is_cuda and x.is_cuda and (isinstance(edge_index, GraphPlan) or edge_index.is_cuda)):
         raise RuntimeError("EGNN forward needs CUDA(ROCm) tensors; there is no CPU fallback in diffusion_model_amd")
     if torch.is_grad_enabled() and (h.requires_grad or x.requires_grad or any(p.requires_grad for l in layers for p in l.parameters())):
         from .autograd import egnn_forward_autograd

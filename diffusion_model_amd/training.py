@@ -202,7 +202,9 @@ def train_step(nn_dict, data, params, diffusion_process, optimizer, reducer: Opt
     nglob = global_graph_count(nb, dev) if num_graphs_global is None else int(num_graphs_global)
     if reducer is not None:
         reducer.arm()
-    loss, _, _ = training_loss(egnn, data.edge_index, data.batch, noised, cond, params["atom_type_size"],
+    # a collated data.Batch brings its own device-built graph plan (no edge sort / host sync per step)
+    topo = data.plan() if callable(getattr(data, "plan", None)) else data.edge_index
+    loss, _, _ = training_loss(egnn, topo, data.batch, noised, cond, params["atom_type_size"],
                                num_graph_global=nglob, num_graphs=nb)
     loss.backward()
     if reducer is not None:
@@ -227,7 +229,7 @@ def _epoch(nn_dict, loader, params, diffusion_process, optimizer, train: bool, r
             loss = train_step(nn_dict, data, params, diffusion_process, optimizer, reducer)
         else:
             with torch.no_grad():
-                noised = diffuse_as_batch(data.pos, data.x, data.batch, diffusion_process)
+                noised = diffuse_as_batch(data.pos, data.x, data.batch, diffusion_process, num_graphs=nb)
                 cols = []
                 if params["conditional"]:
                     spec = data.spectrum.float()
@@ -237,7 +239,9 @@ def _epoch(nn_dict, loader, params, diffusion_process, optimizer, train: bool, r
                 if params["give_exO"]:
                     cols.append(data.exO.float())
                 cond = torch.cat(cols, dim=1) if cols else None
-                loss, _, _ = training_loss(egnn, data.edge_index, data.batch, noised, cond, params["atom_type_size"])
+                topo = data.plan() if callable(getattr(data, "plan", None)) else data.edge_index
+                loss, _, _ = training_loss(egnn, topo, data.batch, noised, cond, params["atom_type_size"],
+                                           num_graphs=nb)
         total += float(loss) * nb                     # the reference re-multiplies by num_graph (:178)
     return total / max(nodes, 1)                      # average per node (:181)
 

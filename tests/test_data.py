@@ -136,3 +136,19 @@ def test_train_epoch_over_a_loader():
     l2 = dma.eval_epoch(nn_dict, loader, params, proc, opt)
     assert l2 == l2
     assert all(torch.equal(a, b) for a, b in zip(mid, nn_dict["egnn"].parameters()))
+
+
+@pytest.mark.gpu
+def test_forward_accepts_a_plan_in_place_of_edge_index():
+    from tests._util import dims_for
+    torch.manual_seed(1)
+    b = D.collate(_records((6, 4, 7)), device="cuda")
+    net = dma.EquivariantGNN(2, **dims_for(36, 128, 256, 256, 256)).cuda().eval()
+    net.norm_scope = "graph"
+    h, x = torch.randn(b.num_nodes, 36, device="cuda"), b.pos.clone()
+    with torch.no_grad():
+        h1, x1 = net(b.edge_index, h, x, batch=b.batch)
+        h2, x2 = net(b.plan(), h, x)
+    assert torch.equal(h1, h2) and torch.equal(x1, x2)
+    with pytest.raises(ValueError):
+        net(b.plan(), h[:-1], x[:-1])
