@@ -21,11 +21,12 @@ needs torch_geometric and an unpickler to read.
 """
 from __future__ import annotations
 
+import functools
 from typing import Iterable, Iterator, List, Optional, Sequence
 
 import torch
 
-from .graph import fully_connected_edge_index
+from .graph import fully_connected_edge_index, plan_record_stream
 
 _NODE_KEYS = ("x", "pos", "spectrum", "spectrum_raw", "exO")
 
@@ -121,11 +122,22 @@ class Batch(GraphData):
         return out
 
 
+@functools.lru_cache(maxsize=64)
+def _fc_index(n: int) -> torch.Tensor:
+    return fully_connected_edge_index(n)
+
+
 def _is_fully_connected(g: GraphData, n: int) -> bool:
     ei = getattr(g, "edge_index", None)
     if ei is None or ei.shape[1] != n * (n - 1):
         return False
-    return bool(torch.equal(ei.cpu(), fully_connected_edge_index(n)))
+    tag = getattr(g, "_fc_checked", None)     # (id of the tensor, its version): records are collated once per epoch
+    key = (id(ei), ei._version)
+    if tag is not None and tag[0] == key:
+        return tag[1]
+    ok = bool(torch.equal(ei.cpu(), _fc_index(n)))
+    g._fc_checked = (key, ok)
+    return ok
 
 
 def collate(graphs: Sequence[GraphData], device=None) -> Batch:
@@ -150,23 +162,31 @@ def collate(graphs: Sequence[GraphData], device=None) -> Batch:
                 raise ValueError(f"field {k!r} is not node-level")
         out_v = torch.cat(vals, 0)
         setattr(out, k, out_v.to(device) if device is not None else out_v)
-    eis = []
-    for g, off, n in zip(graphs, ptr[:-1].tolist(), sizes):
-        ei = getattr(g, "edge_index", None)
-        if ei is None:
+    for g in graphs:
+        if getattr(g, "edge_index", None) is None:
             raise ValueError("every record needs an edge_index")
-        if ei.numel() and (int(ei.min()) < 0 or int(ei.max()) >= n):
-            raise ValueError("edge_index refers to a node outside its graph")
-        eis.append(ei.long() + off)
-    ei = torch.cat(eis, 1)
-    out.edge_index = ei.to(device) if device is not None else ei
+    out.fully_connected = all(_is_fully_connected(g, n) for g, n in zip(graphs, sizes))
+    if out.fully_connected and device is not None and torch.device(device).type == "cuda":
+        # all ordered pairs in every graph: the device builds the CSR and the collated edge_index comes from it (same
+        # edges in the same order) -- no concatenation of B edge lists on the host, no 16 B/edge host -> device copy
+        from .graph import fully_connected_plan, plan_edge_index
+        out._plan = fully_connected_plan(sizes, device)
+        out.edge_index = plan_edge_index(out._plan)
+    else:
+        eis = []
+        for g, off, n in zip(graphs, ptr[:-1].tolist(), sizes):
+            ei = g.edge_index
+            if ei.numel() and (int(ei.min()) < 0 or int(ei.max()) >= n):
+                raise ValueError("edge_index refers to a node outside its graph")
+            eis.append(ei.long() + off)
+        ei = torch.cat(eis, 1)
+        out.edge_index = ei.to(device) if device is not None else ei
     b = torch.repeat_interleave(torch.arange(len(graphs)), torch.tensor(sizes))
     out.batch = b.to(device) if device is not None else b
     out.ptr = ptr
     out.sizes = sizes
     out.num_graphs = len(graphs)
     out.id = [getattr(g, "id", None) for g in graphs]
-    out.fully_connected = all(_is_fully_connected(g, n) for g, n in zip(graphs, sizes))
     return out
 
 
@@ -204,10 +224,31 @@ class GraphLoader:
         if nb == 0:
             return
         steps = (nb + self.world_size - 1) // self.world_size
+        dev = torch.device(self.device) if self.device is not None else None
+        on_gpu = dev is not None and dev.type == "cuda"
+        if on_gpu and getattr(self, "_copy_stream", None) is None:
+            # host -> device copies of pageable tensors are ordered behind everything already queued on their stream: on
+            # the compute stream the host would wait for the previous training step before it can collate the next batch
+            self._copy_stream = torch.cuda.Stream(dev)
         for s in range(steps):
             gb = (s * self.world_size + self.rank) % nb
             idx = order[gb * self.batch_size:(gb + 1) * self.batch_size]
-            yield collate([self.dataset[i] for i in idx], device=self.device)
+            recs = [self.dataset[i] for i in idx]
+            if not on_gpu:
+                yield collate(recs, device=self.device)
+                continue
+            with torch.cuda.stream(self._copy_stream):
+                batch = collate(recs, device=dev)
+                plan = batch.plan()   # CSR of the batch, built here for the same reason (its small tables are copied too)
+            cur = torch.cuda.current_stream(dev)
+            cur.wait_stream(self._copy_stream)
+            # everything allocated under the copy stream is consumed on the compute stream, possibly long after the host
+            # has dropped the batch: the allocator must not recycle it for the next copies before that work has run
+            for v in vars(batch).values():
+                if torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(cur)
+            plan_record_stream(plan, cur)
+            yield batch
 
 
 # ---- flat on-disk format ---------------------------------------------------------------------------------------------

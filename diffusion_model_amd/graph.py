@@ -82,6 +82,18 @@ class GraphPlan:
             raise ValueError("an edge connects two different graphs")
 
 
+def plan_record_stream(plan: "GraphPlan", stream) -> None:
+    """Tell the caching allocator that every device array of ``plan`` (allocated under another stream, e.g. a loader's copy
+    stream) is used by work queued on ``stream``: its memory is not handed out again before that work has run."""
+    for v in vars(plan).values():
+        if torch.is_tensor(v) and v.is_cuda:
+            v.record_stream(stream)
+        elif isinstance(v, (tuple, list)):
+            for t in v:
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(stream)
+
+
 def _plan_from_sizes(sizes, device):
     from . import _lib
     dev = torch.device(device)

@@ -33,7 +33,8 @@ def diffuse_as_batch(pos, x_types, batch, diffusion_process, times: Optional[Seq
     times_t = torch.as_tensor(list(times), dtype=torch.long)
     if times_t.numel() != nb:
         raise ValueError("one diffusion time per graph")
-    times_d = times_t.to(pos.device, non_blocking=True)
+    # (pinned staging: a pageable host -> device copy makes the host wait for everything already queued on the stream)
+    times_d = (times_t.pin_memory() if pos.is_cuda else times_t).to(pos.device, non_blocking=True)
     a_all, s_all = diffusion_process.alpha_sigma_tables(pos.device, with_grad=torch.is_grad_enabled())
     t_node = times_d.index_select(0, batch)
     an, sn = a_all.index_select(0, t_node).unsqueeze(1), s_all.index_select(0, t_node).unsqueeze(1)
@@ -220,7 +221,8 @@ def _epoch(nn_dict, loader, params, diffusion_process, optimizer, train: bool, r
         (optimizer.train if train else optimizer.eval)()
     if params.get("to_compress_spectrum"):
         nn_dict["spectrum_compressor"].train(train)
-    total, nodes = 0.0, 0
+    total, nodes = None, 0   # the loss sum stays on the device: no host sync per step, so collating the next batch
+                             # overlaps the GPU's work on this one
     for data in loader:
         nb = getattr(data, "num_graphs", None)
         nb = int(data.batch.max().item()) + 1 if nb is None else int(nb)
@@ -242,8 +244,9 @@ def _epoch(nn_dict, loader, params, diffusion_process, optimizer, train: bool, r
                 topo = data.plan() if callable(getattr(data, "plan", None)) else data.edge_index
                 loss, _, _ = training_loss(egnn, topo, data.batch, noised, cond, params["atom_type_size"],
                                            num_graphs=nb)
-        total += float(loss) * nb                     # the reference re-multiplies by num_graph (:178)
-    return total / max(nodes, 1)                      # average per node (:181)
+        term = loss.detach().float() * nb             # the reference re-multiplies by num_graph (:178)
+        total = term if total is None else total + term
+    return (float(total) if total is not None else 0.0) / max(nodes, 1)   # average per node (:181)
 
 
 def train_epoch(nn_dict, train_loader, params, diffusion_process, optimizer, reducer=None):
