@@ -58,6 +58,24 @@ def test_collate_keeps_arbitrary_edge_lists_and_rejects_bad_input():
         D.collate([c, half])
 
 
+from hypothesis import given, settings, strategies as st
+
+
+@settings(max_examples=25, deadline=None)
+@given(st.lists(st.integers(min_value=1, max_value=9), min_size=1, max_size=6), st.integers(min_value=0, max_value=10 ** 6))
+def test_collate_round_trip_property(sizes, seed):
+    """collate -> to_data_list gives the records back (any sizes, single-atom graphs without edges included), and the
+    collated edge_index never crosses a graph boundary."""
+    recs = _records(tuple(sizes), S=3, seed=seed)
+    b = D.collate(recs)
+    assert b.batch.numel() == sum(sizes) and b.edge_index.shape[1] == sum(n * (n - 1) for n in sizes)
+    if b.edge_index.numel():
+        assert torch.equal(b.batch[b.edge_index[0]], b.batch[b.edge_index[1]])
+    for r, q in zip(recs, b.to_data_list()):
+        for k in ("x", "pos", "spectrum", "exO", "edge_index"):
+            assert torch.equal(getattr(r, k), getattr(q, k))
+
+
 def test_loader_epochs_and_shuffle():
     recs = _records((2, 3, 2, 4, 3, 2, 2))
     plain = list(D.GraphLoader(recs, batch_size=3))
