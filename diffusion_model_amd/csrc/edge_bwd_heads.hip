@@ -114,33 +114,49 @@ __global__ __launch_bounds__(kHT) void heads_m_kernel(int n_edges, const int* __
   for (int k = 0; k < 4; ++k) { wan[k] = was[c0 + k] * kNegLog2e; cs_b[k] = 0.f; cs_w[k] = 0.f; }
   const float ba = scal[1];
   float gba = 0.f;
-  for (int rr = wave; rr < rows; rr += kHT / 64) {
-    const int e = e_base + rr;
-    bf16x4_t* row = reinterpret_cast<bf16x4_t*>(t2 + (size_t)e * M + c0);
-    const bf16x4_t tv = *row;
-    const f32x4 g = *reinterpret_cast<const f32x4*>(g_sum_m + (size_t)dst[e] * M + c0);
-    float m[4], ds[4];
-    float z = 0.f, d = 0.f;
+  // two rows per sweep: their two pairs of wave reductions (12 dependent cross-lane steps each) overlap
+  for (int rr = 2 * wave; rr < rows; rr += 2 * (kHT / 64)) {
+    const bool two = rr + 1 < rows;
+    bf16x4_t* row[2];
+    bf16x4_t tv[2];
+    f32x4 g[2];
+    float m[2][4], ds[2][4], z[2] = {0.f, 0.f}, d[2] = {0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      silu_grad_s((float)tv[k], m[k], ds[k]);
-      z = fmaf(wan[k], m[k], z);
-      d = fmaf(g[k], m[k], d);
+    for (int u = 0; u < 2; ++u) {
+      const int e = e_base + rr + ((u == 1 && two) ? 1 : 0);
+      row[u] = reinterpret_cast<bf16x4_t*>(t2 + (size_t)e * M + c0);
+      tv[u] = *row[u];
+      g[u] = *reinterpret_cast<const f32x4*>(g_sum_m + (size_t)dst[e] * M + c0);
     }
 #pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) { z += __shfl_xor(z, s); d += __shfl_xor(d, s); }
-    const float gate = sigmoid_f(z + ba);
-    const float coef = d * gate * (1.0f - gate);
-    gba += coef;
-    bf16x4_t gv;
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float ga = fmaf(g[k], gate, coef * wan[k]) * ds[k];
-      cs_b[k] += ga;
-      cs_w[k] = fmaf(coef, m[k], cs_w[k]);
-      gv[k] = (__bf16)ga;
+      for (int k = 0; k < 4; ++k) {
+        silu_grad_s((float)tv[u][k], m[u][k], ds[u][k]);
+        z[u] = fmaf(wan[k], m[u][k], z[u]);
+        d[u] = fmaf(g[u][k], m[u][k], d[u]);
+      }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+      z[0] += __shfl_xor(z[0], s); d[0] += __shfl_xor(d[0], s);
+      z[1] += __shfl_xor(z[1], s); d[1] += __shfl_xor(d[1], s);
     }
-    *row = gv;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (u == 1 && !two) break;
+      const float gate = sigmoid_f(z[u] + ba);
+      const float coef = d[u] * gate * (1.0f - gate);
+      gba += coef;
+      bf16x4_t gv;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float ga = fmaf(g[u][k], gate, coef * wan[k]) * ds[u][k];
+        cs_b[k] += ga;
+        cs_w[k] = fmaf(coef, m[u][k], cs_w[k]);
+        gv[k] = (__bf16)ga;
+      }
+      *row[u] = gv;
+    }
   }
   __shared__ float s_cs[2][kHT / 64][M];
   __shared__ float s_red[kHT / 64];
