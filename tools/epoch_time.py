@@ -18,7 +18,7 @@ t0 = time.perf_counter(); l = dma.train_epoch(nn_dict, loader, params, proc, opt
 print("train_epoch: %.1f ms per step (6 steps), loss/node %.3f" % ((t1 - t0) / 6 * 1e3, l))
 # a few more epochs: the host runs several steps ahead of the GPU here, which is what exposes lifetime mistakes between
 # the loader's copy stream and the compute stream
-for ep in range(3):
+for ep in range(6):
     t0 = time.perf_counter(); l = dma.train_epoch(nn_dict, loader, params, proc, opt); torch.cuda.synchronize(); t1 = time.perf_counter()
-    print("epoch %d: %.1f ms per step, loss/node %.3f" % (ep, (t1 - t0) / 6 * 1e3, l))
+    print("epoch %d: %.1f ms per step, loss/node %.3f, reserved %.1f GB, allocated %.1f GB" % (ep, (t1 - t0) / 6 * 1e3, l, torch.cuda.memory_reserved() / 2**30, torch.cuda.memory_allocated() / 2**30))
     assert l == l
