@@ -3,7 +3,7 @@ Ren-Okubo/diffusion_model).  Host-side mirror of the reference's operator interf
 arithmetic on the path runs in libegnn_amd.so (hand-written HIP for gfx950) through the C ABI
 declared in include/egnn_amd.h."""
 from .egnn import EGCL, EquivariantGNN  # noqa: F401
-from .diffusion import E3DiffusionProcess, remove_mean  # noqa: F401
+from .diffusion import E3DiffusionProcess, E3DiffusionProcessLegacy, E3DiffusionProcessXOnly, remove_mean  # noqa: F401
 from .graph import GraphPlan, fully_connected_edge_index, fully_connected_plan, plan_edge_index, radius_plan  # noqa: F401
 from . import partition, stats  # noqa: F401
 from .partition import PartitionedSampler  # noqa: F401

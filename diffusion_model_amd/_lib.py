@@ -45,6 +45,7 @@ SIGNATURES = {
     "schedule_table_from_alpha": (_i, [_i, _fp, _fp, _fp]),
     "ddpm_reverse_step": (_i, [_vp, _i, _i, _i, _vp, _i, _f, _f, _f, _vp, _i, _vp, _vp, _vp, _i]),
     "egnn_sampler_prepare": (_i, [_vp, _i, _i, _f, _vp, _vp, _u64]),
+    "egnn_sampler_set_mode": (_i, [_vp, _i]),
     "egnn_sampler_init": (_i, [_vp, _vp, _vp, _vp]),
     "egnn_sampler_run": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "egnn_sampler_final": (_i, [_vp, _vp, _i, _i] + [_vp] * 5),

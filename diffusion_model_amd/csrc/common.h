@@ -64,6 +64,7 @@ constexpr int kGraphSteps = 8;   // reverse steps captured per hipGraph
 struct Sampler {
   bool ready = false;
   int T = 0, A = 0, t = 0;
+  int x_only = 0;                  // 1: positions diffuse, atom types fixed (test.py:253-279)
   float onehot_scale = 1.f;
   uint64_t seed = 0;
   const float* d_table = nullptr;  // [(T+1)*4] caller-owned

@@ -127,6 +127,7 @@ struct StepParams {
   float* pos;           // state, updated in place
   float* h;             // state [N][H], columns [0,A) and H-1 updated in place
   int* bad;             // [B]
+  int x_only;           // 1: the x-only loop of test.py:253-279 -- atom types stay fixed, only positions diffuse
 };
 constexpr int kMaxA = 8;
 
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(kThreads) void sampler_step_kernel(const StepParams
       p.pos[3 * n + j] = v;
       bad |= !isfinite(v);
     }
-    for (int a0 = 0; a0 < p.A; a0 += 4) {
+    for (int a0 = 0; a0 < (p.x_only ? 0 : p.A); a0 += 4) {
       float zh[4];
       if (!p.noise_h) normal4(p.seed, (uint32_t)t, (uint32_t)n, 1u + a0 / 4, zh);
       for (int j = 0; j < 4 && a0 + j < p.A; ++j) {
@@ -287,7 +288,7 @@ static StepParams make_params(egnn_ctx* c) {
   p.graph_ptr = c->graph_ptr; p.table = s.d_table; p.t_dev = s.t_dev; p.t0_dev = s.t_dev + 1;
   p.ticket = reinterpret_cast<unsigned*>(s.t_dev + 2);
   p.noise_pos = nullptr; p.noise_h = nullptr; p.h_out = s.h_out; p.x_out = s.x_out; p.pos = s.pos; p.h = s.h;
-  p.bad = s.bad; p.t_imm = 0;
+  p.bad = s.bad; p.t_imm = 0; p.x_only = s.x_only;
   return p;
 }
 
@@ -390,7 +391,7 @@ static int ext_params(StepParams& p, int N, int H, int A, int B, int T, const in
   }
   p.N = N; p.H = H; p.A = A; p.T = T; p.scale = scale; p.seed = seed; p.graph_ptr = graph_ptr; p.table = table;
   p.t_dev = nullptr; p.t0_dev = nullptr; p.ticket = nullptr; p.t_imm = 0; p.noise_pos = nullptr; p.noise_h = nullptr;
-  p.h_out = nullptr; p.x_out = nullptr; p.pos = pos; p.h = h; p.bad = bad;
+  p.h_out = nullptr; p.x_out = nullptr; p.pos = pos; p.h = h; p.bad = bad; p.x_only = 0;
   return EGNN_OK;
 }
 
@@ -521,8 +522,17 @@ int egnn_sampler_prepare(egnn_ctx* c, int T, int A, float onehot_scale, const fl
   return EGNN_OK;
 }
 
+int egnn_sampler_set_mode(egnn_ctx* c, int x_only) {
+  if (!c || !c->smp.ready) { set_error("egnn_sampler_prepare first"); return EGNN_ESTATE; }
+  if (x_only != 0 && x_only != 1) { set_error("sampler mode must be 0 (x and h) or 1 (x only)"); return EGNN_EINVAL; }
+  if (c->smp.x_only != x_only) graph_free(c->smp);   // the captured step kernels carry the mode
+  c->smp.x_only = x_only;
+  return EGNN_OK;
+}
+
 int egnn_sampler_init(egnn_ctx* c, void* stream, const float* d_pos_init, const float* d_x_init) {
   if (!c || !c->smp.ready) { set_error("egnn_sampler_prepare first"); return EGNN_ESTATE; }
+  if (c->smp.x_only && !d_x_init) { set_error("the x-only sampler needs the fixed atom types (x_init)"); return EGNN_EINVAL; }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   Sampler& s = c->smp;
   s.t = s.T;
@@ -574,6 +584,7 @@ int egnn_sampler_final(egnn_ctx* c, void* stream, int prec, int norm_scope, cons
   if (!c || !c->smp.ready) { set_error("egnn_sampler_prepare first"); return EGNN_ESTATE; }
   Sampler& s = c->smp;
   if (s.t != 0) { set_error("final decode called at t=%d (must be 0)", s.t); return EGNN_ESTATE; }
+  if (s.x_only) { set_error("the x-only loop (test.py:253-279) has no t = 0 decode: read egnn_sampler_state"); return EGNN_ESTATE; }
   if (!d_pos_out || !d_hc_out || !d_onehot_out) { set_error("null output"); return EGNN_EINVAL; }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int rc;

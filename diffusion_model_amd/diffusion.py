@@ -217,3 +217,103 @@ class E3DiffusionProcessXOnly(E3DiffusionProcess):
                                                 float(self.step_table()[t][2]), _lib.ptr(mc), d, _lib.ptr(mc),
                                                 _lib.ptr(nz), _lib.ptr(out), d))
         return out
+
+
+class E3DiffusionProcessLegacy:
+    """The oldest process of the reference (E3diffusion.py:9-120, named by north_star; imported by no driver): the
+    beta-schedule class -- ``E3DiffusionProcess(initial_beta, final_beta, num_diffusion_timestep, schedule_function)`` with
+    ``diffuse_zero_to_t(pos, t)`` (:23-28: alpha_bar_t pos + beta_t noise, sic), ``calculate_mu(pos, eps, t)`` (:30-56, x_hat
+    divided by sqrt(alpha_t) of the step, sic) and ``reverse_diffuse_one_step(mu, t)`` (:58-72) -- and its second, polynomial
+    variant ``diffuse_to_t / mu_calculate / reverse_onestep`` (:88-120; schedule with steps = T + 1, :79-86).
+
+    The [T+1] schedules are built on the host with the reference's own torch expressions; every step is a linear
+    combination c0 z - c1 eps + c2 remove_mean(noise) and runs in the ``ddpm_reverse_step`` kernel.  ``noise`` (extension,
+    as in E3DiffusionProcess) replaces the N(0, I) draw before the mean removal."""
+
+    def __init__(self, initial_beta, final_beta, num_diffusion_timestep: int, schedule_function="sigmoid"):
+        self.initial_beta, self.final_beta = initial_beta, final_beta
+        self.schedule_function = schedule_function
+        self.num_diffusion_timestep = num_diffusion_timestep
+        if schedule_function == "sigmoid":      # :15-17
+            self.beta_schedule = torch.sigmoid(torch.linspace(-6, 6, num_diffusion_timestep + 1))
+            self.beta_schedule = self.beta_schedule * (final_beta - initial_beta) + initial_beta
+        elif schedule_function == "linear":     # :18-19
+            self.beta_schedule = torch.linspace(initial_beta, final_beta, num_diffusion_timestep + 1)
+        else:
+            raise ValueError(schedule_function)
+        self.alpha_schedule = torch.ones(self.beta_schedule.shape) - self.beta_schedule      # :20
+        self.alpha_bar_schedule = torch.cumprod(self.alpha_schedule, dim=0)                  # :21
+        self._poly = {}
+
+    # -- the three kernels' constants -----------------------------------------------------------------
+    @staticmethod
+    def _mix(z, eps, noise, c0, c1, c2, remove):
+        zc, ec = E3DiffusionProcess._prep(z), E3DiffusionProcess._prep(eps)
+        if noise is None:
+            noise = torch.zeros_like(zc).normal_(mean=0, std=1)
+        nz = E3DiffusionProcess._prep(noise)
+        out = torch.empty_like(zc)
+        n, d = zc.shape
+        _lib.check(_lib.lib().ddpm_reverse_step(_lib.stream_ptr(), n, d, 1 if remove else 0, None, 0, float(c0), float(c1),
+                                                float(c2), _lib.ptr(zc), d, _lib.ptr(ec), _lib.ptr(nz), _lib.ptr(out), d))
+        return out
+
+    @staticmethod
+    def _step_consts(alpha_t, alpha_s, sq_t, sq_s, xhat_div, xhat_sig):
+        """mu = alpha_ts sq_s z / sq_t + alpha_s sq_ts x_hat / sq_t with x_hat = (z - xhat_sig eps) / xhat_div, as fp32
+        scalars in the reference's operation order -> (c0, c1, std)"""
+        alpha_ts = alpha_t / alpha_s
+        sq_ts = sq_t - torch.pow(alpha_ts, 2) * sq_s
+        a, b = alpha_ts * sq_s / sq_t, alpha_s * sq_ts / sq_t
+        return a + b / xhat_div, b * xhat_sig / xhat_div, torch.sqrt(sq_ts * sq_s / sq_t)
+
+    def _beta_consts(self, t):
+        ab = self.alpha_bar_schedule
+        return self._step_consts(torch.sqrt(ab[t]), torch.sqrt(ab[t - 1]), 1 - ab[t], 1 - ab[t - 1],
+                                 torch.sqrt(self.alpha_schedule[t]), torch.sqrt(1 - ab[t]))
+
+    # -- beta-schedule class (:23-72) ------------------------------------------------------------------
+    def diffuse_zero_to_t(self, pos, t: int, noise: Optional[torch.Tensor] = None):
+        pc = E3DiffusionProcess._prep(pos)
+        noise = torch.zeros_like(pc).normal_(mean=0, std=1) if noise is None else E3DiffusionProcess._prep(noise).clone()
+        noise = remove_mean(noise)
+        return self._mix(pc, pc, noise, self.alpha_bar_schedule[t], 0.0, self.beta_schedule[t], False), noise
+
+    def calculate_mu(self, pos, epsilon, t: int):
+        c0, c1, _ = self._beta_consts(t)
+        return self._mix(pos, epsilon, epsilon, c0, c1, 0.0, False)
+
+    def reverse_diffuse_one_step(self, mu, t: int, noise: Optional[torch.Tensor] = None):
+        return self._mix(mu, mu, noise, 1.0, 0.0, self._beta_consts(t)[2], True)
+
+    # -- polynomial variant (:79-120) ------------------------------------------------------------------
+    def clip_noise_schedule(self, alphas2, clip_value=0.001):
+        alphas2 = torch.cat([torch.ones(1), alphas2], dim=0)
+        return torch.cumprod(torch.clamp(alphas2[1:] / alphas2[:-1], min=clip_value, max=1.0), dim=0)
+
+    def polynomial_schedule(self, timesteps: int, s=1e-4, power=3.0):
+        steps = timesteps + 1                                            # :80-81 (sic: not the grid of diffusion_x_h.py)
+        x = torch.linspace(0, steps, steps)
+        alphas2 = self.clip_noise_schedule(torch.pow(1 - torch.pow(x / steps, power), 2), clip_value=0.001)
+        return (1 - 2 * s) * alphas2 + s
+
+    def _poly_consts(self, t, s):
+        if s not in self._poly:      # the reference rebuilds the schedule on every call (:89, :96, :108)
+            self._poly[s] = self.polynomial_schedule(self.num_diffusion_timestep, s=s)
+        alpha = self._poly[s]
+        sq_t, sq_s = 1 - alpha[t] ** 2, 1 - alpha[t - 1] ** 2
+        return alpha, self._step_consts(alpha[t], alpha[t - 1], sq_t, sq_s, alpha[t], torch.sqrt(sq_t))
+
+    def diffuse_to_t(self, pos, t: int, s=1e-4, noise: Optional[torch.Tensor] = None):
+        alpha, _ = self._poly_consts(max(t, 1), s)
+        pc = E3DiffusionProcess._prep(pos)
+        noise = torch.zeros_like(pc).normal_(mean=0, std=1) if noise is None else E3DiffusionProcess._prep(noise).clone()
+        noise = remove_mean(noise)
+        return self._mix(pc, pc, noise, alpha[t], 0.0, torch.sqrt(1 - alpha[t] ** 2), False), noise
+
+    def mu_calculate(self, pos, epsilon, t: int, s=1e-4):
+        c0, c1, _ = self._poly_consts(t, s)[1]
+        return self._mix(pos, epsilon, epsilon, c0, c1, 0.0, False)
+
+    def reverse_onestep(self, mu, t: int, s=1e-4, noise: Optional[torch.Tensor] = None):
+        return self._mix(mu, mu, noise, 1.0, 0.0, self._poly_consts(t, s)[1][2], True)

@@ -24,12 +24,17 @@ class DeviceSampler:
 
     One live sampler per model: the sampler state lives in the model's egnn_ctx, so preparing a second
     DeviceSampler on the same ``egnn`` invalidates the first (its next call raises EGNN_ESTATE).
+
+    mode='x_only': the reverse loop of the reference's test.py:253-279 (process of E3diffusion_new.py): the atom types
+    ``x_types`` [N, A] stay fixed, only the positions diffuse, and the loop ends with the reverse step at t = 1 (no
+    t = 0 decode); ``sample()`` then returns (pos, x_types, x_types as int64, bad).
     """
 
     def __init__(self, egnn, diffusion_process, sizes: Sequence[int], cond: Optional[torch.Tensor],
                  atom_type_size: int = 2, onehot_scaling_factor: float = 1.0, seed: int = 0,
                  precision: Optional[str] = None, norm_scope: str = "graph", device=None,
-                 edge_index: Optional[torch.Tensor] = None):
+                 edge_index: Optional[torch.Tensor] = None, mode: str = "x_h",
+                 x_types: Optional[torch.Tensor] = None):
         self.device = torch.device(device if device is not None else "cuda")
         if self.device.type != "cuda":
             raise RuntimeError("DeviceSampler needs an AMD GPU ('cuda' device); there is no CPU fallback")
@@ -41,6 +46,13 @@ class DeviceSampler:
         self.T = diffusion_process.num_diffusion_timestep
         self.precision = _lib.PRECISIONS[precision or egnn.precision]
         self.norm_scope = _lib.NORM_SCOPES[norm_scope]
+        if mode not in ("x_h", "x_only"):
+            raise ValueError("mode must be 'x_h' or 'x_only'")
+        self.x_only = mode == "x_only"
+        if self.x_only:
+            if x_types is None or tuple(x_types.shape) != (self.N, self.A):
+                raise ValueError(f"mode='x_only' needs the fixed atom types x_types [{self.N}, {self.A}]")
+            self.x_types = x_types.detach().to(self.device, torch.float32).contiguous()
         H = egnn.egcl_list[0].dims["H"]
         ncond = H - self.A - 1
         if ncond < 0:
@@ -60,6 +72,8 @@ class DeviceSampler:
         torch.cuda.current_stream().synchronize()
         _lib.check(_lib.lib().egnn_sampler_prepare(self.ctx.handle, self.T, self.A, float(onehot_scaling_factor),
                                                    _lib.ptr(self.table), _lib.ptr(cond), C.c_uint64(seed)))
+        if self.x_only:
+            _lib.check(_lib.lib().egnn_sampler_set_mode(self.ctx.handle, 1))
 
     def _sp(self):
         return C.c_void_p(self.stream.cuda_stream)
@@ -68,6 +82,8 @@ class DeviceSampler:
         """x_T ~ N(0,I) mean-removed per graph, h_T ~ N(0,I) (:301-305), or explicit initial state."""
         self.egnn.context_for(self.plan)  # re-pack if the weights changed
         self.stream.wait_stream(torch.cuda.current_stream())
+        if self.x_only and x_init is None:
+            x_init = self.x_types
         keep = [t.detach().to(self.device, torch.float32).contiguous() if t is not None else None for t in (pos_init, x_init)]
         _lib.check(_lib.lib().egnn_sampler_init(self.ctx.handle, self._sp(), _lib.ptr(keep[0]), _lib.ptr(keep[1])))
         self.stream.synchronize()
@@ -126,6 +142,9 @@ class DeviceSampler:
     def sample(self, use_graph: bool = True):
         self.init()
         self.run(use_graph=use_graph)
+        if self.x_only:   # test.py:253-279 ends with the reverse step at t = 1
+            pos, xt, bad = self.state()
+            return pos, xt, xt.round().long(), bad
         return self.final()
 
 

@@ -226,6 +226,11 @@ int ddpm_reverse_step(void* stream, int N, int D, int mode_pos, const int32_t* d
  * egnn_sampler_step. */
 int egnn_sampler_prepare(egnn_ctx* ctx, int T, int A, float onehot_scale, const float* d_table,
                          const float* d_cond, uint64_t seed);
+/* x_only = 1 selects the x-only reverse loop of the reference's test.py:253-279 (process of E3diffusion_new.py:63-98):
+ * the atom types given to egnn_sampler_init stay FIXED, only the positions take reverse steps (mu in the x_hat form is
+ * algebraically the mu of diffusion_x_h.py:61-73, so the same step table serves both), and the loop ends with the reverse
+ * step at t = 1: there is no t = 0 decode (egnn_sampler_final refuses; read egnn_sampler_state).  0 (default) = x and h. */
+int egnn_sampler_set_mode(egnn_ctx* ctx, int x_only);
 /* x_T ~ N(0,I) mean-removed per graph, h_T ~ N(0,I) (:301-305); or copy from the given arrays */
 int egnn_sampler_init(egnn_ctx* ctx, void* stream, const float* d_pos_init, const float* d_x_init);
 /* run `nsteps` reverse steps starting at the sampler's current t (initially T), optionally

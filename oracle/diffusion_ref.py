@@ -139,3 +139,60 @@ class DiffusionRef:
         a0, s0 = self.alpha(0), self.sigma(0)
         tab[0, 0], tab[0, 1], tab[0, 2], tab[0, 3] = 1.0 / a0, s0 / a0, s0 / a0, 0.0
         return tab
+
+
+class LegacyRef:
+    """Restatement of the oldest process, E3diffusion.py:9-120 (imported by no driver; named by north_star), with explicit
+    noise: the beta-schedule class (:15-72) and the polynomial variant (:79-120)."""
+
+    def __init__(self, initial_beta, final_beta, num_diffusion_timestep, schedule_function="sigmoid"):
+        self.num_diffusion_timestep = num_diffusion_timestep
+        self.beta_schedule, self.alpha_schedule, self.alpha_bar_schedule = beta_schedule_legacy(
+            initial_beta, final_beta, num_diffusion_timestep, schedule_function)
+
+    @staticmethod
+    def _mu(pos, eps, alpha_t, alpha_s, sq_t, sq_s, x_hat):
+        alpha_ts = alpha_t / alpha_s
+        sq_ts = sq_t - torch.pow(alpha_ts, 2) * sq_s
+        return alpha_ts * sq_s * pos / sq_t + alpha_s * sq_ts * x_hat / sq_t
+
+    @staticmethod
+    def _std(alpha_t, alpha_s, sq_t, sq_s):
+        alpha_ts = alpha_t / alpha_s
+        sq_ts = sq_t - torch.pow(alpha_ts, 2) * sq_s
+        return torch.sqrt(sq_ts * sq_s / sq_t)
+
+    def diffuse_zero_to_t(self, pos, t, noise):
+        """:23-28 (alpha_bar_t * pos + beta_t * noise, sic)."""
+        noise = remove_mean(noise)
+        return self.alpha_bar_schedule[t] * pos + self.beta_schedule[t] * noise, noise
+
+    def calculate_mu(self, pos, eps, t):
+        """:30-56; x_hat is divided by sqrt(alpha_schedule[t]) (the step's alpha, not alpha_bar -- sic, :39)."""
+        ab = self.alpha_bar_schedule
+        x_hat = (pos - torch.sqrt(1 - ab[t]) * eps) / torch.sqrt(self.alpha_schedule[t])
+        return self._mu(pos, eps, torch.sqrt(ab[t]), torch.sqrt(ab[t - 1]), 1 - ab[t], 1 - ab[t - 1], x_hat)
+
+    def reverse_diffuse_one_step(self, mu, t, noise):
+        """:58-72."""
+        ab = self.alpha_bar_schedule
+        return mu + self._std(torch.sqrt(ab[t]), torch.sqrt(ab[t - 1]), 1 - ab[t], 1 - ab[t - 1]) * remove_mean(noise)
+
+    # polynomial variant: the schedule is rebuilt on every call in the reference (:89, :96, :108)
+    def diffuse_to_t(self, pos, t, noise, s=1e-4):
+        """:88-94."""
+        alpha = polynomial_schedule_legacy(self.num_diffusion_timestep, s=s)
+        noise = remove_mean(noise)
+        return alpha[t] * pos + torch.sqrt(1 - alpha[t] ** 2) * noise, noise
+
+    def mu_calculate(self, pos, eps, t, s=1e-4):
+        """:95-105."""
+        alpha = polynomial_schedule_legacy(self.num_diffusion_timestep, s=s)
+        sq_t, sq_s = 1 - alpha[t] ** 2, 1 - alpha[t - 1] ** 2
+        x_hat = pos / alpha[t] - torch.sqrt(sq_t) / alpha[t] * eps
+        return self._mu(pos, eps, alpha[t], alpha[t - 1], sq_t, sq_s, x_hat)
+
+    def reverse_onestep(self, mu, t, noise, s=1e-4):
+        """:107-120."""
+        alpha = polynomial_schedule_legacy(self.num_diffusion_timestep, s=s)
+        return mu + self._std(alpha[t], alpha[t - 1], 1 - alpha[t] ** 2, 1 - alpha[t - 1] ** 2) * remove_mean(noise)

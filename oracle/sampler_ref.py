@@ -102,3 +102,66 @@ def training_loss(sd, diff: DiffusionRef, pos0, x0, cond, edge_index, graph_inde
     target = torch.cat((y_pos, y_h), dim=1)
     loss = ((pred - target) ** 2).sum() / nb
     return loss, eps_x, eps_h, y_pos, y_h
+
+
+def sample_batch(sd, diff: DiffusionRef, sizes, cond: Optional[torch.Tensor], generator,
+                 atom_type_size=2, onehot_scale=1.0, x_fixed: Optional[torch.Tensor] = None):
+    """The same while-body (:301-428) for MANY independent graphs at once (statistics tests): every graph is what
+    ``sample_one_graph`` computes for it -- per-graph mean removal, per-graph coordinate normaliser
+    (norm_scope='graph' == one graph per call) -- with the N(0, I) draws taken from ``generator``
+    (a torch.Generator, or a callable ``draw(rows, cols) -> tensor``; the reference uses torch's global RNG).
+    Draw order: x_T, h_T, then per step the position noise and the type noise, then the two draws of the decode.
+
+    ``x_fixed`` [N, A]: the x-only loop of test.py:253-279 instead -- atom types stay fixed, only positions
+    diffuse, mu in the x_hat form of E3diffusion_new.py:63-83, and there is NO t = 0 decode (the loop ends with
+    the reverse step at t = 1).
+
+    Returns (pos [N,3], h_cont [N,A], onehot [N,A], finite flag per graph [B]).
+    """
+    sizes = [int(s) for s in sizes]
+    B, N = len(sizes), sum(sizes)
+    T = diff.num_diffusion_timestep
+    gi = torch.repeat_interleave(torch.arange(B), torch.tensor(sizes))
+    ptr = torch.zeros(B + 1, dtype=torch.long)
+    ptr[1:] = torch.cumsum(torch.tensor(sizes), 0)
+    ei = fully_connected_edge_index(sizes)
+    rn = generator if callable(generator) else (lambda *shape: torch.randn(*shape, generator=generator))
+    pos = remove_mean(rn(N, 3), gi)
+    x = rn(N, atom_type_size) if x_fixed is None else x_fixed.float().clone()
+    ok = torch.ones(B, dtype=torch.bool)
+
+    def graph_ok(*ts):
+        f = torch.ones(N, dtype=torch.bool)
+        for t_ in ts:
+            f &= torch.isfinite(t_).all(dim=1)
+        return torch.zeros(B, dtype=torch.long).index_add_(0, gi, (~f).long()) == 0
+
+    def h_of(t_frac):
+        cols = [onehot_scale * x] + ([cond] if cond is not None and cond.shape[1] > 0 else [])
+        return torch.cat(cols + [torch.full((N, 1), float(t_frac))], dim=1)
+
+    for t in range(T, 0, -1):
+        h = h_of(t / T)
+        new_h, new_x = egnn_forward(sd, ei, h, pos, "graph", ptr)
+        eps_x = remove_mean((new_x - pos).clone(), gi)
+        if x_fixed is None:
+            eps_h = new_h[:, :atom_type_size]
+            # per-graph mean removal of the position noise == remove_mean(noise) of a one-graph call
+            mu = diff.calculate_mu(pos, eps_x, t)
+            pos = mu + diff.step_std(t) * remove_mean(rn(N, 3), gi)
+            x = diff.reverse_diffuse_one_step(h[:, :atom_type_size], eps_h, t, rn(N, atom_type_size), "h")
+        else:
+            pos = diff.calculate_mu_xhat(pos, eps_x, t) + diff.step_std(t) * remove_mean(rn(N, 3), gi)
+        ok &= graph_ok(pos, x)
+    if x_fixed is not None:
+        return pos, x, x.round().long(), ok
+    h = h_of(0.0)
+    new_h, new_x = egnn_forward(sd, ei, h, pos, "graph", ptr)
+    eps_x = remove_mean((new_x - pos).clone(), gi)
+    hh, eps_h = h[:, :atom_type_size], new_h[:, :atom_type_size]
+    a0, s0 = diff.alpha(0), diff.sigma(0)
+    pos = pos / a0 - s0 * eps_x / a0 + s0 * remove_mean(rn(N, 3), gi) / a0
+    hc = hh / a0 - s0 * eps_h / a0 + s0 * rn(N, atom_type_size) / a0
+    onehot = torch.nn.functional.one_hot(torch.argmax(hc, dim=1), num_classes=atom_type_size)
+    ok &= graph_ok(pos, hc)
+    return pos, hc, onehot, ok

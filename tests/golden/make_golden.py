@@ -216,6 +216,83 @@ def run_diffusion_cases(dxh, dnew, dold):
     return out
 
 
+def run_learned_and_legacy_cases(dxh, dnew, dold):
+    """round 3: (a) diffusion_x_h.E3DiffusionProcess(..., noise_schedule='learned') executed as it is (:27-30, :36-46,
+    :61-90): the alpha / sigma tables over the whole grid and calculate_mu / reverse_diffuse_one_step / diffuse_zero_to_t
+    at t in {1, 2, T/2, T-1, T} with the reference's own draws recorded; (b) the legacy process of E3diffusion.py:9-120 --
+    beta-schedule class (diffuse_zero_to_t :23-28, calculate_mu :30-56 incl. its sqrt(alpha_t) in x_hat,
+    reverse_diffuse_one_step :58-72) and the second polynomial variant (diffuse_to_t / mu_calculate / reverse_onestep
+    :88-120)."""
+    out = {}
+    T = 50
+    torch.manual_seed(31)
+    proc = dxh.E3DiffusionProcess(1e-5, 2.0, T, noise_schedule="learned").eval()
+    with torch.no_grad():
+        proc.gamma.gamma_0.fill_(-4.0)      # not the init values, so that a loaded state dict is what is tested
+        proc.gamma.gamma_1.fill_(7.5)
+    for k, v in sd_numpy(proc.gamma, prefix="learned.W.").items():
+        out[k] = v
+    g = torch.Generator().manual_seed(77)
+    z3, e3 = torch.randn(9, 3, generator=g), torch.randn(9, 3, generator=g)
+    z2, e2 = torch.randn(9, 2, generator=g), torch.randn(9, 2, generator=g)
+    out["learned.z3"], out["learned.e3"], out["learned.z2"], out["learned.e2"] = z3.numpy(), e3.numpy(), z2.numpy(), e2.numpy()
+    with torch.no_grad():
+        out["learned.gamma"] = proc.gamma_schedule().numpy()
+        out["learned.alpha"] = torch.stack([proc.alpha(t) for t in range(T + 1)]).reshape(-1).numpy()
+        out["learned.sigma"] = torch.stack([proc.sigma(t) for t in range(T + 1)]).reshape(-1).numpy()
+        ts = sorted({1, 2, T // 2, T - 1, T})
+        out["learned.ts"] = np.array(ts, dtype=np.int64)
+        for t in ts:
+            out[f"learned.mu3.t{t}"] = proc.calculate_mu(z3, e3, t).numpy()
+            out[f"learned.mu2.t{t}"] = proc.calculate_mu(z2, e2, t).numpy()
+            for mode, z, e in (("pos", z3, e3), ("h", z2, e2)):
+                torch.manual_seed(4000 + t)
+                noise = torch.zeros_like(z).normal_(mean=0, std=1)
+                torch.manual_seed(4000 + t)
+                out[f"learned.rev_{mode}.t{t}"] = proc.reverse_diffuse_one_step(z, e, t, mode=mode).numpy()
+                out[f"learned.noise_{mode}.t{t}"] = noise.numpy()
+                torch.manual_seed(5000 + t)
+                noise = torch.zeros_like(z, dtype=torch.float).normal_(mean=0, std=1)
+                torch.manual_seed(5000 + t)
+                zt, used = proc.diffuse_zero_to_t(z, t, mode=mode)
+                out[f"learned.fwd_{mode}.t{t}"] = zt.numpy()
+                out[f"learned.fwd_noise_{mode}.t{t}"] = noise.numpy()
+    # ---- legacy process ----
+    Tl = 100
+    out["legacy.params"] = np.array([1e-4, 2e-2, Tl], dtype=np.float64)
+    ts = [1, 2, Tl // 2, Tl - 1, Tl]
+    out["legacy.ts"] = np.array(ts, dtype=np.int64)
+    out["legacy.z3"], out["legacy.e3"] = z3.numpy(), e3.numpy()
+    for fn in ("sigmoid", "linear"):
+        old = dold.E3DiffusionProcess(1e-4, 2e-2, Tl, schedule_function=fn)
+        for t in ts:
+            mu = old.calculate_mu(z3, e3, t)
+            out[f"legacy.{fn}.mu.t{t}"] = mu.numpy()
+            torch.manual_seed(6000 + t)
+            noise = torch.zeros_like(z3).normal_(mean=0, std=1)
+            torch.manual_seed(6000 + t)
+            out[f"legacy.{fn}.rev.t{t}"] = old.reverse_diffuse_one_step(mu, t).numpy()
+            out[f"legacy.{fn}.noise.t{t}"] = noise.numpy()
+            torch.manual_seed(7000 + t)
+            zt, used = old.diffuse_zero_to_t(z3, t)
+            out[f"legacy.{fn}.fwd.t{t}"] = zt.numpy()
+            out[f"legacy.{fn}.fwd_used.t{t}"] = used.numpy()
+    old = dold.E3DiffusionProcess(1e-4, 2e-2, Tl)
+    for t in ts:
+        mu = old.mu_calculate(z3, e3, t, s=1e-4)
+        out[f"legacy.poly.mu.t{t}"] = mu.numpy()
+        torch.manual_seed(8000 + t)
+        noise = torch.zeros_like(z3).normal_(mean=0, std=1)
+        torch.manual_seed(8000 + t)
+        out[f"legacy.poly.rev.t{t}"] = old.reverse_onestep(mu, t, s=1e-4).numpy()
+        out[f"legacy.poly.noise.t{t}"] = noise.numpy()
+        torch.manual_seed(9000 + t)
+        zt, used = old.diffuse_to_t(z3, t, s=1e-4)
+        out[f"legacy.poly.fwd.t{t}"] = zt.numpy()
+        out[f"legacy.poly.fwd_used.t{t}"] = used.numpy()
+    return out
+
+
 def run_aux_cases(SNR, DP):
     out = {}
     torch.manual_seed(5)
@@ -303,12 +380,13 @@ def main():
     np.savez_compressed(os.path.join(OUT, "egnn_golden.npz"), **run_egnn_cases(EG.EquivariantGNN))
     np.savez_compressed(os.path.join(OUT, "diffusion_golden.npz"), **run_diffusion_cases(dxh, dnew, dold))
     np.savez_compressed(os.path.join(OUT, "aux_golden.npz"), **run_aux_cases(SNR, DP))
+    np.savez_compressed(os.path.join(OUT, "learned_legacy_golden.npz"), **run_learned_and_legacy_cases(dxh, dnew, dold))
     os.environ.setdefault("MPLBACKEND", "Agg")
     import evaluate_by_angle_for_2_atoms_graph as EA
     sys.modules.setdefault("wandb", types.ModuleType("wandb"))    # empty: lets `import wandb` succeed, nothing else
     import evaluate_RDF as ER
     np.savez_compressed(os.path.join(OUT, "stats_golden.npz"), **run_stats_cases(ER, EA))
-    for f in ("egnn_golden.npz", "diffusion_golden.npz", "aux_golden.npz", "stats_golden.npz"):
+    for f in ("egnn_golden.npz", "diffusion_golden.npz", "aux_golden.npz", "stats_golden.npz", "learned_legacy_golden.npz"):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 
 

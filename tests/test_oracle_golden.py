@@ -198,3 +198,53 @@ def test_statistics_hand_geometries():
     sel = aux_ref.select_si_o_si(torch.tensor([[0.0, 0, 0], [1.6, 0, 0], [-1.6, 0.1, 0], [3.0, 0, 0]]),
                                  torch.tensor([[1, 0], [0, 1], [0, 1], [1, 0]]))
     assert sel is not None and sel.shape == (3, 3)
+
+
+G_LL = load_golden("learned_legacy_golden.npz")
+
+
+def test_learned_schedule_steps_match_executed_reference():
+    """diffusion_x_h.E3DiffusionProcess(..., noise_schedule='learned') (:27-30, :36-46, :61-90) executed by
+    make_golden.py: gamma grid -> alpha / sigma tables -> calculate_mu / reverse step / forward noising."""
+    sd = {k[len("learned.W."):]: torch.from_numpy(G_LL[k]) for k in G_LL.files if k.startswith("learned.W.")}
+    T = G_LL["learned.alpha"].shape[0] - 1
+    gam = aux_ref.gamma_forward(sd, torch.linspace(0, 1, T + 1).view(T + 1, 1))
+    assert max_rel(gam, torch.from_numpy(G_LL["learned.gamma"])) <= 1e-6
+    ref = diffusion_ref.DiffusionRef(0.0, 0.0, T, gamma_table=torch.from_numpy(G_LL["learned.gamma"]))
+    assert max_rel(ref.alpha_schedule, torch.from_numpy(G_LL["learned.alpha"])) <= 1e-6
+    assert max_rel(ref.sigma_schedule, torch.from_numpy(G_LL["learned.sigma"])) <= 1e-6
+    z3, e3, z2, e2 = (torch.from_numpy(G_LL[f"learned.{k}"]) for k in ("z3", "e3", "z2", "e2"))
+    for t in [int(v) for v in G_LL["learned.ts"]]:
+        assert max_rel(ref.calculate_mu(z3, e3, t), torch.from_numpy(G_LL[f"learned.mu3.t{t}"])) <= 1e-5
+        assert max_rel(ref.calculate_mu(z2, e2, t), torch.from_numpy(G_LL[f"learned.mu2.t{t}"])) <= 1e-5
+        for mode, z, e in (("pos", z3, e3), ("h", z2, e2)):
+            nz = torch.from_numpy(G_LL[f"learned.noise_{mode}.t{t}"])
+            assert max_rel(ref.reverse_diffuse_one_step(z, e, t, nz, mode), torch.from_numpy(G_LL[f"learned.rev_{mode}.t{t}"])) <= 1e-5
+            fz = torch.from_numpy(G_LL[f"learned.fwd_noise_{mode}.t{t}"])
+            assert max_rel(ref.diffuse_zero_to_t(z, t, fz, mode)[0], torch.from_numpy(G_LL[f"learned.fwd_{mode}.t{t}"])) <= 1e-5
+
+
+def test_legacy_process_matches_executed_reference():
+    """E3diffusion.py:9-120 executed by make_golden.py: beta-schedule class and polynomial variant."""
+    ib, fb, T = float(G_LL["legacy.params"][0]), float(G_LL["legacy.params"][1]), int(G_LL["legacy.params"][2])
+    z3, e3 = torch.from_numpy(G_LL["legacy.z3"]), torch.from_numpy(G_LL["legacy.e3"])
+    for fn in ("sigmoid", "linear"):
+        ref = diffusion_ref.LegacyRef(ib, fb, T, fn)
+        for t in [int(v) for v in G_LL["legacy.ts"]]:
+            mu = ref.calculate_mu(z3, e3, t)
+            assert max_rel(mu, torch.from_numpy(G_LL[f"legacy.{fn}.mu.t{t}"])) <= 1e-6
+            nz = torch.from_numpy(G_LL[f"legacy.{fn}.noise.t{t}"])
+            assert max_rel(ref.reverse_diffuse_one_step(mu, t, nz), torch.from_numpy(G_LL[f"legacy.{fn}.rev.t{t}"])) <= 1e-6
+            # forward noising: the golden holds the (mean-removed) noise the reference used
+            used = torch.from_numpy(G_LL[f"legacy.{fn}.fwd_used.t{t}"])
+            want = torch.from_numpy(G_LL[f"legacy.{fn}.fwd.t{t}"])
+            assert max_rel(ref.alpha_bar_schedule[t] * z3 + ref.beta_schedule[t] * used, want) <= 1e-6
+    ref = diffusion_ref.LegacyRef(ib, fb, T)
+    for t in [int(v) for v in G_LL["legacy.ts"]]:
+        mu = ref.mu_calculate(z3, e3, t)
+        assert max_rel(mu, torch.from_numpy(G_LL[f"legacy.poly.mu.t{t}"])) <= 1e-6
+        nz = torch.from_numpy(G_LL[f"legacy.poly.noise.t{t}"])
+        assert max_rel(ref.reverse_onestep(mu, t, nz), torch.from_numpy(G_LL[f"legacy.poly.rev.t{t}"])) <= 1e-6
+        used = torch.from_numpy(G_LL[f"legacy.poly.fwd_used.t{t}"])
+        alpha = diffusion_ref.polynomial_schedule_legacy(T, s=1e-4)
+        assert max_rel(alpha[t] * z3 + torch.sqrt(1 - alpha[t] ** 2) * used, torch.from_numpy(G_LL[f"legacy.poly.fwd.t{t}"])) <= 1e-6
