@@ -23,6 +23,19 @@ def test_learned_schedule_steps_match_reference_golden():
     T = G_LL["learned.alpha"].shape[0] - 1
     proc = dma.E3DiffusionProcess(1e-5, 2.0, T, noise_schedule="learned")
     proc.gamma.load_state_dict({k[len("learned.W."):]: torch.from_numpy(G_LL[k]) for k in G_LL.files if k.startswith("learned.W.")})
+    # (1) GammaNetwork from the reference's weights.  gamma(t) = g0 + (g1 - g0) (gt(t) - gt(0)) / (gt(1) - gt(0)) with
+    # 1024-term fp32 sums in gt: torch's own CPU kernels move the result by 5e-4 absolute with the thread count (measured
+    # in the build container: 8 threads reproduce the golden bit for bit, 1 or 2 threads differ by 4.6e-4), i.e. the
+    # reference does not reproduce itself more closely than that across hosts; alpha = sqrt(sigmoid(-gamma)) follows
+    # at half that in relative terms.
+    with torch.no_grad():
+        gam = proc.gamma_schedule().reshape(-1).cpu()
+    assert float((gam - torch.from_numpy(G_LL["learned.gamma"]).reshape(-1)).abs().max()) <= 2e-3
+    a = torch.stack([proc.alpha(t) for t in range(T + 1)])
+    assert max_rel(a, torch.from_numpy(G_LL["learned.alpha"])) <= 1e-3
+    # (2) the step arithmetic on the schedule the reference evaluated (its gamma grid), 1e-6 / 1e-5
+    proc.gamma_schedule = lambda: torch.from_numpy(G_LL["learned.gamma"]).clone()
+    proc._gamma_sig = None
     a = torch.stack([proc.alpha(t) for t in range(T + 1)])
     s = torch.stack([proc.sigma(t) for t in range(T + 1)])
     assert max_rel(a, torch.from_numpy(G_LL["learned.alpha"])) <= 1e-6
@@ -38,9 +51,10 @@ def test_learned_schedule_steps_match_reference_golden():
             got, _ = proc.diffuse_zero_to_t(z, t, mode=mode, noise=f(f"fwd_noise_{mode}").to(DEV))
             assert max_rel(got.cpu(), f(f"fwd_{mode}")) <= 1e-5
     # a parameter update re-tabulates the schedule (the table is cached per parameter version)
+    del proc.gamma_schedule
     with torch.no_grad():
         proc.gamma.gamma_1.add_(1.0)
-    assert float(proc.alpha(T)) < float(G_LL["learned.alpha"][T])
+    assert float(proc.alpha(T)) < 0.99 * float(G_LL["learned.alpha"][T])
 
 
 def test_legacy_process_matches_reference_golden():
@@ -178,7 +192,7 @@ def test_config0_toy_graphs_end_to_end():
                                   noise_h=nh.to(DEV), num_graphs=4)
     loss, _, _ = dma.training_loss(net, ei.to(DEV), batch.to(DEV), noised, None, A, num_graphs=4)
     loss.backward()
-    assert abs(float(loss) - float(loss_ref)) <= 1e-4 * abs(float(loss_ref))
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 1e-4 * abs(float(loss_ref.detach()))
     for k, p_ in net.named_parameters():
         gref = params[k].grad
         assert rel_err(p_.grad.cpu(), gref) <= 2e-3 or float(gref.abs().max()) < 1e-8, k

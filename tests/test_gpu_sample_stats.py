@@ -36,7 +36,7 @@ def _net(precision):
 
 
 # bf16: MFMA operands of the edge and node MLPs rounded to 8 significant bits in each of the 51 chained evaluations; the
-# trained denoiser contracts perturbations, so the final structure stays close: 3e-2 relative on positions (measured 4e-3)
+# trained denoiser contracts perturbations, so the final structure stays close: 3e-2 relative on positions and continuous types (measured 9.5e-3, no type flips)
 @pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 3e-2)])
 def test_full_chain_same_noise_matches_oracle(precision, tol):
     net, sd, A, T, proc = _net(precision)
