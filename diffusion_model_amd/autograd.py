@@ -206,8 +206,19 @@ class _EGNNFunction(torch.autograd.Function):
                 bool(L.egcl_backward_fused_supported(c.handle))):
             Epad = _round_up(E, 64)
             need = len(layers) * Epad * (2 * Wx + Wm + M) * 2
-            if need < 0.5 * torch.cuda.mem_get_info(hc.device)[0]:
+            # decided ONCE per (edge count, widths) on the context: "free" = what the driver reports plus what the caching
+            # allocator holds reserved but unallocated (after the first step the kept buffers sit there), so the path does
+            # not flip between steps or between ranks that share a device
+            key = (Epad, len(layers), Wx, Wm, M)
+            cache = getattr(c, "_keep_decision", None)
+            if cache is None or cache[0] != key:
+                free = torch.cuda.mem_get_info(hc.device)[0] + (torch.cuda.memory_reserved(hc.device) -
+                                                                torch.cuda.memory_allocated(hc.device))
+                cache = (key, need < 0.5 * free)
+                c._keep_decision = cache
+            if cache[1]:
                 kept = []
+            c.last_backward_path = "kept activations" if cache[1] else "recompute"
         for l in range(len(layers)):
             ho, xo = torch.empty_like(hc), torch.empty_like(xc)
             if kept is not None:
@@ -237,6 +248,8 @@ class _EGNNFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gh, gx):
         layers, plan, prec = ctx.layers, ctx.plan, ctx.prec
+        if prec == _lib.PREC_BF16X3:   # forward on the split-operand kernels; the backward chain is the fp32 one
+            prec = _lib.PREC_F32
         scope_graph = ctx.scope == _lib.NORM_GRAPH
         saved = ctx.saved_tensors
         dst32, src32 = plan.edge_dst, plan.edge_src

@@ -53,6 +53,9 @@ struct LayerPack {
   float* sc = nullptr;       // [w1catT_s | b1cat_s | wdx_s | wdm_s | b2x_s | w3x_s | b2m_s | wa_s]
   void* w2x_bf16s = nullptr;
   void* w2m_bf16s = nullptr;
+  void* w2x_bf16s_lo = nullptr;   // bf16 remainders of the scaled second-layer weights (precision bf16x3)
+  void* w2m_bf16s_lo = nullptr;
+  void* w2x_bf16s16 = nullptr;  // mlp_x.2 scaled, as v_mfma_f32_16x16x32_bf16 B fragments [N/16][K/32][64][8]
   void* w2xT_bf16 = nullptr;  // mlp_x.2 TRANSPOSED bf16 fragments for the backward dgrad (k = output n, column = hidden k)
   void* w2mT_bf16 = nullptr;  // mlp_m.2 transposed (K = MP, N = WmP)
   void* w1hl_bf16 = nullptr;  // scaled first layers as bf16 hi/lo B fragments [TC/32][3][hi|lo][64][8] (node_pre_hilo_kernel)

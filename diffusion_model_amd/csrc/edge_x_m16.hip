@@ -1,0 +1,222 @@
+// Coordinate edge kernel on v_mfma_f32_16x16x32_bf16 (gfx950): the SAME workgroup tile as edge_kernel_bf16_v3<2, false>
+// (128 edges x 512 columns of mlp_x.2, EquivariantGraphNeuralNetwork.py:19-25, :62-65; 8 waves, 128 rows x 64 columns per
+// wave, 64-deep activation chunks, phase-opposed SIMD partners, weight fragments streamed from L2), with the matrix
+// instruction's shape changed.  Why build it: the coordinate kernel runs against the power limit (held clock 1.9-2.1 GHz),
+// and on random data the chip holds a higher clock on the 16x16x32 shape than on 32x32x16 at about equal cycles per FLOP
+// (MI355X_MICROARCH.md "DVFS give-back" item 7, cdna_hip_programming.md rule 28: "build both at the same output tile per
+// wave and keep the faster by wall").  What changes with the shape:
+//   * operands: lane l holds A[row l & 15][k = 8 (l >> 4) + j], B[k = 8 (l >> 4) + j][col l & 15]: a k-step is 32 deep,
+//     8 row blocks x 4 column blocks of 16 per wave, 32 MFMAs of 16 cycles per k-step, 128 accumulator registers as before;
+//   * LDS activation image: [8 k-groups][128 rows][16 B] with the row's low three bits XORed by the k-group -- the 8 lanes
+//     that write one row's eight 16-byte pieces hit eight different slots of the 128-B store bank row, and every 16-lane
+//     group of an operand ds_read_b128 (rows 0-3 and 12-15 of one k-group + rows 4-11 of the next) reads 16 different
+//     slots of the 256-B load bank row (no padding: 16 KiB per chunk);
+//   * weight fragments packed [16-column block][32-deep k-step][lane][8 bf16] (pack_frags_bf16_n16);
+//   * the row sums of the head s = w3 . SiLU(a2) + b3 run over the 16 lanes of a DPP row (tile128::butterfly16).
+// Prologue and segment sums are the shared ones of edge_tile.h.
+#include "edge_tile.h"
+
+namespace egnn {
+
+namespace {
+
+using namespace tile128;
+constexpr int kT = 512;
+constexpr int kKC = 64;                       // activation chunk depth
+constexpr size_t kA1 = (size_t)8 * kR * 16;   // one activation chunk: [8 k-groups][128 rows][8 bf16], XOR-swizzled rows
+__host__ __device__ inline size_t x16_smem_bytes(int KP) { return kOffLoop + 2 * kA1 + (size_t)KP * 4; }
+
+typedef __attribute__((ext_vector_type(4))) float f32x4v;
+
+__global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const Lds L(smem);
+  char* s_a1 = smem + kOffLoop;
+  float* s_wd = reinterpret_cast<float*>(s_a1 + 2 * kA1);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r15 = lane & 15, q4 = lane >> 4;
+  const int KP = p.WxP;
+  const int nsplit = p.WxP / 512;
+  const int j = xcd_tile(blockIdx.x, gridDim.x);
+  const int tile = j / nsplit, half = j - tile * nsplit;
+  const int e0 = tile * kR;
+  const int nvalid = min(kR, p.E - e0);
+
+  const int S = prologue(p, L, e0, nvalid, p.wdx, KP, s_wd, tid, lane, wave);
+
+  // ---- K loop ----
+  const int NC = KP / kKC, KS = KP / 32;
+  const int brow = tid >> 3, kg = tid & 7;   // this thread builds rows brow and brow + 64, columns 8 kg .. 8 kg + 7 of a chunk
+  const rsrc_t rs_tab = make_rsrc(p.table, (p.dbg & 2) ? 0u : (unsigned)((size_t)p.N * p.TC * 2));
+  const rsrc_t rs_w = make_rsrc(p.w2x, (p.dbg & 1) ? 0u : (unsigned)((size_t)p.WxP * KP * 2));
+  const unsigned vdst0 = (unsigned)L.dst[brow] * (unsigned)p.TC * 2u + (unsigned)kg * 16u;
+  const unsigned vsrc0 = (unsigned)L.src[brow] * (unsigned)p.TC * 2u + (unsigned)kg * 16u;
+  const unsigned vdst1 = (unsigned)L.dst[brow + 64] * (unsigned)p.TC * 2u + (unsigned)kg * 16u;
+  const unsigned vsrc1 = (unsigned)L.src[brow + 64] * (unsigned)p.TC * 2u + (unsigned)kg * 16u;
+  const float d2r0 = L.d2[brow], d2r1 = L.d2[brow + 64];
+  const unsigned offP = 0u, offQ = (unsigned)p.WxP * 2u;   // fp16 table: {Px | Qx | Pm | Qm}
+  char* slot0 = s_a1 + (size_t)kg * (kR * 16) + (size_t)(brow ^ kg) * 16;
+  char* slot1 = slot0 + 64 * 16;
+  const unsigned lane16 = lane * 16u;
+  // LDS byte address of this lane's operand piece in buffer 0 for the two k-steps of a chunk (k-groups q4 and 4 + q4)
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)s_a1;
+  const unsigned abase0 = lds0 + (unsigned)q4 * (kR * 16) + (unsigned)(r15 ^ q4) * 16u;
+  const unsigned abase1 = lds0 + (unsigned)(4 + q4) * (kR * 16) + (unsigned)(r15 ^ (4 + q4)) * 16u;
+  const int cb0 = half * 32 + wave * 4;       // first 16-column block of this wave
+  const unsigned w0 = (unsigned)cb0 * KS * 1024u;
+
+  f32x4v acc[8][4];
+#pragma unroll
+  for (int rb = 0; rb < 8; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[rb][cb][i] = 0.f;
+
+  {  // chunk 0
+    UnitH u;
+    unith_load(u, rs_tab, vdst0, vsrc0, offP, offQ);
+    unith_finish(u, s_wd + kg * 8, d2r0, slot0);
+    unith_load(u, rs_tab, vdst1, vsrc1, offP, offQ);
+    unith_finish(u, s_wd + kg * 8, d2r1, slot1);
+  }
+  bf16x8 bq[2][4];   // weight fragments of the 2 k-steps of the current chunk
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) bq[s][cb] = ldbuf_bf16x8(rs_w, lane16, w0 + ((unsigned)cb * KS + s) * 1024u);
+  __syncthreads();
+
+  // matrix phase of chunk c: 2 k-steps x (8 row blocks x 4 column blocks).  Operand pipeline as in edge_bf16_v3.hip: the
+  // A pieces by inline-asm ds_read_b128 (hipcc sinks compiler-visible LDS reads to their use) through a ring of 4 register
+  // sets, each refilled in place for the use 4 row blocks later right after its MFMAs were issued; LDS returns in order,
+  // so lgkmcnt(3) before a use means "all but the 3 younger reads have landed".  The weight fragments of k-step s of chunk c + 1 are requested after the MFMAs of
+  // k-step s of chunk c (a whole chunk of distance).
+  auto mphase = [&](const int c, const bool last) {
+    const unsigned boff = (unsigned)(c & 1) * (unsigned)kA1;
+    const unsigned ab0 = abase0 + boff, ab1 = abase1 + boff;
+    bf16x8 a[4];   // ring of 4 operand pieces: use u = 8 s + rb takes a[u & 3], which is refilled for use u + 4 right after
+#define LDS_RD(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(off))
+#define LDS_WAIT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
+    LDS_RD(a[0], ab0, 0); LDS_RD(a[1], ab0, 256); LDS_RD(a[2], ab0, 512); LDS_RD(a[3], ab0, 768);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int rb = 0; rb < 8; ++rb) {
+        const int u = 8 * s + rb;
+        if (u <= 12) LDS_WAIT(3);
+        else if (u == 13) LDS_WAIT(2);
+        else if (u == 14) LDS_WAIT(1);
+        else LDS_WAIT(0);
+        asm volatile("" : "+v"(a[u & 3]));   // uses of the piece stay below the wait
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+          acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u & 3], bq[s][cb], acc[rb][cb], 0, 0, 0);
+        // refill in place for use u + 4 (the MFMAs above have read the registers at issue)
+        if (u == 0) LDS_RD(a[0], ab0, 1024); if (u == 1) LDS_RD(a[1], ab0, 1280); if (u == 2) LDS_RD(a[2], ab0, 1536);
+        if (u == 3) LDS_RD(a[3], ab0, 1792); if (u == 4) LDS_RD(a[0], ab1, 0); if (u == 5) LDS_RD(a[1], ab1, 256);
+        if (u == 6) LDS_RD(a[2], ab1, 512); if (u == 7) LDS_RD(a[3], ab1, 768); if (u == 8) LDS_RD(a[0], ab1, 1024);
+        if (u == 9) LDS_RD(a[1], ab1, 1280); if (u == 10) LDS_RD(a[2], ab1, 1536); if (u == 11) LDS_RD(a[3], ab1, 1792);
+      }
+      if (!last) {
+        const unsigned ksn = (unsigned)((c + 1) * 2 + s) * 1024u;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) bq[s][cb] = ldbuf_bf16x8(rs_w, lane16, w0 + (unsigned)cb * KS * 1024u + ksn);
+      }
+    }
+#undef LDS_WAIT
+#undef LDS_RD
+  };
+  UnitH ua0, ua1;
+  auto vload = [&](const int cq) {   // table rows for the activations of chunk cq (clamped: a harmless repeat at the end)
+    const int c = cq < NC ? cq : NC - 1;
+    const unsigned kb = (unsigned)c * kKC * 2u;
+    unith_load(ua0, rs_tab, vdst0, vsrc0, offP + kb, offQ + kb);
+    unith_load(ua1, rs_tab, vdst1, vsrc1, offP + kb, offQ + kb);
+  };
+  auto vfinish = [&](const int c) {  // SiLU + bf16 pack of chunk c into its LDS buffer
+    const size_t nbuf = (size_t)(c & 1) * kA1;
+    __builtin_amdgcn_s_setprio(3);   // vector work wins issue arbitration over the partner wave's MFMAs
+    unith_finish(ua0, s_wd + c * kKC + kg * 8, d2r0, slot0 + nbuf);
+    unith_finish(ua1, s_wd + c * kKC + kg * 8, d2r1, slot1 + nbuf);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // SIMD partners (waves w and w + 4) in opposite phase, one barrier per chunk (edge_bf16_v3.hip)
+  vload(1);
+  if (wave < 4) {
+    for (int i = 0; i < NC - 1; ++i) {
+      mphase(i, false);
+      vfinish(i + 1);
+      vload(i + 2);
+      __syncthreads();
+    }
+  } else {
+    for (int i = 0; i < NC - 1; ++i) {
+      vfinish(i + 1);
+      vload(i + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mphase(i, false);
+      __syncthreads();
+    }
+  }
+  mphase(NC - 1, true);
+  __syncthreads();
+
+  // ---- epilogue: s[row] = [b3] + sum_n w3[n] * SiLU(a2[row][n] + b2[n]) over this workgroup's 512 columns ----
+  // accumulator layout of the 16x16 tile: column = lane & 15, row = 4 (lane >> 4) + register
+  float part[32];
+#pragma unroll
+  for (int v = 0; v < 32; ++v) part[v] = 0.f;
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) {
+    const int n = 16 * (cb0 + cb) + r15;
+    const float bb = p.b2x[n], w = p.w3x[n];
+#pragma unroll
+    for (int rb = 0; rb < 8; ++rb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) part[rb * 4 + i] = fmaf(w, silu_s(fmaf(acc[rb][cb][i], kNegLog2e, bb)), part[rb * 4 + i]);
+  }
+  {
+    float t0, t1;
+    butterfly16(part, lane, t0, t1);   // value indices 2 m, 2 m + 1 (m = lane & 15): row block m >> 1, register 2 (m & 1) + {0, 1}
+    const int row = 16 * (r15 >> 1) + 4 * q4 + 2 * (r15 & 1);
+    L.part[wave * kR + row] = t0;
+    L.part[wave * kR + row + 1] = t1;
+  }
+  __syncthreads();
+  if (tid < kR) {
+    float v = half == 0 ? p.scal[0] : 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) v += L.part[w * kR + tid];
+    L.val[tid] = v;
+  }
+  __syncthreads();
+  coordinate_segment_sums(p, L, S, tile, half, tid, lane, wave);
+}
+
+}  // namespace
+
+int init_edge_x_m16_attributes() {
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_x_m16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               160 * 1024));
+  return EGNN_OK;
+}
+
+bool edge_x_m16_supported(const EdgeParams& p) {
+  return (p.WxP == 512 || p.WxP == 1024) && p.w2x16 != nullptr && x16_smem_bytes(p.WxP) <= 160 * 1024 &&
+         (size_t)p.N * p.TC * 2 < ((size_t)1 << 32);
+}
+
+// coordinate kernel only; p.w2x16 = mlp_x.2 packed by pack_frags_bf16_n16 (scaled by -1/log2(e))
+int launch_edge_x_m16(const EdgeParams& p, hipStream_t st) {
+  const int tiles = (p.E + kR - 1) / kR;
+  EdgeParams q = p;
+  q.w2x = p.w2x16;
+  hipLaunchKernelGGL(edge_x_m16_kernel, dim3(tiles * (p.WxP / 512)), dim3(kT), x16_smem_bytes(p.WxP), st, q);
+  EGNN_HIP(hipGetLastError());
+  return EGNN_OK;
+}
+
+}  // namespace egnn

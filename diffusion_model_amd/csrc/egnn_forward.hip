@@ -69,6 +69,34 @@ __global__ void pack_frags_bf16(const float* __restrict__ W, int Nout, int K, in
     out[i] = (__bf16)((n < Nout && k < K) ? W[(size_t)n * ldw + k] * scale : 0.f);
   }
 }
+// v_mfma_f32_16x16x32_bf16: lane l holds B[k = 32*ks + 8*(l>>4) + j][n = 16*nb + (l&15)], j = 0..7.
+// out[((nb*KS + ks)*64 + lane)*8 + j]
+__global__ void pack_frags_bf16_n16(const float* __restrict__ W, int Nout, int K, int ldw, int NP, int KP,
+                                    __bf16* __restrict__ out, float scale) {
+  const int KS = KP / 32;
+  const size_t total = (size_t)(NP / 16) * KS * 64 * 8;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int j = i & 7, lane = (i >> 3) & 63;
+    const size_t f = i >> 9;
+    const int ks = f % KS, nb = f / KS;
+    const int n = 16 * nb + (lane & 15), k = 32 * ks + 8 * (lane >> 4) + j;
+    out[i] = (__bf16)((n < Nout && k < K) ? W[(size_t)n * ldw + k] * scale : 0.f);
+  }
+}
+// bf16 remainder of the same fragments: out = bf16(v - bf16(v)), v = W * scale (precision bf16x3)
+__global__ void pack_frags_bf16_lo(const float* __restrict__ W, int Nout, int K, int ldw, int NP, int KP,
+                                   __bf16* __restrict__ out, float scale) {
+  const int KS = KP / 16;
+  const size_t total = (size_t)(NP / 32) * KS * 64 * 8;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int j = i & 7, lane = (i >> 3) & 63;
+    const size_t f = i >> 9;
+    const int ks = f % KS, nb = f / KS;
+    const int n = 32 * nb + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + j;
+    const float v = (n < Nout && k < K) ? W[(size_t)n * ldw + k] * scale : 0.f;
+    out[i] = (__bf16)(v - (float)(__bf16)v);
+  }
+}
 // mlp_h.2 as the A operand of out^T = W2h . hidden^T where hidden^T comes straight from an accumulator tile:
 // element j of lane half hh in k-step ks is hidden unit 32*(ks/2) + 16*(ks%2) + 8*(j>>2) + 4*hh + (j&3).
 __global__ void pack_frags_bf16_accperm(const float* __restrict__ W, int Nout, int K, int ldw, int NP, int KP,
@@ -969,6 +997,8 @@ int init_kernel_attributes() {
   if ((rc = init_edge_bf16_v4_attributes())) return rc;
   if ((rc = init_node_bf16_attributes())) return rc;
   if ((rc = init_edge_dgrad_attributes())) return rc;
+  if ((rc = init_edge_x_m16_attributes())) return rc;
+  if ((rc = init_edge_bf16x3_attributes())) return rc;
   done = true;
   return EGNN_OK;
 }
@@ -1011,6 +1041,8 @@ static void use_scaled_pack(egnn_ctx* c, int layer, EdgeParams& p, const float*&
   p.b2m = o; o += c->MP;
   p.wa = o;
   p.w2x = lp.w2x_bf16s; p.w2m = lp.w2m_bf16s;
+  p.w2x16 = lp.w2x_bf16s16;
+  p.w2x_lo = lp.w2x_bf16s_lo; p.w2m_lo = lp.w2m_bf16s_lo;
 }
 // first-layer table of the v3 / v4 kernels (fp16, pre-scaled) for node features h
 static int launch_node_pre_f16(egnn_ctx* c, hipStream_t st, int layer, const float* h, const float* w1catT,
@@ -1113,6 +1145,14 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
   fill_edge_params(c, layer, prec, x, p);
   static const int edge_sel = getenv("EGNN_EDGE") ? atoi(getenv("EGNN_EDGE")) : 4;   // A/B switch: 1, 2, 3 or 4
   int path = 1;
+  if (prec == EGNN_PREC_BF16X3) {   // split-operand kernels where the 128-edge tiling applies, else the exact fp32 path
+    EdgeParams q = p;
+    const float *w1c, *b1c;
+    use_scaled_pack(c, layer, q, w1c, b1c);
+    if (edge_bf16x3_supported(q)) path = 5;
+    else prec = EGNN_PREC_F32;
+    fill_edge_params(c, layer, prec, x, p);
+  }
   if (prec == EGNN_PREC_BF16 && edge_sel >= 4 && edge_bf16_v4_supported(p) && edge_bf16_v3_supported(p)) path = 4;
   else if (prec == EGNN_PREC_BF16 && edge_sel >= 3 && edge_bf16_v3_supported(p)) path = 3;
   else if (prec == EGNN_PREC_BF16 && edge_sel >= 2 && edge_bf16_v2_supported(p)) path = 2;
@@ -1124,7 +1164,15 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
   prof_begin(c, st, 1);
   {
     static const int pre_sel = getenv("EGNN_PRE") ? atoi(getenv("EGNN_PRE")) : 3;   // A/B switch
-    if (path >= 3) {   // the v3 / v4 edge kernels read a half-precision table
+    if (path == 5) {   // bf16x3: exact fp32 table of the scaled first layers
+      dim3 grid((N + kPre2Nodes - 1) / kPre2Nodes, (c->TC + kPre2Cols - 1) / kPre2Cols);
+      const size_t sm = (size_t)((c->H + 1) & ~1) * 33 * sizeof(float);
+      if (c->H <= 64)
+        hipLaunchKernelGGL(node_pre_mfma_kernel<float>, grid, dim3(kThreads), sm, st, h, N, c->H, w1catT, b1cat, c->TC, c->table);
+      else
+        hipLaunchKernelGGL(node_pre_kernel<float>, dim3((N + kPreNodes - 1) / kPreNodes, (c->TC + kThreads - 1) / kThreads),
+                           dim3(kThreads), (size_t)kPreNodes * c->H * sizeof(float), st, h, N, c->H, w1catT, b1cat, c->TC, c->table);
+    } else if (path >= 3) {   // the v3 / v4 edge kernels read a half-precision table
       int rc = launch_node_pre_f16(c, st, layer, h, w1catT, b1cat);
       if (rc) return rc;
     } else if (pre_sel >= 2 && c->H <= 64) {
@@ -1138,7 +1186,7 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
       hipLaunchKernelGGL(node_pre_kernel<float>, grid, dim3(kThreads), sm, st, h, N, c->H, w1catT, b1cat, c->TC,
                          c->table);
     }
-    if (path != 4) {   // the v4 edge kernels sum d^2 per receiving node themselves
+    if (path < 4) {   // the 128-edge-tile kernels sum d^2 per receiving node themselves
       hipLaunchKernelGGL(node_d2_kernel, dim3((N + 255) / 256), dim3(256), 0, st, x, c->row_ptr, c->edge_src, N,
                          c->node_d2);
       hipLaunchKernelGGL(graph_sum_kernel, dim3(per_graph ? c->B : 1), dim3(kThreads), 0, st, c->node_d2,
@@ -1153,7 +1201,11 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
     const size_t smem = edge_smem_bytes(R, c->MP);
     prof_begin(c, st, 0);
     int rc;
-    if (path == 4) {
+    if (path == 5) {
+      R = 128;
+      nsplit_x = p.WxP / 256;
+      rc = launch_edge_bf16x3(p, st);
+    } else if (path == 4) {
       R = edge_v4_rows();
       nsplit_x = p.WxP >= 512 ? p.WxP / 512 : 1;
       // coordinate kernels with the phase-opposed K loop of edge_bf16_v3.hip, message kernel with the in-wave pipeline
@@ -1168,7 +1220,12 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
       // layer is fewer workgroups than CUs (one 64-atom graph: 0.353 vs 0.323 ms per reverse step).
       static const int x4_sel = getenv("EGNN_X4") ? atoi(getenv("EGNN_X4")) : 0;
       const bool x4 = p.WxP >= 512 && !v4x && x4_sel > 0;
-      auto launch_x = [&](hipStream_t s) { return x4 ? launch_edge_bf16_v4_x1(p, s) : launch_edge_bf16_v3_x(p, s); };
+      // A/B switch: the coordinate kernel on v_mfma_f32_16x16x32_bf16 (edge_x_m16.hip), same workgroup tile
+      static const int xm16_sel = getenv("EGNN_XM16") ? atoi(getenv("EGNN_XM16")) : 0;
+      const bool xm16 = xm16_sel > 0 && !x4 && edge_x_m16_supported(p);
+      auto launch_x = [&](hipStream_t s) {
+        return x4 ? launch_edge_bf16_v4_x1(p, s) : (xm16 ? launch_edge_x_m16(p, s) : launch_edge_bf16_v3_x(p, s));
+      };
       if (x4) nsplit_x = p.WxP / 256;
       if (c->save_s1x) {   // training forward (egcl_forward_save): the same kernels, which also store what the backward needs
         nsplit_x = p.WxP >= 512 ? p.WxP / 512 : 1;
@@ -1201,7 +1258,7 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
 
   c->last_R = R; c->last_nsplit_x = nsplit_x;
   c->sq_from_agg = false;
-  if (path == 4) {
+  if (path >= 4) {
     if (E == 0) {
       EGNN_HIP(hipMemsetAsync(c->gscale, 0, sizeof(float) * (per_graph ? c->B : 1), st));
     } else if (!per_graph || need_gscale) {
@@ -1295,7 +1352,7 @@ int egnn_create(egnn_ctx** out, int device) {
 static void free_layer(LayerPack& lp) {
   void* ptrs[] = {lp.w1catT, lp.b1cat, lp.wdx, lp.wdm, lp.w2x_f32, lp.w2x_bf16, lp.b2x, lp.w3x, lp.w2m_f32,
                   lp.w2m_bf16, lp.b2m, lp.wa, lp.scal, lp.w1h_f32, lp.b1h, lp.w2h_f32, lp.b2h, lp.sc, lp.w2x_bf16s, lp.w2m_bf16s, lp.w1h_bf16, lp.w2h_bf16p,
-                  lp.w2xT_bf16, lp.w2mT_bf16, lp.w1hl_bf16};
+                  lp.w2xT_bf16, lp.w2mT_bf16, lp.w1hl_bf16, lp.w2x_bf16s16, lp.w2x_bf16s_lo, lp.w2m_bf16s_lo};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   lp = LayerPack();
@@ -1399,6 +1456,12 @@ int egnn_pack_layer(egnn_ctx* c, void* stream, int l, const float* m0_w, const f
     if ((rc = dev_alloc(&tmp, (size_t)MP * WmP))) return rc;
     lp.w2m_bf16s = tmp; tmp = nullptr;
     if ((rc = dev_alloc(&tmp, (size_t)WxP * WxP))) return rc;
+    lp.w2x_bf16s16 = tmp; tmp = nullptr;
+    if ((rc = dev_alloc(&tmp, (size_t)WxP * WxP))) return rc;
+    lp.w2x_bf16s_lo = tmp; tmp = nullptr;
+    if ((rc = dev_alloc(&tmp, (size_t)MP * WmP))) return rc;
+    lp.w2m_bf16s_lo = tmp; tmp = nullptr;
+    if ((rc = dev_alloc(&tmp, (size_t)WxP * WxP))) return rc;
     lp.w2xT_bf16 = tmp; tmp = nullptr;
     if ((rc = dev_alloc(&tmp, (size_t)MP * WmP))) return rc;
     lp.w2mT_bf16 = tmp; tmp = nullptr;
@@ -1437,6 +1500,9 @@ int egnn_pack_layer(egnn_ctx* c, void* stream, int l, const float* m0_w, const f
     hipLaunchKernelGGL(scale_copy, dim3(8), b, 0, st, lp.wa, (size_t)MP, s2, o);
     hipLaunchKernelGGL(pack_frags_bf16, g, b, 0, st, x2_w, Wx, Wx, Wx, WxP, WxP, reinterpret_cast<__bf16*>(lp.w2x_bf16s), s2);
     hipLaunchKernelGGL(pack_frags_bf16, g, b, 0, st, m2_w, M, Wm, Wm, MP, WmP, reinterpret_cast<__bf16*>(lp.w2m_bf16s), s2);
+    hipLaunchKernelGGL(pack_frags_bf16_n16, g, b, 0, st, x2_w, Wx, Wx, Wx, WxP, WxP, reinterpret_cast<__bf16*>(lp.w2x_bf16s16), s2);
+    hipLaunchKernelGGL(pack_frags_bf16_lo, g, b, 0, st, x2_w, Wx, Wx, Wx, WxP, WxP, reinterpret_cast<__bf16*>(lp.w2x_bf16s_lo), s2);
+    hipLaunchKernelGGL(pack_frags_bf16_lo, g, b, 0, st, m2_w, M, Wm, Wm, MP, WmP, reinterpret_cast<__bf16*>(lp.w2m_bf16s_lo), s2);
     hipLaunchKernelGGL(pack_frags_bf16, g, b, 0, st, h0_w, Wh, H + M, H + M, WhP, c->K1Q, reinterpret_cast<__bf16*>(lp.w1h_bf16), 1.0f);
     hipLaunchKernelGGL(pack_frags_bf16_accperm, g, b, 0, st, h2_w, H, Wh, Wh, HP, WhP, reinterpret_cast<__bf16*>(lp.w2h_bf16p));
     if (H <= 48)   // hi/lo bf16 fragments of the scaled first-layer weights (node_pre_hilo_kernel)
@@ -1467,7 +1533,7 @@ int egnn_set_graph(egnn_ctx* c, int N, int E, int B, const int32_t* edge_dst, co
 
 static int check_ready(egnn_ctx* c, int prec, int norm_scope) {
   if (!c || c->L == 0 || c->N == 0) { set_error("model/graph not set"); return EGNN_ESTATE; }
-  if (prec != EGNN_PREC_F32 && prec != EGNN_PREC_BF16) { set_error("bad precision %d", prec); return EGNN_EINVAL; }
+  if (prec != EGNN_PREC_F32 && prec != EGNN_PREC_BF16 && prec != EGNN_PREC_BF16X3) { set_error("bad precision %d", prec); return EGNN_EINVAL; }
   if (norm_scope != EGNN_NORM_CALL && norm_scope != EGNN_NORM_GRAPH) { set_error("bad norm scope"); return EGNN_EINVAL; }
   return EGNN_OK;
 }

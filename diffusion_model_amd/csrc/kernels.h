@@ -40,6 +40,8 @@ struct EdgeParams {
   int TC, WxP, WmP, MP, cbx, cbm;
   const float *wdx, *wdm, *b2x, *w3x, *b2m, *wa, *scal;
   const void *w2x, *w2m;
+  const void *w2x_lo, *w2m_lo;   // bf16 remainders W - bf16(W) of the scaled second-layer weights, same fragment layout (bf16x3)
+  const void* w2x16;   // mlp_x.2 as 16x16x32 B fragments (edge_x_m16.hip), scaled; null when not packed
   float *agg_m, *agg_x, *part_m, *part_x;
   size_t agg_x_stride, part_x_stride;  // elements between the column-split copies of agg_x / part_x
   unsigned long long* stamps;  // diagnostic builds only (EGNN_EXP_STAMP): s_memtime stamps of one workgroup
@@ -292,5 +294,11 @@ int init_edge_bf16_v4_attributes();
 int init_edge_bf16_v2_attributes();
 int init_edge_bf16_v3_attributes();
 bool edge_bf16_v2_supported(const EdgeParams& p);
+int launch_edge_x_m16(const EdgeParams& p, hipStream_t st);   // coordinate kernel on v_mfma_f32_16x16x32_bf16
+bool edge_x_m16_supported(const EdgeParams& p);
+int init_edge_x_m16_attributes();
+int launch_edge_bf16x3(const EdgeParams& p, hipStream_t st);    // precision 'bf16x3': head / remainder split operands
+bool edge_bf16x3_supported(const EdgeParams& p);
+int init_edge_bf16x3_attributes();
 
 }  // namespace egnn

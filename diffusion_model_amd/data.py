@@ -93,9 +93,23 @@ class Batch(GraphData):
     ``sizes`` (host list), ``num_graphs``, ``id`` (list).  ``fully_connected`` says every graph carries all ordered
     pairs, in which case ``plan()`` builds the CSR on the device."""
 
+    def to(self, device) -> "Batch":
+        """copy on ``device``; the cached graph plan (device arrays of the OLD device) is not carried over: ``plan()``
+        rebuilds it where the batch now lives"""
+        out = super().to(device)
+        out._plan = None
+        return out
+
+    def clone(self) -> "Batch":
+        out = super().clone()
+        out._plan = None          # a plan is not shared between copies
+        return out
+
     def plan(self):
         from .graph import GraphPlan, fully_connected_plan
         cached = getattr(self, "_plan", None)
+        if cached is not None and cached.edge_dst.device != self.pos.device:
+            cached = None         # built for another device
         if cached is None:
             dev = self.pos.device
             if self.fully_connected and dev.type == "cuda":
@@ -196,18 +210,41 @@ class GraphLoader:
     ``drop_last=False``).  Under data parallelism (``world_size`` > 1) every rank draws the SAME permutation (seeded
     ``generator``) and takes the batches ``rank, rank + world_size, ...`` -- graphs are partitioned across ranks with no
     data-path communication (BASELINE configs[3]); ranks are padded to an equal number of steps by wrapping around, as
-    ``torch.utils.data.DistributedSampler`` does, so that every rank joins every gradient all-reduce."""
+    ``torch.utils.data.DistributedSampler`` does, so that every rank joins every gradient all-reduce.
+
+    The permutation of a shuffled multi-rank loader comes from ``seed`` and the epoch number (``set_epoch``; the epoch
+    advances by itself after every pass), never from a process-global RNG: with each rank drawing its own permutation an
+    epoch would silently duplicate and drop records.  A caller-made ``generator`` is accepted with ``world_size`` > 1 only
+    together with ``seed`` left None AND is then required to be seeded identically on every rank (documented contract;
+    prefer ``seed``)."""
 
     def __init__(self, dataset: Sequence[GraphData], batch_size: int = 1, shuffle: bool = False,
                  generator: Optional[torch.Generator] = None, drop_last: bool = False, device=None, rank: int = 0,
-                 world_size: int = 1):
+                 world_size: int = 1, seed: Optional[int] = None):
         if batch_size < 1:
             raise ValueError("batch_size must be positive")
         if not (0 <= rank < world_size):
             raise ValueError("rank must be in [0, world_size)")
+        if shuffle and world_size > 1 and generator is None and seed is None:
+            raise ValueError("a shuffled loader over several ranks needs `seed=` (or an identically seeded generator on every "
+                             "rank): every rank must draw the same permutation")
         self.dataset, self.batch_size, self.shuffle = dataset, int(batch_size), bool(shuffle)
         self.generator, self.drop_last, self.device = generator, bool(drop_last), device
         self.rank, self.world_size = int(rank), int(world_size)
+        self.seed, self.epoch = seed, 0
+
+    def set_epoch(self, epoch: int) -> None:
+        """epoch number mixed into the seeded permutation (as DistributedSampler.set_epoch)"""
+        self.epoch = int(epoch)
+
+    def _order(self, n: int):
+        if not self.shuffle:
+            return list(range(n))
+        if self.seed is not None:
+            g = torch.Generator().manual_seed(int(self.seed) * 1000003 + self.epoch)
+            self.epoch += 1
+            return torch.randperm(n, generator=g).tolist()
+        return torch.randperm(n, generator=self.generator).tolist()
 
     def _num_global_batches(self) -> int:
         n = len(self.dataset)
@@ -219,7 +256,7 @@ class GraphLoader:
 
     def __iter__(self) -> Iterator[Batch]:
         n = len(self.dataset)
-        order = torch.randperm(n, generator=self.generator).tolist() if self.shuffle else list(range(n))
+        order = self._order(n)
         nb = self._num_global_batches()
         if nb == 0:
             return

@@ -98,12 +98,56 @@ class GradAllReducer:
         self._done, self._pending, self._armed = set(), [], True
         autograd.ACTIVE_REDUCER = self
 
+    def disarm(self):
+        """drop the backward hook and wait for whatever was started (also the error path of ``armed()``): nothing of this
+        step is left for a later backward to trip over"""
+        from . import autograd
+        if autograd.ACTIVE_REDUCER is self:
+            autograd.ACTIVE_REDUCER = None
+        self._armed = False
+        try:
+            self.sync()
+        finally:
+            self._done, self._pending = set(), []
+
+    def armed(self):
+        """``with reducer.armed(): loss.backward()`` == arm() ... finish(), and on an exception inside the block the hook
+        is removed and the started exchanges are drained, so that a later backward on the same layers (e.g. a one-rank
+        validation pass with gradients) does not issue collectives the other ranks never join."""
+        red = self
+
+        class _Armed:
+            def __enter__(self):
+                red.arm()
+                return red
+
+            def __exit__(self, exc_type, exc, tb):
+                if exc_type is None:
+                    red.finish()
+                else:
+                    red.disarm()
+                return False
+        return _Armed()
+
+    def check_covers(self, optimizer):
+        """every trainable parameter the optimizer steps must belong to a bucket: a parameter left out (e.g. the learned
+        schedule's gamma_0 / gamma_1 when ``diffusion_process.gamma`` was not passed in ``modules``) would be stepped with
+        the LOCAL gradient and drift apart across ranks"""
+        have = {id(p) for ps in self.buckets for p in ps}
+        missing = [p for g in optimizer.param_groups for p in g["params"] if p.requires_grad and id(p) not in have]
+        if missing and self._active():
+            raise RuntimeError(f"{len(missing)} trainable parameter(s) of the optimizer are in no GradAllReducer bucket "
+                               f"(shapes {[tuple(p.shape) for p in missing[:4]]}...): add their modules to GradAllReducer(modules)")
+
     def layer_ready(self, module, grads):
         """grads: tensors (or None) aligned with the module's trainable parameters.  Starts the bucket's all-reduce
         and returns views of the reduced flat buffer in the same order (valid after ``sync()``)."""
         i = self.bucket_of.get(id(module))
         if i is None or not self._active():
             return grads
+        if i in self._done:
+            raise RuntimeError("GradAllReducer: a layer's gradients arrived twice in one armed step (two forward passes "
+                               "through the same layers before one backward?): use reduce() on .grad for that pattern")
         ps = self.buckets[i]
         flat = torch.cat([(g if g is not None else torch.zeros_like(p)).reshape(-1).float() for p, g in zip(ps, grads)])
         if self.stream is not None:
@@ -201,15 +245,20 @@ def train_step(nn_dict, data, params, diffusion_process, optimizer, reducer: Opt
         cols.append(data.exO.to(dev).float())
     cond = torch.cat(cols, dim=1) if cols else None
     nglob = global_graph_count(nb, dev) if num_graphs_global is None else int(num_graphs_global)
-    if reducer is not None:
-        reducer.arm()
     # a collated data.Batch brings its own device-built graph plan (no edge sort / host sync per step)
     topo = data.plan() if callable(getattr(data, "plan", None)) else data.edge_index
-    loss, _, _ = training_loss(egnn, topo, data.batch, noised, cond, params["atom_type_size"],
-                               num_graph_global=nglob, num_graphs=nb)
-    loss.backward()
     if reducer is not None:
-        reducer.finish()
+        if getattr(reducer, "_checked_opt", None) is not optimizer:
+            reducer.check_covers(optimizer)
+            reducer._checked_opt = optimizer
+        with reducer.armed():     # an exception in the forward / backward disarms the hook and drains the exchanges
+            loss, _, _ = training_loss(egnn, topo, data.batch, noised, cond, params["atom_type_size"],
+                                       num_graph_global=nglob, num_graphs=nb)
+            loss.backward()
+    else:
+        loss, _, _ = training_loss(egnn, topo, data.batch, noised, cond, params["atom_type_size"],
+                                   num_graph_global=nglob, num_graphs=nb)
+        loss.backward()
     optimizer.step()
     return loss.detach()
 

@@ -170,3 +170,38 @@ def test_forward_accepts_a_plan_in_place_of_edge_index():
     assert torch.equal(h1, h2) and torch.equal(x1, x2)
     with pytest.raises(ValueError):
         net(b.plan(), h[:-1], x[:-1])
+
+
+def test_shuffled_multi_rank_loader_draws_one_permutation():
+    """with world_size > 1 every rank must take its batches from the SAME permutation: seeded by `seed` and the
+    epoch, never by a process-global RNG; the union over ranks is then one full pass over the records."""
+    recs = _records(sizes=(3, 2, 4, 2, 3, 5, 2, 4), seed=3)
+    for i, r in enumerate(recs):
+        r.id = i
+    with pytest.raises(ValueError):
+        dma.GraphLoader(recs, batch_size=2, shuffle=True, rank=0, world_size=2)
+    for epoch in range(2):
+        seen = []
+        for rank in range(2):
+            torch.manual_seed(100 + rank)          # different global RNG state per rank, as in separate processes
+            ld = dma.GraphLoader(recs, batch_size=2, shuffle=True, rank=rank, world_size=2, seed=7)
+            ld.set_epoch(epoch)
+            for b in ld:
+                seen += list(b.id)
+        assert sorted(seen) == list(range(len(recs)))
+    a = [list(b.id) for b in dma.GraphLoader(recs, batch_size=2, shuffle=True, seed=7)]
+    ld = dma.GraphLoader(recs, batch_size=2, shuffle=True, seed=7)
+    first = [list(b.id) for b in ld]
+    second = [list(b.id) for b in ld]                # the epoch advances by itself
+    assert first == a and second != first
+
+
+def test_batch_copy_does_not_carry_a_plan_of_another_device():
+    """Batch.to() / clone() must not hand the cached GraphPlan (device arrays) to the copy"""
+    b = dma.collate(_records())
+    p0 = b.plan()
+    assert b.plan() is p0
+    c = b.clone()
+    assert c.plan() is not p0 and torch.equal(c.plan().edge_dst, p0.edge_dst)
+    d = b.to("cpu")
+    assert d.plan() is not p0 and d.plan().edge_dst.device == d.pos.device

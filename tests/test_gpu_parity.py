@@ -4,7 +4,8 @@ the CPU oracle and the committed golden vectors.
 Tolerances
   fp32 path  : 1e-4 relative (BASELINE.json north_star); measured errors are ~1e-6.
   bf16 path  : MFMA operands are rounded to bf16 (8 significant bits) with fp32 accumulation;
-               5e-2 relative to the oracle on eps, stated in each test.
+               1e-2 relative to the oracle on eps (measured 2-4e-3), stated in each test.
+  bf16x3 path: head + remainder operands on the bf16 matrix cores: 1e-4 as the fp32 path.
 """
 import math
 
@@ -60,10 +61,32 @@ def test_egnn_bf16_close_to_oracle(tag):
     ei = dma.fully_connected_edge_index(sizes, device=DEV)
     with torch.no_grad():
         h_o, x_o = net(ei, h.to(DEV), x.to(DEV))
-    # bf16 operands, fp32 accumulation: tolerance 5e-2 on the layer outputs / eps
-    assert rel_err(h_o.cpu(), layers[-1][0]) <= 5e-2
-    assert rel_err(x_o.cpu() - x, layers[-1][1] - x) <= 5e-2
+    # bf16 operands (8 significant bits), fp32 accumulation: 1e-2 on the layer outputs / eps (measured 2-4e-3)
+    eh, ex = rel_err(h_o.cpu(), layers[-1][0]), rel_err(x_o.cpu() - x, layers[-1][1] - x)
+    print(f"bf16 {tag}: h {eh:.2e} eps_x {ex:.2e}")
+    assert eh <= 1e-2 and ex <= 1e-2
     assert torch.isfinite(h_o).all() and torch.isfinite(x_o).all()
+
+
+@pytest.mark.parametrize("tag", EGNN_CASES)
+def test_egnn_bf16x3_matches_reference_golden(tag):
+    """precision 'bf16x3' (head + remainder operands on the bf16 matrix cores; shapes outside the 128-edge tiling run the
+    fp32 kernels) against the reference goldens at north_star's 1e-4, final outputs and every layer."""
+    sd, h, x, sizes, layers, d = golden_case(G_EGNN, tag)
+    L = len(layers)
+    net = build_net(sd, d, L, precision="bf16x3")
+    ei = dma.fully_connected_edge_index(sizes, device=DEV)
+    with torch.no_grad():
+        h_o, x_o = net(ei, h.to(DEV), x.to(DEV))
+    eh, ex = max_rel(h_o.cpu(), layers[-1][0]), max_rel(x_o.cpu(), layers[-1][1])
+    print(f"bf16x3 {tag}: h {eh:.2e} x {ex:.2e}")
+    assert eh <= 1e-4 and ex <= 1e-4
+    hh, xx = h.to(DEV), x.to(DEV)
+    with torch.no_grad():
+        for l in range(L):
+            hh, xx = net.egcl_list[l](ei, hh, xx)
+            assert max_rel(hh.cpu(), layers[l][0]) <= 1e-4, f"layer {l} h"
+            assert max_rel(xx.cpu(), layers[l][1]) <= 1e-4, f"layer {l} x"
 
 
 def test_norm_scope_graph_equals_single_graph_calls_on_gpu():
@@ -157,7 +180,10 @@ def c2_inputs(batch, n_atoms=64, H=36, seed=0):
     return h, pos
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16", 6e-2)])
+# tolerances: fp32 and bf16x3 1e-4 (north_star); bf16 1e-2 on the layer outputs / eps of the 4-layer stack (measured 2-4e-3:
+# MFMA operands carry 8 significant bits), 1e-4 under a permutation of graphs (measured 2e-5: fp32 summation-order
+# differences of tile partials occasionally flip the bf16 rounding of a later layer's operand)
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16x3", 1e-4), ("bf16", 1e-2)])
 def test_full_size_c2_properties(precision, tol):
     """BASELINE configs[1] size (256 graphs x 64 atoms, L=4, widths 1024/256): size-independent
     properties -- E(3) equivariance, graph-permutation equivariance, batch == single-graph calls --
@@ -177,27 +203,28 @@ def test_full_size_c2_properties(precision, tol):
         R, tvec = _rot(5), torch.tensor([0.7, -0.2, 1.1])
         h1, x1 = net(ei, h.to(DEV), (x @ R.T + tvec).to(DEV), batch=batch)
     assert torch.isfinite(h0).all() and torch.isfinite(x0).all()
-    etol = 1e-4 if precision == "fp32" else tol
-    assert rel_err(h1.cpu(), h0.cpu()) <= etol
-    assert rel_err((x1.cpu() - (x @ R.T + tvec)), (x0.cpu() - x) @ R.T) <= etol
+    etol = 1e-4 if precision != "bf16" else tol
+    e_rot = max(rel_err(h1.cpu(), h0.cpu()), rel_err((x1.cpu() - (x @ R.T + tvec)), (x0.cpu() - x) @ R.T))
     # permuting whole graphs permutes the outputs (up to the fp32 summation order of tile partials: a
     # graph's 4032 edges need not start on a tile boundary)
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(3))
     idx = (perm.repeat_interleave(n) * n + torch.arange(n).repeat(B))
     with torch.no_grad():
         h2, x2 = net(ei, h[idx].to(DEV), x[idx].to(DEV), batch=batch)
-    ptol = 1e-5 if precision == "fp32" else 5e-3   # bf16 re-rounding (eps 4e-3) amplifies fp32 order differences
-    assert rel_err(h2.cpu(), h0.cpu()[idx]) <= ptol and rel_err(x2.cpu(), x0.cpu()[idx]) <= ptol
+    ptol = 1e-5 if precision != "bf16" else 1e-4
+    e_perm = max(rel_err(h2.cpu(), h0.cpu()[idx]), rel_err(x2.cpu(), x0.cpu()[idx]))
     # oracle spot check on graphs 0 and 137
     e1 = egnn_ref.fully_connected_edge_index(n)
+    e_or = 0.0
     for gidx in (0, 137):
         sl = slice(gidx * n, (gidx + 1) * n)
         ho, xo = egnn_ref.egnn_forward(sd, e1, h[sl], x[sl])
-        assert rel_err(h0[sl].cpu(), ho) <= tol
-        assert rel_err(x0[sl].cpu() - x[sl], xo - x[sl]) <= tol
+        e_or = max(e_or, rel_err(h0[sl].cpu(), ho), rel_err(x0[sl].cpu() - x[sl], xo - x[sl]))
+    print(f"C2 {precision}: rotation {e_rot:.2e}  permutation {e_perm:.2e}  oracle {e_or:.2e}")
+    assert e_rot <= etol and e_perm <= ptol and e_or <= tol
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16", 6e-2)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16x3", 1e-4), ("bf16", 1e-2)])
 def test_full_size_c3_properties(precision, tol):
     """BASELINE configs[2] size at FULL width (32 graphs x 512 atoms, E = 8,372,224, L=4, widths 1024/256: the
     edge_kernel_bf16_v3<2,false> / <1,true> kernels on degree-511 rows, 4 tiles per receiving node): E(3)
@@ -230,21 +257,20 @@ def test_full_size_c3_properties(precision, tol):
         h1, x1 = net(ei, h.to(DEV), (x @ R.T + tvec).to(DEV), batch=batch)
     assert torch.isfinite(h0).all() and torch.isfinite(x0).all()
     assert torch.equal(h0, h0b) and torch.equal(x0, x0b)
-    etol = 1e-4 if precision == "fp32" else tol
-    assert rel_err(h1.cpu(), h0.cpu()) <= etol
-    assert rel_err((x1.cpu() - (x @ R.T + tvec)), (x0.cpu() - x) @ R.T) <= etol
+    etol = 1e-4 if precision != "bf16" else tol
+    e_rot = max(rel_err(h1.cpu(), h0.cpu()), rel_err((x1.cpu() - (x @ R.T + tvec)), (x0.cpu() - x) @ R.T))
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(4))
     idx = (perm.repeat_interleave(n) * n + torch.arange(n).repeat(B))
     with torch.no_grad():
         h2, x2 = net(ei, h[idx].to(DEV), x[idx].to(DEV), batch=batch)
     # every 512-atom graph starts on a tile boundary (261,632 = 2044 x 128), so a permutation of graphs is exact
-    ptol = 1e-5 if precision == "fp32" else 5e-3
-    assert rel_err(h2.cpu(), h0.cpu()[idx]) <= ptol and rel_err(x2.cpu(), x0.cpu()[idx]) <= ptol
+    e_perm = max(rel_err(h2.cpu(), h0.cpu()[idx]), rel_err(x2.cpu(), x0.cpu()[idx]))
     gidx = 17
     sl = slice(gidx * n, (gidx + 1) * n)
     ho, xo = egnn_ref.egnn_forward(sd, egnn_ref.fully_connected_edge_index(n), h[sl], x[sl])
-    assert rel_err(h0[sl].cpu(), ho) <= tol
-    assert rel_err(x0[sl].cpu() - x[sl], xo - x[sl]) <= tol
+    e_or = max(rel_err(h0[sl].cpu(), ho), rel_err(x0[sl].cpu() - x[sl], xo - x[sl]))
+    print(f"C3 {precision}: rotation {e_rot:.2e}  permutation {e_perm:.2e}  oracle {e_or:.2e}")
+    assert e_rot <= etol and e_perm <= 1e-5 and e_or <= tol
 
 
 @pytest.mark.parametrize("tag", ["T1000", "T50", "T200"])
@@ -527,12 +553,14 @@ def test_width_sweep_all_edge_kernel_variants(H, m_size, wm, wx, wh):
     batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes)).to(DEV)
     for scope in ("call", "graph"):
         h_ref, x_ref = egnn_ref.egnn_forward(sd, ei_cpu, h, x, norm_scope=scope, graph_ptr=ptr)
-        for precision, tol in (("fp32", 1e-4), ("bf16", 5e-2)):
+        for precision, tol in (("fp32", 1e-4), ("bf16x3", 1e-4), ("bf16", 1e-2)):
             net = build_net(sd, d, 2, precision=precision, norm_scope=scope)
             with torch.no_grad():
                 h_o, x_o = net(ei_cpu.to(DEV), h.to(DEV), x.to(DEV), batch=batch)
-            assert rel_err(h_o.cpu(), h_ref) <= tol, (scope, precision, "h")
-            assert rel_err(x_o.cpu(), x_ref) <= tol, (scope, precision, "x")
+            eh, ex = rel_err(h_o.cpu(), h_ref), rel_err(x_o.cpu() - x, x_ref - x)
+            print(f"width sweep {(H, m_size, wm, wx, wh)} {scope} {precision}: h {eh:.2e} eps_x {ex:.2e}")
+            assert eh <= tol, (scope, precision, "h")
+            assert ex <= tol, (scope, precision, "eps_x")
 
 
 _FALLBACK_SNIPPET = r"""
@@ -557,7 +585,7 @@ with torch.no_grad():
     h_o, x_o = net(ei.cuda(), h.cuda(), x.cuda())
 eh, ex = rel_err(h_o.cpu(), h_ref), rel_err(x_o.cpu(), x_ref)
 print("ERR", eh, ex)
-assert eh <= 5e-2 and ex <= 5e-2
+assert eh <= 1e-2 and ex <= 1e-2
 """
 
 

@@ -256,8 +256,48 @@ def _ddp_worker(rank, world, port, out):
     ps = list(net.parameters())
     want = [a + b for a, b in zip(_rank_grads(ps, 0), _rank_grads(ps, 1))]
     errs += [float((q.grad - w).abs().max()) for q, w in zip(ps, want)]
+    # ---- learned schedule under data parallelism: gamma_0 / gamma_1 train, so the process's
+    # GammaNetwork must be one of the reducer's modules; a reducer that leaves optimizer parameters out is refused
+    proc = dma.E3DiffusionProcess(1e-5, 2.0, 20, noise_schedule="learned")
+    opt = torch.optim.SGD(list(net.parameters()) + list(proc.gamma.parameters()), lr=0.1)
+    covers = True
+    try:
+        dma.GradAllReducer(list(net.egcl_list)).check_covers(opt)
+        covers = False
+    except RuntimeError:
+        pass
+    red2 = dma.GradAllReducer(list(net.egcl_list) + [proc.gamma])
+    red2.check_covers(opt)
+    gps = [q for q in proc.gamma.parameters() if q.requires_grad]
+    for q, g_ in zip(gps, _rank_grads(gps, rank + 50)):
+        q.grad = g_
+    for p_ in net.parameters():
+        p_.grad = torch.zeros_like(p_)
+    red2.arm()
+    red2.finish()                      # nothing came through the backward hook: every bucket is reduced from .grad
+    want = [a + b for a, b in zip(_rank_grads(gps, 50), _rank_grads(gps, 51))]
+    errs += [float((q.grad - w).abs().max()) for q, w in zip(gps, want)]
+    # ---- an exception inside an armed step leaves no hook behind; a layer handed in twice is refused
+    from diffusion_model_amd import autograd as _ag
+    try:
+        with red.armed():
+            raise ValueError("boom")
+    except ValueError:
+        pass
+    hook_cleared = _ag.ACTIVE_REDUCER is None
+    twice = False
+    with red.armed():
+        layer = net.egcl_list[0]
+        ps = red.buckets[red.bucket_of[id(layer)]]
+        red.layer_ready(layer, _rank_grads(ps, rank))
+        try:
+            red.layer_ready(layer, _rank_grads(ps, rank))
+        except RuntimeError:
+            twice = True
+        for p_ in list(net.parameters()) + list(comp.parameters()):
+            p_.grad = torch.zeros_like(p_)
     if rank == 0:
-        torch.save({"n_global": n_global, "errs": errs}, out)
+        torch.save({"n_global": n_global, "errs": errs, "covers": covers, "hook_cleared": hook_cleared, "twice": twice}, out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -268,6 +308,7 @@ def test_gradient_allreduce_world_size_2_gloo(tmp_path):
     res = torch.load(out, weights_only=True)
     assert res["n_global"] == 8
     assert max(res["errs"]) < 1e-6
+    assert res["covers"] and res["hook_cleared"] and res["twice"]
 
 
 def _part_worker(rank, world, port, out):
