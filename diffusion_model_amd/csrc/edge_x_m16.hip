@@ -44,7 +44,26 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
   const int e0 = tile * kR;
   const int nvalid = min(kR, p.E - e0);
 
+#ifdef EGNN_EXP_STAMP   // diagnostic build only: cycle / 100 MHz wall stamps of one workgroup (tools/stamps.py layout)
+  const bool stamp_wg = blockIdx.x == gridDim.x / 2;
+  unsigned long long* st_base = p.stamps + (size_t)wave * 32 * 4;
+#define STAMP_(insn, c, k)                                                                        \
+  do {                                                                                            \
+    unsigned long long t_;                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    asm volatile(insn " %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                        \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    if (stamp_wg && lane == 0) st_base[(c) * 4 + (k)] = t_;                                       \
+  } while (0)
+#define STAMP(c, k) STAMP_("s_memtime", c, k)
+#define RSTAMP(c, k) STAMP_("s_memrealtime", c, k)
+#else
+#define STAMP(c, k)
+#define RSTAMP(c, k)
+#endif
+  STAMP(30, 0);   // kernel entry
   const int S = prologue(p, L, e0, nvalid, p.wdx, KP, s_wd, tid, lane, wave);
+  STAMP(30, 1);   // tile structure ready
 
   // ---- K loop ----
   const int NC = KP / kKC, KS = KP / 32;
@@ -144,6 +163,8 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
     __builtin_amdgcn_s_setprio(0);
   };
   // SIMD partners (waves w and w + 4) in opposite phase, one barrier per chunk (edge_bf16_v3.hip)
+  STAMP(30, 2);   // chunk 0 built, first weights requested
+  RSTAMP(31, 1);
   vload(1);
   if (wave < 4) {
     for (int i = 0; i < NC - 1; ++i) {
@@ -163,6 +184,8 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
   }
   mphase(NC - 1, true);
   __syncthreads();
+  STAMP(30, 3);   // K loop done
+  RSTAMP(31, 2);
 
   // ---- epilogue: s[row] = [b3] + sum_n w3[n] * SiLU(a2[row][n] + b2[n]) over this workgroup's 512 columns ----
   // accumulator layout of the 16x16 tile: column = lane & 15, row = 4 (lane >> 4) + register
@@ -194,6 +217,9 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
   }
   __syncthreads();
   coordinate_segment_sums(p, L, S, tile, half, tid, lane, wave);
+  STAMP(31, 0);   // epilogue done
+#undef STAMP
+#undef RSTAMP
 }
 
 }  // namespace

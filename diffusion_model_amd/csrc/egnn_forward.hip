@@ -1220,8 +1220,9 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
       // layer is fewer workgroups than CUs (one 64-atom graph: 0.353 vs 0.323 ms per reverse step).
       static const int x4_sel = getenv("EGNN_X4") ? atoi(getenv("EGNN_X4")) : 0;
       const bool x4 = p.WxP >= 512 && !v4x && x4_sel > 0;
-      // A/B switch: the coordinate kernel on v_mfma_f32_16x16x32_bf16 (edge_x_m16.hip), same workgroup tile
-      static const int xm16_sel = getenv("EGNN_XM16") ? atoi(getenv("EGNN_XM16")) : 0;
+      // the coordinate kernel on v_mfma_f32_16x16x32_bf16 (edge_x_m16.hip, default: 5-6 % faster by wall on random data than
+      // the 32x32x16 kernel at the same workgroup tile, profiles/r03c_ab_xm16.log); EGNN_XM16=0 selects edge_bf16_v3.hip (A/B)
+      static const int xm16_sel = getenv("EGNN_XM16") ? atoi(getenv("EGNN_XM16")) : 1;
       const bool xm16 = xm16_sel > 0 && !x4 && edge_x_m16_supported(p);
       auto launch_x = [&](hipStream_t s) {
         return x4 ? launch_edge_bf16_v4_x1(p, s) : (xm16 ? launch_edge_x_m16(p, s) : launch_edge_bf16_v3_x(p, s));
