@@ -24,6 +24,7 @@ SIGNATURES = {
     "egnn_set_model": (_i, [_vp] + [_i] * 6),
     "egnn_pack_layer": (_i, [_vp, _vp, _i] + [_vp] * 16),
     "egnn_set_graph": (_i, [_vp, _i, _i, _i] + [_vp] * 5),
+    "egnn_set_side_stream": (_i, [_vp, _vp]),
     "egcl_forward": (_i, [_vp, _vp, _i, _i, _i] + [_vp] * 4),
     "egcl_forward_begin": (_i, [_vp, _vp, _i, _i, _i] + [_vp] * 3),
     "egcl_forward_end": (_i, [_vp, _vp, _i, _i, _i] + [_vp] * 5),

@@ -953,13 +953,16 @@ static void prof_end(egnn_ctx* c, hipStream_t st) {
   c->ev_used += 2;
 }
 
-// Side stream + fork / join events of a context.  Created only for the sampler of a SMALL graph (egnn_sampler_prepare, i.e.
-// outside any stream capture), never for training contexts: with two ranks sharing one GPU over gloo, the mere existence
-// of one more HIP stream in the process made every gradient all-reduce take seconds (round-2 rehearsal, blocking or
-// non-blocking flag alike) -- the workloads that fork never run a collective.
+// Side stream + fork / join events of a context.  The library creates NO stream of its own: the caller hands one in
+// (egnn_set_side_stream; the Python host passes the process-wide auxiliary stream of diffusion_model_amd/streams.py, the same
+// one the gradient all-reduce uses), so a process holds a fixed, small set of HIP streams however many contexts and samplers
+// it creates.  Round 2 created a stream per sampler context and saw, in the 2-processes-on-one-GPU gloo rehearsal, every
+// gradient all-reduce take seconds once one more stream existed: two processes with 5-6 streams each oversubscribe the
+// device's hardware queues, and the scheduler then multiplexes queues between the processes with a coarse time slice
+// (DESIGN.md section 7).
 // The coordinate and the message kernel of a layer are independent.  On one stream the message kernel starts when the LAST
 // round of coordinate workgroups has drained; when that round leaves enough CUs idle for all message workgroups (two per
-// CU), the message kernel goes to a side stream and runs in that shadow: one 64-atom graph 64 of 256 CUs busy, five graphs
+// CU), the message kernel goes to the side stream and runs in that shadow: one 64-atom graph 64 of 256 CUs busy, five graphs
 // (generate()'s default gen_num_per_spectrum) 316 coordinate workgroups = 1.23 rounds -> 0.49 -> 0.42 ms per reverse step.
 // Full rounds (16 graphs and more: measured equal eager, 2-8 % slower in graph replay) keep the single stream.
 static bool fork_candidate(int E, int WxP) {
@@ -968,10 +971,8 @@ static bool fork_candidate(int E, int WxP) {
   return E > 0 && idle >= (tiles + 1) / 2;
 }
 
-int fork_streams(egnn_ctx* c) {
-  if (c->side) return EGNN_OK;
-  if (!fork_candidate(c->E, c->WxP)) return EGNN_OK;
-  if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { c->side = nullptr; return EGNN_EHIP; }
+int fork_streams(egnn_ctx* c) {   // fork / join events for a context whose caller provided a side stream
+  if (!c->side || c->ev_fork) return EGNN_OK;
   if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) return EGNN_EHIP;
   return EGNN_OK;
@@ -1373,7 +1374,7 @@ int egnn_destroy(egnn_ctx* c) {
   sampler_free(c);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-  if (c->side) (void)hipStreamDestroy(c->side);
+  c->side = nullptr;   // the caller's stream (egnn_set_side_stream)
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   delete c;
   return EGNN_OK;
@@ -1515,6 +1516,19 @@ int egnn_pack_layer(egnn_ctx* c, void* stream, int l, const float* m0_w, const f
   EGNN_HIP(hipGetLastError());
   lp.packed = true;
   return EGNN_OK;
+}
+
+int egnn_set_side_stream(egnn_ctx* c, void* stream) {
+  if (!c) return EGNN_EINVAL;
+  c->side = reinterpret_cast<hipStream_t>(stream);
+  if (c->smp.ready) {   // captured graphs carry the fork / join edges of the old setting
+    for (int i = 0; i < 2; ++i) {
+      if (c->smp.graph_exec[i]) { (void)hipGraphExecDestroy(c->smp.graph_exec[i]); c->smp.graph_exec[i] = nullptr; }
+      if (c->smp.graph[i]) { (void)hipGraphDestroy(c->smp.graph[i]); c->smp.graph[i] = nullptr; }
+    }
+    c->smp.graph_prec = c->smp.graph_norm = -1;
+  }
+  return fork_streams(c);
 }
 
 int egnn_set_graph(egnn_ctx* c, int N, int E, int B, const int32_t* edge_dst, const int32_t* edge_src,

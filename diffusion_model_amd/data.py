@@ -266,7 +266,8 @@ class GraphLoader:
         if on_gpu and getattr(self, "_copy_stream", None) is None:
             # host -> device copies of pageable tensors are ordered behind everything already queued on their stream: on
             # the compute stream the host would wait for the previous training step before it can collate the next batch
-            self._copy_stream = torch.cuda.Stream(dev)
+            from . import streams
+            self._copy_stream = streams.copy_stream(dev)
         for s in range(steps):
             gb = (s * self.world_size + self.rank) % nb
             idx = order[gb * self.batch_size:(gb + 1) * self.batch_size]

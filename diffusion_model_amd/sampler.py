@@ -13,7 +13,7 @@ from typing import List, Optional, Sequence
 
 import torch
 
-from . import _lib
+from . import _lib, streams
 from .graph import GraphPlan, fully_connected_edge_index, fully_connected_plan
 
 
@@ -67,11 +67,14 @@ class DeviceSampler:
             self.plan = GraphPlan(edge_index.to(self.device), self.N, sizes=self.sizes)
         self.ctx = egnn.context_for(self.plan)
         self.table = diffusion_process.step_table(self.device)
-        self.stream = torch.cuda.Stream(device=self.device)
+        self.stream = streams.work_stream(self.device)          # shared by every sampler of the process (streams.py)
         self._cond = cond
         torch.cuda.current_stream().synchronize()
+        self.stream.synchronize()
         _lib.check(_lib.lib().egnn_sampler_prepare(self.ctx.handle, self.T, self.A, float(onehot_scaling_factor),
                                                    _lib.ptr(self.table), _lib.ptr(cond), C.c_uint64(seed)))
+        # small graphs: the message kernel may run beside the coordinate kernel on the process's second stream
+        _lib.check(_lib.lib().egnn_set_side_stream(self.ctx.handle, C.c_void_p(streams.comm_stream(self.device).cuda_stream)))
         if self.x_only:
             _lib.check(_lib.lib().egnn_sampler_set_mode(self.ctx.handle, 1))
 

@@ -86,7 +86,8 @@ class GradAllReducer:
                 self.bucket_of[id(m)] = len(self.buckets)
                 self.buckets.append(ps)
         self._nccl = torch.cuda.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"
-        self.stream = torch.cuda.Stream() if self._nccl else None
+        from . import streams
+        self.stream = streams.comm_stream(torch.cuda.current_device()) if self._nccl else None   # the process's ONE comm stream
         self._done, self._pending, self._armed = set(), [], False
 
     def _active(self):

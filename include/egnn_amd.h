@@ -83,6 +83,11 @@ int egnn_set_graph(egnn_ctx* ctx, int N, int E, int B,
                    const int32_t* d_edge_dst, const int32_t* d_edge_src, const int32_t* d_row_ptr,
                    const int32_t* d_graph_ptr, const int32_t* d_node_graph);
 
+/* Optional second stream of the caller's for small graphs: when a layer's coordinate kernel leaves most CUs idle, the
+ * message kernel of the same layer is launched on `stream` between a fork and a join event (graph edges under capture).
+ * The library itself never creates a stream; NULL (default) = everything on the stream of the call. */
+int egnn_set_side_stream(egnn_ctx* ctx, void* stream);
+
 /* One EGCL layer: EGCL.forward(edge_index, h, coords) -> (h', x')
  * (EquivariantGraphNeuralNetwork.py:67-71).  h [N,H], x [N,3]; outputs must not alias inputs. */
 int egcl_forward(egnn_ctx* ctx, void* stream, int layer, int prec, int norm_scope,

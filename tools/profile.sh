@@ -20,5 +20,6 @@ rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$out
 echo "pmc_write rc=$?" >> "$out/pmc_write.log"
 python3 "$root/tools/summarize_prof.py" "$out" > "$out/summary.txt" 2>&1
 cat "$out/summary.txt"
+python3 "$root/tools/make_traffic_json.py" "$out" "${GIT_HEAD:-unknown}" "$out/traffic.json" > /dev/null 2>&1
 # keep the merged-back directory small
 find "$out" -name "*.csv" -size +8M -delete

@@ -11,8 +11,8 @@ out = sys.argv[1]
 
 def short(name):
     name = name.replace("(anonymous namespace)::", "").split("(")[0]
-    for k in ("edge_kernel", "node_post_kernel", "node_pre_kernel", "node_d2_kernel", "graph_scale_kernel",
-              "sampler_step_kernel", "advance_t_kernel"):
+    for k in ("edge_kernel", "edge_x_m16_kernel", "edge_x3_kernel", "edge_dgrad_kernel", "node_post", "node_pre", "node_d2_kernel",
+              "graph_scale_kernel", "sampler_step_kernel", "advance_t_kernel"):
         if k in name:
             return name[name.find(k):][:60]
     return name[-60:]
@@ -42,7 +42,7 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
         for r in csv.DictReader(open(f)):
             acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, cs in acc.items():
-        if not any(x in k for x in ("edge_kernel", "node_post", "node_pre")):
+        if not any(x in k for x in ("edge_kernel", "edge_x", "node_post", "node_pre")):
             continue
         print(f"[{os.path.basename(d)}] {k}")
         for c, v in sorted(cs.items()):
