@@ -28,6 +28,11 @@ __host__ __device__ inline size_t x16_smem_bytes(int KP) { return kOffLoop + 2 *
 
 typedef __attribute__((ext_vector_type(4))) float f32x4v;
 
+// SAVE = true: the training forward (egcl_forward_save): the same kernel, which also leaves in HBM the activation chunks
+// (s1_out, as the MFMA consumed them), the scaled second-layer pre-activations -log2(e) * (a2 + b2) (g_a2_out, row-major bf16
+// through a per-wave LDS transpose) and this column share of s_e (s_half_out) -- what edge_kernel_bf16_v3<2, false, false, true>
+// leaves, so that egcl_backward_heads_saved / the wgrad GEMMs find the same buffers.
+template <bool SAVE>
 __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const Lds L(smem);
@@ -94,12 +99,21 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[rb][cb][i] = 0.f;
 
+  // training forward: the activation chunk also goes to HBM, 16 bytes per thread, 128 contiguous bytes per row and chunk
+  // (both column shares build the same activations: only share 0 stores them)
+  auto s1_store = [&](const bf16x8 o0, const bf16x8 o1, const int c) {
+    if (half != 0) return;
+    __bf16* base = static_cast<__bf16*>(p.s1_out) + (size_t)e0 * KP + c * kKC + kg * 8;
+    if (brow < nvalid) *reinterpret_cast<bf16x8*>(base + (size_t)brow * KP) = o0;
+    if (brow + 64 < nvalid) *reinterpret_cast<bf16x8*>(base + (size_t)(brow + 64) * KP) = o1;
+  };
   {  // chunk 0
     UnitH u;
     unith_load(u, rs_tab, vdst0, vsrc0, offP, offQ);
-    unith_finish(u, s_wd + kg * 8, d2r0, slot0);
+    const bf16x8 o0 = unith_finish(u, s_wd + kg * 8, d2r0, slot0);
     unith_load(u, rs_tab, vdst1, vsrc1, offP, offQ);
-    unith_finish(u, s_wd + kg * 8, d2r1, slot1);
+    const bf16x8 o1 = unith_finish(u, s_wd + kg * 8, d2r1, slot1);
+    if constexpr (SAVE) s1_store(o0, o1, 0);
   }
   bf16x8 bq[2][4];   // weight fragments of the 2 k-steps of the current chunk
 #pragma unroll
@@ -158,9 +172,10 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
   auto vfinish = [&](const int c) {  // SiLU + bf16 pack of chunk c into its LDS buffer
     const size_t nbuf = (size_t)(c & 1) * kA1;
     __builtin_amdgcn_s_setprio(3);   // vector work wins issue arbitration over the partner wave's MFMAs
-    unith_finish(ua0, s_wd + c * kKC + kg * 8, d2r0, slot0 + nbuf);
-    unith_finish(ua1, s_wd + c * kKC + kg * 8, d2r1, slot1 + nbuf);
+    const bf16x8 o0 = unith_finish(ua0, s_wd + c * kKC + kg * 8, d2r0, slot0 + nbuf);
+    const bf16x8 o1 = unith_finish(ua1, s_wd + c * kKC + kg * 8, d2r1, slot1 + nbuf);
     __builtin_amdgcn_s_setprio(0);
+    if constexpr (SAVE) s1_store(o0, o1, c);
   };
   // SIMD partners (waves w and w + 4) in opposite phase, one barrier per chunk (edge_bf16_v3.hip)
   STAMP(30, 2);   // chunk 0 built, first weights requested
@@ -192,6 +207,35 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
   float part[32];
 #pragma unroll
   for (int v = 0; v < 32; ++v) part[v] = 0.f;
+  if constexpr (SAVE) {   // the scaled pre-activations go to HBM first (the K-loop buffers are free behind the last barrier);
+                          // the accumulators then hold them for the SiLU below
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const float bb = p.b2x[16 * (cb0 + cb) + r15];
+#pragma unroll
+      for (int rb = 0; rb < 8; ++rb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[rb][cb][i] = fmaf(acc[rb][cb][i], kNegLog2e, bb);
+    }
+    // per-wave staging tile [16 rows][72 bf16] (64 columns + pad); 16-byte row-major stores, 128 contiguous bytes per row
+    __bf16* stg = reinterpret_cast<__bf16*>(s_a1) + (size_t)wave * 16 * 72;
+    __bf16* tout = static_cast<__bf16*>(p.g_a2_out) + (size_t)e0 * p.WxP + 16 * cb0;
+#pragma unroll
+    for (int rb = 0; rb < 8; ++rb) {
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) stg[(4 * q4 + i) * 72 + 16 * cb + r15] = (__bf16)acc[rb][cb][i];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int piece = lane + 64 * t, row = piece >> 3, seg = piece & 7;   // 16 rows x 8 pieces of 16 bytes
+        if (16 * rb + row < nvalid)
+          *reinterpret_cast<bf16x8*>(tout + (size_t)(16 * rb + row) * p.WxP + 8 * seg) = *reinterpret_cast<const bf16x8*>(stg + row * 72 + 8 * seg);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
 #pragma unroll
   for (int cb = 0; cb < 4; ++cb) {
     const int n = 16 * (cb0 + cb) + r15;
@@ -199,7 +243,8 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
 #pragma unroll
     for (int rb = 0; rb < 8; ++rb)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) part[rb * 4 + i] = fmaf(w, silu_s(fmaf(acc[rb][cb][i], kNegLog2e, bb)), part[rb * 4 + i]);
+      for (int i = 0; i < 4; ++i)
+        part[rb * 4 + i] = fmaf(w, silu_s(SAVE ? acc[rb][cb][i] : fmaf(acc[rb][cb][i], kNegLog2e, bb)), part[rb * 4 + i]);
   }
   {
     float t0, t1;
@@ -225,7 +270,9 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
 }  // namespace
 
 int init_edge_x_m16_attributes() {
-  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_x_m16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_x_m16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               160 * 1024));
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_x_m16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                160 * 1024));
   return EGNN_OK;
 }
@@ -240,7 +287,17 @@ int launch_edge_x_m16(const EdgeParams& p, hipStream_t st) {
   const int tiles = (p.E + kR - 1) / kR;
   EdgeParams q = p;
   q.w2x = p.w2x16;
-  hipLaunchKernelGGL(edge_x_m16_kernel, dim3(tiles * (p.WxP / 512)), dim3(kT), x16_smem_bytes(p.WxP), st, q);
+  hipLaunchKernelGGL(edge_x_m16_kernel<false>, dim3(tiles * (p.WxP / 512)), dim3(kT), x16_smem_bytes(p.WxP), st, q);
+  EGNN_HIP(hipGetLastError());
+  return EGNN_OK;
+}
+
+// training forward: p.s1_out / p.g_a2_out / p.s_half_out receive what the backward needs (see the kernel's SAVE mode)
+int launch_edge_x_m16_save(const EdgeParams& p, hipStream_t st) {
+  const int tiles = (p.E + kR - 1) / kR;
+  EdgeParams q = p;
+  q.w2x = p.w2x16;
+  hipLaunchKernelGGL(edge_x_m16_kernel<true>, dim3(tiles * (p.WxP / 512)), dim3(kT), x16_smem_bytes(p.WxP), st, q);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }

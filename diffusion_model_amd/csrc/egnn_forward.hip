@@ -1232,7 +1232,7 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
       if (c->save_s1x) {   // training forward (egcl_forward_save): the same kernels, which also store what the backward needs
         nsplit_x = p.WxP >= 512 ? p.WxP / 512 : 1;
         p.s1_out = c->save_s1x; p.g_a2_out = c->save_t2x; p.s_half_out = c->save_s;
-        rc = launch_edge_bf16_v3_x_save(p, st);
+        rc = xm16 ? launch_edge_x_m16_save(p, st) : launch_edge_bf16_v3_x_save(p, st);
         p.s1_out = c->save_s1m; p.g_a2_out = c->save_t2m; p.s_half_out = nullptr;
         if (!rc) rc = launch_edge_bf16_v4_m_save(p, st);
       } else if (v4x) rc = launch_edge_bf16_v4(p, st);

@@ -295,6 +295,7 @@ int init_edge_bf16_v2_attributes();
 int init_edge_bf16_v3_attributes();
 bool edge_bf16_v2_supported(const EdgeParams& p);
 int launch_edge_x_m16(const EdgeParams& p, hipStream_t st);   // coordinate kernel on v_mfma_f32_16x16x32_bf16
+int launch_edge_x_m16_save(const EdgeParams& p, hipStream_t st);
 bool edge_x_m16_supported(const EdgeParams& p);
 int init_edge_x_m16_attributes();
 int launch_edge_bf16x3(const EdgeParams& p, hipStream_t st);    // precision 'bf16x3': head / remainder split operands

@@ -412,3 +412,70 @@ def test_saved_activation_backward_matches_recompute(monkeypatch):
     for k in out["1"][1]:
         assert torch.isfinite(out["1"][1][k]).all()
         assert rel_err(out["1"][1][k].cpu(), out["0"][1][k].cpu()) <= 3e-2, k
+
+
+# ---------------- data-parallel training step on RCCL (needs >= 2 GPUs: skipped on a one-GPU box) ----------------
+def _nccl_worker(rank, world, port, out):
+    """one rank per GPU, backend nccl (= RCCL on ROCm): each rank runs the real forward + backward on its shard of the
+    graphs with the overlapped per-layer all-reduce (GradAllReducer.armed), the loss divided by the GLOBAL graph count"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    H, A, T = 36, 2, 50
+    d = dims_for(H, 128, 256, 256, 256)
+    torch.manual_seed(3)
+    net = dma.EquivariantGNN(2, **d).to(dev)
+    net.norm_scope = "graph"
+    sizes = (6, 4, 7, 5)
+    pos0, x0, cond, batch, ei, npos, nh, _ = _problem(seed=5, sizes=sizes)
+    times = [17, 3, 40, 22]
+    mine = [g for g in range(len(sizes)) if g % world == rank]
+    sel = torch.cat([(batch == g).nonzero().flatten() for g in mine])
+    lsizes = [sizes[g] for g in mine]
+    lbatch = torch.repeat_interleave(torch.arange(len(mine)), torch.tensor(lsizes)).to(dev)
+    lei = fully_connected_edge_index(lsizes).to(dev)
+    proc = dma.E3DiffusionProcess(1e-5, 2.0, T)
+    red = dma.GradAllReducer(list(net.egcl_list))
+    noised = dma.diffuse_as_batch(pos0[sel].to(dev), x0[sel].to(dev), lbatch, proc, times=[times[g] for g in mine],
+                                  noise_pos=npos[sel].to(dev), noise_h=nh[sel].to(dev), num_graphs=len(mine))
+    with red.armed():
+        loss, _, _ = dma.training_loss(net, lei, lbatch, noised, cond[sel].to(dev), A, num_graph_global=len(sizes),
+                                       num_graphs=len(mine))
+        loss.backward()
+    tot = loss.detach().clone()
+    dist.all_reduce(tot)
+    torch.cuda.synchronize(dev)
+    if rank == 0:
+        torch.save({"loss": float(tot), "grads": {k: p.grad.cpu() for k, p in net.named_parameters()},
+                    "world": dist.get_world_size(), "backend": dist.get_backend()}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_ddp_gradients_on_rccl_equal_single_process(tmp_path):
+    """BASELINE configs[3]'s exchange on real RCCL: 2 ranks x 2 graphs each == one process on the 4 graphs (2e-3: the
+    segment sums of the two shards associate differently).  Needs two visible GPUs; the round's one-GPU box skips it."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL over xGMI); the gloo world_size-2 tests cover the logic on CPU")
+    out = str(tmp_path / "nccl.pt")
+    mp.spawn(_nccl_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    res = torch.load(out, weights_only=True)
+    assert res["world"] == 2 and res["backend"] == "nccl"
+    dev = "cuda:0"
+    H, A, T = 36, 2, 50
+    d = dims_for(H, 128, 256, 256, 256)
+    torch.manual_seed(3)
+    net = dma.EquivariantGNN(2, **d).to(dev)
+    net.norm_scope = "graph"
+    sizes = (6, 4, 7, 5)
+    pos0, x0, cond, batch, ei, npos, nh, _ = _problem(seed=5, sizes=sizes)
+    proc = dma.E3DiffusionProcess(1e-5, 2.0, T)
+    noised = dma.diffuse_as_batch(pos0.to(dev), x0.to(dev), batch.to(dev), proc, times=[17, 3, 40, 22], noise_pos=npos.to(dev),
+                                  noise_h=nh.to(dev), num_graphs=4)
+    loss, _, _ = dma.training_loss(net, ei.to(dev), batch.to(dev), noised, cond.to(dev), A, num_graphs=4)
+    loss.backward()
+    assert abs(float(loss.detach()) - res["loss"]) <= 1e-4 * abs(res["loss"])
+    for k, p in net.named_parameters():
+        assert rel_err(res["grads"][k], p.grad.cpu()) <= 2e-3, k
