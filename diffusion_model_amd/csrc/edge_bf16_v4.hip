@@ -30,7 +30,7 @@
 // the double-buffered LDS activation chunk, CB B fragments straight from the packed weights, 4*CB MFMAs.
 #include <type_traits>
 
-#include "kernels.h"
+#include "edge_tile.h"
 
 namespace egnn {
 
@@ -40,23 +40,8 @@ constexpr int kT3 = 512;
 constexpr int kR3 = 128, kRB3 = 4, kRPAD3 = kR3 + 1;
 constexpr int kKC3 = 64;
 constexpr size_t kA1_3 = (size_t)8 * kRPAD3 * 16;  // one activation chunk [8 k-groups][129][8 bf16]
-constexpr int kSegFast3 = 8;
-
-// LDS carve (bytes)
-constexpr size_t kOffDst = 0;                                  // int[R]
-constexpr size_t kOffSrc = kOffDst + kR3 * 4;                  // int[R]
-constexpr size_t kOffD2 = kOffSrc + kR3 * 4;                   // float[R]
-constexpr size_t kOffDiff = kOffD2 + kR3 * 4;                  // float[3][R]
-constexpr size_t kOffVal = kOffDiff + 3 * kR3 * 4;             // float[R]   s_ij (X) / gate (M)
-constexpr size_t kOffPart = kOffVal + kR3 * 4;                 // float[8][R] per-wave partial row sums
-constexpr size_t kOffSegRow = kOffPart + 8 * kR3 * 4;          // int[R]
-constexpr size_t kOffSegNode = kOffSegRow + kR3 * 4;           // int[R]
-constexpr size_t kOffSegRs = kOffSegNode + kR3 * 4;            // int[R]
-constexpr size_t kOffSegRe = kOffSegRs + kR3 * 4;              // int[R]
-constexpr size_t kOffSegMode = kOffSegRe + kR3 * 4;            // int[R]
-constexpr size_t kOffMisc = kOffSegMode + kR3 * 4;             // int[16]
-constexpr size_t kOffGseg = kOffMisc + 64;                     // float[kSegFast3][R]
-constexpr size_t kOffA1 = kOffGseg + kSegFast3 * kR3 * 4;      // ring of 3 activation chunks, then wd[KP]
+using namespace tile128;
+constexpr size_t kOffA1 = kOffLoop;      // ring of 3 activation chunks, then wd[KP] (the per-tile arrays: edge_tile.h)
 constexpr int kRing = 3;
 __host__ __device__ inline size_t v4_smem_bytes(int KP, int MP, bool is_m) {
   (void)MP; (void)is_m;
@@ -73,19 +58,9 @@ __host__ __device__ inline size_t v4_smem_bytes(int KP, int MP, bool is_m) {
 template <int CB, bool IS_M, bool BWD = false, bool SAVE = false>
 __global__ __launch_bounds__(kT3, ((CB == 1 && !BWD) ? EGNN_V4_M_WAVES : 2)) void edge_kernel_bf16_v4(const EdgeParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  int* s_dst = reinterpret_cast<int*>(smem + kOffDst);
-  int* s_src = reinterpret_cast<int*>(smem + kOffSrc);
-  float* s_d2 = reinterpret_cast<float*>(smem + kOffD2);
-  float* s_diff = reinterpret_cast<float*>(smem + kOffDiff);
-  float* s_val = reinterpret_cast<float*>(smem + kOffVal);
-  float* s_part = reinterpret_cast<float*>(smem + kOffPart);
-  int* s_seg_of_row = reinterpret_cast<int*>(smem + kOffSegRow);
-  int* s_seg_node = reinterpret_cast<int*>(smem + kOffSegNode);
-  int* s_seg_rs = reinterpret_cast<int*>(smem + kOffSegRs);
-  int* s_seg_re = reinterpret_cast<int*>(smem + kOffSegRe);
-  int* s_seg_mode = reinterpret_cast<int*>(smem + kOffSegMode);
-  int* s_misc = reinterpret_cast<int*>(smem + kOffMisc);
-  float* s_gseg = reinterpret_cast<float*>(smem + kOffGseg);
+  const Lds L(smem);
+  int* const s_dst = L.dst; int* const s_src = L.src;
+  float* const s_d2 = L.d2; float* const s_val = L.val; float* const s_part = L.part; float* const s_gseg = L.gseg;
   char* s_a1 = smem + kOffA1;
   float* s_wd = reinterpret_cast<float*>(s_a1 + kRing * kA1_3);
 
@@ -131,54 +106,8 @@ __global__ __launch_bounds__(kT3, ((CB == 1 && !BWD) ? EGNN_V4_M_WAVES : 2)) voi
 #define STAMP1(c, k) STAMP(c, k)
 #endif
   STAMP(30, 0);   // kernel entry
-  // ---- prologue: edge rows, geometry, segment (= receiving node) structure ----
-  if (tid < kR3) {
-    int d = 0, s = 0;
-    float dx = 0.f, dy = 0.f, dz = 0.f;
-    if (tid < nvalid) {
-      d = p.edge_dst[e0 + tid];
-      s = p.edge_src[e0 + tid];
-      dx = p.x[3 * d] - p.x[3 * s];
-      dy = p.x[3 * d + 1] - p.x[3 * s + 1];
-      dz = p.x[3 * d + 2] - p.x[3 * s + 2];
-    }
-    s_dst[tid] = d;
-    s_src[tid] = s;
-    s_diff[tid] = dx; s_diff[kR3 + tid] = dy; s_diff[2 * kR3 + tid] = dz;
-    const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);  // norm(...)**2 as in the reference (:56)
-    s_d2[tid] = nrm * nrm;
-  }
-  {
-    const float* wd = IS_M ? p.wdm : p.wdx;
-    for (int i = tid; i < KP; i += kT3) s_wd[i] = wd[i];
-  }
-  __syncthreads();
-  bool is_start = false, is_end = false;
-  unsigned long long starts = 0;
-  if (tid < kR3) {   // waves 0 and 1
-    const bool valid = tid < nvalid;
-    const int d = s_dst[tid];
-    is_start = valid && (tid == 0 || s_dst[tid - 1] != d);
-    is_end = valid && (tid == nvalid - 1 || s_dst[tid + 1] != d);
-    starts = __ballot(is_start);
-    if (lane == 0) s_misc[1 + wave] = __popcll(starts);
-  }
-  __syncthreads();
-  if (tid < kR3) {
-    const int seg = (wave == 1 ? s_misc[1] : 0) + __popcll(starts & ((2ull << lane) - 1ull)) - 1;
-    s_seg_of_row[tid] = tid < nvalid ? seg : -1;
-    if (is_start) { s_seg_node[seg] = s_dst[tid]; s_seg_rs[seg] = tid; }
-    if (is_end) s_seg_re[seg] = tid;
-    if (tid == 0) s_misc[0] = s_misc[1] + s_misc[2];
-  }
-  __syncthreads();
-  const int S = s_misc[0];
-  if (tid < S) {   // where does each segment's sum go?  (same rule as the other edge kernels)
-    const int n = s_seg_node[tid];
-    const bool first = (e0 + s_seg_rs[tid]) == p.row_ptr[n];
-    const bool last = (e0 + s_seg_re[tid] + 1) == p.row_ptr[n + 1];
-    s_seg_mode[tid] = (first && last) ? 2 : (first ? 1 : 0);
-  }
+  const int S = prologue(p, L, e0, nvalid, IS_M ? p.wdm : p.wdx, KP, s_wd, tid, lane, wave);
+  (void)S;
 
   STAMP(30, 1);   // tile structure ready
 
@@ -427,88 +356,12 @@ __global__ __launch_bounds__(kT3, ((CB == 1 && !BWD) ? EGNN_V4_M_WAVES : 2)) voi
       store_block_bf16(blk, 1, stg, gout + (size_t)(32 * rb) * p.MP, (size_t)p.MP, nvalid - 32 * rb, lane);
     }
   } else if constexpr (!IS_M) {
-    // ---- mlp_x epilogue: s[row] = [b3] + sum_n w3[n] * SiLU(acc + b2[n]) over this workgroup's columns ----
-    float part[64];
-#pragma unroll
-    for (int q = 0; q < 64; ++q) part[q] = 0.f;
-#pragma unroll
-    for (int cb = 0; cb < CB; ++cb) {
-      const int n = 32 * (colblk0 + cb) + r;
-      const float bb = p.b2x[n], w = p.w3x[n];
-#pragma unroll
-      for (int rb = 0; rb < kRB3; ++rb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) part[rb * 16 + i] = fmaf(w, silu_s(fmaf(acc[rb][cb][i], kNegLog2e, bb)), part[rb * 16 + i]);
-    }
-    {
-      float lo[32], hi[32];
-#pragma unroll
-      for (int q = 0; q < 32; ++q) { lo[q] = part[q]; hi[q] = part[32 + q]; }
-      const float t0 = butterfly32(lo, lane), t1 = butterfly32(hi, lane);
-      s_part[wave * kR3 + row_of(r)] = t0;
-      s_part[wave * kR3 + 64 + row_of(r)] = t1;
-    }
-    __syncthreads();
-    if (tid < kR3) {
-      float v = half == 0 ? p.scal[0] : 0.f;
-#pragma unroll
-      for (int w = 0; w < 8; ++w) v += s_part[w * kR3 + tid];
-      s_val[tid] = v;
-    }
-    __syncthreads();
-    float* aggx = p.agg_x + (size_t)half * p.agg_x_stride;
-    float* partx = p.part_x + (size_t)half * p.part_x_stride;
-    // Component 3 of every coordinate sum carries the segment's sum of |x_i - x_j|^2 (plain squares: the Frobenius norm
-    // of :64 is sqrt of the sum over ALL edges), so the normaliser needs no pass of its own over the edges.
-    if (S <= kSegFast3) {
-      if (wave == 0) {  // coordinate messages (x_i - x_j) * s_ij; 1/(G+1) is applied in node_post
-        float c[2][4];
-        int myseg[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int row = lane + 64 * u;
-          myseg[u] = s_seg_of_row[row];
-          const float sv = s_val[row];
-          const float dx = s_diff[row], dy = s_diff[kR3 + row], dz = s_diff[2 * kR3 + row];
-          c[u][0] = dx * sv; c[u][1] = dy * sv; c[u][2] = dz * sv;
-          c[u][3] = dx * dx + dy * dy + dz * dz;
-        }
-        for (int seg = 0; seg < S; ++seg) {
-          float a0 = (myseg[0] == seg ? c[0][0] : 0.f) + (myseg[1] == seg ? c[1][0] : 0.f);
-          float a1 = (myseg[0] == seg ? c[0][1] : 0.f) + (myseg[1] == seg ? c[1][1] : 0.f);
-          float a2 = (myseg[0] == seg ? c[0][2] : 0.f) + (myseg[1] == seg ? c[1][2] : 0.f);
-          float a3 = (myseg[0] == seg ? c[0][3] : 0.f) + (myseg[1] == seg ? c[1][3] : 0.f);
-#pragma unroll
-          for (int m = 32; m >= 1; m >>= 1) { a0 += __shfl_xor(a0, m); a1 += __shfl_xor(a1, m); a2 += __shfl_xor(a2, m); a3 += __shfl_xor(a3, m); }
-          if (lane < 4) {
-            const int mode = s_seg_mode[seg];
-            float* dstp = mode == 2 ? aggx + (size_t)s_seg_node[seg] * 4 : partx + ((size_t)tile * 2 + mode) * 4;
-            dstp[lane] = lane == 0 ? a0 : (lane == 1 ? a1 : (lane == 2 ? a2 : a3));
-          }
-        }
-      }
-    } else {
-      for (int t = tid; t < 4 * S; t += kT3) {
-        const int seg = t >> 2, d = t & 3, mode = s_seg_mode[seg];
-        float sum = 0.f;
-        if (d < 3) {
-          for (int rr = s_seg_rs[seg]; rr <= s_seg_re[seg]; ++rr) sum += s_diff[d * kR3 + rr] * s_val[rr];
-        } else {
-          for (int rr = s_seg_rs[seg]; rr <= s_seg_re[seg]; ++rr) {
-            const float dx = s_diff[rr], dy = s_diff[kR3 + rr], dz = s_diff[2 * kR3 + rr];
-            sum += dx * dx + dy * dy + dz * dz;
-          }
-        }
-        float* dstp = mode == 2 ? aggx + (size_t)s_seg_node[seg] * 4 : partx + ((size_t)tile * 2 + mode) * 4;
-        dstp[d] = sum;
-      }
-    }
+    static_assert(IS_M, "edge_bf16_v4.hip keeps the message kernels only (coordinate kernels: edge_x_m16.hip, edge_bf16_v3.hip)");
   } else {
     // ---- mlp_m epilogue: m = SiLU(acc + b2), gate = sigmoid(wa . m + ba) (:31-34, :59-60) ----
     static_assert(!IS_M || CB == 1, "message epilogue assumes one 32-column block per wave");
-    float mval[64];
-    const int ncol = 32 * wave + r;
     if constexpr (SAVE) {   // scaled pre-activations to HBM first (the ring is free behind the last chunk's barrier)
+      const int ncol = 32 * wave + r;
       const float bb = p.b2m[ncol];
 #pragma unroll
       for (int rb = 0; rb < kRB3; ++rb)
@@ -524,55 +377,7 @@ __global__ __launch_bounds__(kT3, ((CB == 1 && !BWD) ? EGNN_V4_M_WAVES : 2)) voi
         store_block_bf16(blk, 1, stg, tout + (size_t)(32 * rb) * p.MP, (size_t)p.MP, nvalid - 32 * rb, lane);
       }
     }
-    {
-      const float bb = p.b2m[ncol], wa = p.wa[ncol];
-      float lo[32], hi[32];
-#pragma unroll
-      for (int rb = 0; rb < kRB3; ++rb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const float m = silu_s(SAVE ? acc[rb][0][i] : fmaf(acc[rb][0][i], kNegLog2e, bb));   // = -log2(e) * m
-          mval[rb * 16 + i] = m;
-          if (rb < 2) lo[rb * 16 + i] = wa * m; else hi[(rb - 2) * 16 + i] = wa * m;
-        }
-      const float t0 = butterfly32(lo, lane), t1 = butterfly32(hi, lane);
-      s_part[wave * kR3 + row_of(r)] = t0;
-      s_part[wave * kR3 + 64 + row_of(r)] = t1;
-    }
-    __syncthreads();
-    if (tid < kR3) {
-      float g = p.scal[1];
-#pragma unroll
-      for (int w = 0; w < 8; ++w) g += s_part[w * kR3 + tid];
-      s_val[tid] = sigmoid_f(g) * kNegInvLog2e;   // also undoes the scale of mval
-    }
-    __syncthreads();
-    // segment sums, kSegFast3 segments per pass (one pass unless the tile holds many short segments): the gate of
-    // each row is laid out per segment in LDS and every lane dots its 64 message values with it
-    for (int base = 0; base < S; base += kSegFast3) {
-      const int ns = min(kSegFast3, S - base);
-      if (base > 0) __syncthreads();   // the previous pass has been read
-      for (int t = tid; t < ns * kR3; t += kT3) {
-        const int seg = base + (t >> 7), row = t & 127;
-        s_gseg[t] = (s_seg_of_row[row] == seg) ? s_val[row] : 0.f;
-      }
-      __syncthreads();
-      for (int sg = 0; sg < ns; ++sg) {
-        const int seg = base + sg;
-        const float* gw = s_gseg + sg * kR3 + 4 * hh;
-        float v = 0.f;
-#pragma unroll
-        for (int rb = 0; rb < kRB3; ++rb)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) v = fmaf(mval[rb * 16 + i], gw[32 * rb + (i & 3) + 8 * (i >> 2)], v);
-        v += __shfl_xor(v, 32);
-        if (hh == 0) {
-          const int mode = s_seg_mode[seg];
-          float* dstp = mode == 2 ? p.agg_m + (size_t)s_seg_node[seg] * p.MP : p.part_m + ((size_t)tile * 2 + mode) * p.MP;
-          dstp[ncol] = v;
-        }
-      }
-    }
+    message_epilogue<SAVE>(p, L, acc, S, tile, tid, lane, wave);
   }
   STAMP(31, 0);   // epilogue done
 }
@@ -587,10 +392,6 @@ int launch_v4(const EdgeParams& p, int blocks, size_t smem, hipStream_t st) {
 }  // namespace
 
 int init_edge_bf16_v4_attributes() {
-  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v4<2, false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v4<1, false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v4<1, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v4<1, true, true>),
@@ -615,12 +416,6 @@ int launch_edge_bf16_v4_m_bwd(const EdgeParams& p, hipStream_t st) {
   return launch_v4<1, true, true>(p, tiles, v4_smem_bytes(p.WmP, p.MP, true), st);
 }
 
-// coordinate kernel as 256-column workgroups (two per CU), WxP / 256 column shares per tile
-int launch_edge_bf16_v4_x1(const EdgeParams& p, hipStream_t st) {
-  const int tiles = (p.E + kR3 - 1) / kR3;
-  return launch_v4<1, false>(p, tiles * (p.WxP / 256), v4_smem_bytes(p.WxP, p.MP, false), st);
-}
-
 // training forward of the message branch: p.s1_out / p.g_a2_out receive the activations and the scaled pre-activations
 int launch_edge_bf16_v4_m_save(const EdgeParams& p, hipStream_t st) {
   const int tiles = (p.E + kR3 - 1) / kR3;
@@ -630,16 +425,6 @@ int launch_edge_bf16_v4_m_save(const EdgeParams& p, hipStream_t st) {
 // message kernel only
 int launch_edge_bf16_v4_m(const EdgeParams& p, hipStream_t st) {
   const int tiles = (p.E + kR3 - 1) / kR3;
-  return launch_v4<1, true>(p, tiles, v4_smem_bytes(p.WmP, p.MP, true), st);
-}
-
-int launch_edge_bf16_v4(const EdgeParams& p, hipStream_t st) {
-  const int tiles = (p.E + kR3 - 1) / kR3;
-  int rc;
-  // X: CB = 2 (512 columns per workgroup) when the hidden width allows, else one 256-column workgroup
-  if (p.WxP >= 512) rc = launch_v4<2, false>(p, tiles * (p.WxP / 512), v4_smem_bytes(p.WxP, p.MP, false), st);
-  else rc = launch_v4<1, false>(p, tiles, v4_smem_bytes(p.WxP, p.MP, false), st);
-  if (rc) return rc;
   return launch_v4<1, true>(p, tiles, v4_smem_bytes(p.WmP, p.MP, true), st);
 }
 

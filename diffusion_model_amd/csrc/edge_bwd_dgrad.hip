@@ -158,35 +158,52 @@ __global__ __launch_bounds__(kTD, (CB == 1 ? 4 : 2)) void edge_dgrad_kernel(cons
 #undef LDS_RD
 
   // ---- epilogue: times SiLU'(a1) from the first-layer table, row-major bf16 store ----
+  // The accumulator block goes through the per-wave LDS transpose FIRST (as the plain store would), so that a lane holds
+  // 8 consecutive columns of one row: the first-layer pre-activations P[dst] + Q[src] of exactly those columns are then two
+  // 16-byte table loads (8 lanes cover a 128-byte line), 8 loads per lane and row block in flight, instead of two 2-byte
+  // gathers per accumulator element (round 2: 256 scalar-width vector-memory instructions per wave and row block, the
+  // epilogue as long as the K loop).  SiLU' is applied on the row-major values; the table entries are added in fp16 as the
+  // forward adds them (same a1 bit for bit).
   const rsrc_t rs_tab = make_rsrc(p.table, (unsigned)((size_t)p.N * p.TC * 2));
   __bf16* stg = reinterpret_cast<__bf16*>(s_a1) + (size_t)wave * 32 * 72;
   __bf16* gout = static_cast<__bf16*>(p.g_a1_out) + (size_t)e0 * p.KP + 32 * colblk0;
+  constexpr int kPieces = CB * 4;            // 16-byte pieces per row of this wave's block
+  constexpr int kPer = 32 * kPieces / 64;    // pieces per lane and row block
 #pragma unroll
   for (int rb = 0; rb < kRBD; ++rb) {
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb) {
-      const int col = 32 * (colblk0 + cb) + r;
-      const float wdc = p.wd[col];
-      const unsigned col2 = 2u * (unsigned)col;
-      _Float16 tp[16], tq[16];   // all 32 two-byte gathers of the block in flight before the first use
+    for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = 32 * rb + acc_row(i, lane);
-        tp[i] = __builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(rs_tab, (unsigned)s_dst[row] + col2, 0, 0));
-        tq[i] = __builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(rs_tab, (unsigned)s_src[row] + col2, 0, 0));
-      }
+      for (int i = 0; i < 16; ++i) stg[acc_row(i, lane) * 72 + 32 * cb + r] = (__bf16)acc[rb][cb][i];
+    __builtin_amdgcn_wave_barrier();
+    f16x8 tp[kPer], tq[kPer];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = 32 * rb + acc_row(i, lane);
-        float sv, ds;
-        silu_grad_s(fmaf(wdc, s_d2[row], (float)tp[i] + (float)tq[i]), sv, ds);
-        acc[rb][cb][i] *= ds;
-      }
+    for (int t = 0; t < kPer; ++t) {
+      const int q = lane + 64 * t, row = q / kPieces, seg = q - row * kPieces;
+      const unsigned cbyte = 2u * (unsigned)(32 * colblk0 + 8 * seg);
+      tp[t] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_tab, (unsigned)s_dst[32 * rb + row] + cbyte, 0, 0));
+      tq[t] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_tab, (unsigned)s_src[32 * rb + row] + cbyte, 0, 0));
     }
-    f32x16 blk[2];
-    blk[0] = acc[rb][0];
-    blk[1] = acc[rb][CB - 1];
-    store_block_bf16(blk, CB, stg, gout + (size_t)(32 * rb) * p.KP, (size_t)p.KP, nvalid - 32 * rb, lane);
+#pragma unroll
+    for (int t = 0; t < kPer; ++t) {
+      const int q = lane + 64 * t, row = q / kPieces, seg = q - row * kPieces;
+      const int grow = 32 * rb + row, col0 = 32 * colblk0 + 8 * seg;
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(p.wd + col0), w1 = *reinterpret_cast<const f32x4*>(p.wd + col0 + 4);
+      const float d2 = s_d2[grow];
+      const bf16x8 g = *reinterpret_cast<const bf16x8*>(stg + row * 72 + 8 * seg);
+      const f16x8 a1 = tp[t] + tq[t];
+      bf16x8 o;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        float sv, ds;
+        silu_grad_s(fmaf(w0[jj], d2, (float)a1[jj]), sv, ds);
+        o[jj] = (__bf16)((float)g[jj] * ds);
+        silu_grad_s(fmaf(w1[jj], d2, (float)a1[jj + 4]), sv, ds);
+        o[jj + 4] = (__bf16)((float)g[jj + 4] * ds);
+      }
+      if (grow < nvalid) *reinterpret_cast<bf16x8*>(gout + (size_t)grow * p.KP + 8 * seg) = o;
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -210,8 +227,7 @@ int launch_edge_dgrad(int N, int E, const int* dst, const int* src, const float*
   p.N = N; p.E = E; p.edge_dst = dst; p.edge_src = src; p.x = x; p.table = table; p.TC = TC; p.offP = offP; p.offQ = offQ;
   p.wd = wd; p.g_a2 = g_a2; p.Kd = Kd; p.w2t = w2t; p.KP = KP; p.g_a1_out = g_a1_out;
   const int tiles = (E + kRD - 1) / kRD;
-  static const int cb_sel = getenv("EGNN_DGRAD_CB") ? atoi(getenv("EGNN_DGRAD_CB")) : 2;   // A/B switch (1: equal time, twice the L2 reads)
-  if (KP >= 512 && cb_sel >= 2) hipLaunchKernelGGL(edge_dgrad_kernel<2>, dim3(tiles * (KP / 512)), dim3(kTD), kSmemD, st, p);
+  if (KP >= 512) hipLaunchKernelGGL(edge_dgrad_kernel<2>, dim3(tiles * (KP / 512)), dim3(kTD), kSmemD, st, p);
   else hipLaunchKernelGGL(edge_dgrad_kernel<1>, dim3(tiles * (KP / 256)), dim3(kTD), kSmemD, st, p);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;

@@ -992,9 +992,8 @@ int init_kernel_attributes() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&node_pre_hilo_kernel<2>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  int rc = init_edge_bf16_v2_attributes();
+  int rc = init_edge_bf16_v3_attributes();
   if (rc) return rc;
-  if ((rc = init_edge_bf16_v3_attributes())) return rc;
   if ((rc = init_edge_bf16_v4_attributes())) return rc;
   if ((rc = init_node_bf16_attributes())) return rc;
   if ((rc = init_edge_dgrad_attributes())) return rc;
@@ -1049,8 +1048,7 @@ static void use_scaled_pack(egnn_ctx* c, int layer, EdgeParams& p, const float*&
 static int launch_node_pre_f16(egnn_ctx* c, hipStream_t st, int layer, const float* h, const float* w1catT,
                                const float* b1cat) {
   const int N = c->N;
-  static const int pre_sel = getenv("EGNN_PRE") ? atoi(getenv("EGNN_PRE")) : 3;   // A/B switch: 1 VALU, 2 f32 MFMA, 3 bf16 hi/lo
-  if (pre_sel >= 3 && c->H <= 48) {
+  if (c->H <= 48) {   // bf16 hi/lo MFMA (2^-16), else exact f32 MFMA, else the VALU kernel
     const int ntile = (N + kPre3Nodes - 1) / kPre3Nodes;
     const size_t sm = (size_t)48 * 33 * 4 + (size_t)4 * 32 * (128 + 8) * 2;
     const bf16x8* w1hl = reinterpret_cast<const bf16x8*>(c->layers[layer].w1hl_bf16);
@@ -1061,7 +1059,7 @@ static int launch_node_pre_f16(egnn_ctx* c, hipStream_t st, int layer, const flo
     else
       hipLaunchKernelGGL(node_pre_hilo_kernel<2>, dim3(ntile, (c->TC + 255) / 256), dim3(kThreads), sm, st, h, N, c->H, w1hl,
                          b1cat, c->TC, tab);
-  } else if (pre_sel >= 2 && c->H <= 64) {
+  } else if (c->H <= 64) {
     dim3 grid((N + kPre2Nodes - 1) / kPre2Nodes, (c->TC + kPre2Cols - 1) / kPre2Cols);
     const size_t sm = (size_t)((c->H + 1) & ~1) * 33 * sizeof(float);
     const size_t sm16 = (size_t)kPre2Nodes * (kPre2Cols + 8) * 2;   // output staging tile of the fp16 variant
@@ -1141,30 +1139,32 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
   int R = edge_rows_per_tile(prec), nsplit_x = 1;
   const int per_graph = norm_scope == EGNN_NORM_GRAPH;
 
-  // choose the edge path first: the bf16 fast kernels consume the pre-scaled first-layer table
+  // choose the edge path first: the 128-edge-tile bf16 kernels consume the pre-scaled first-layer table
+  //   path 5  precision bf16x3: edge_bf16x3.hip (head / remainder operands, fp32 table)
+  //   path 4  precision bf16  : coordinate kernel edge_x_m16.hip (hidden width 512 / 1024) or edge_bf16_v3.hip (256) +
+  //                             message kernel edge_bf16_v4.hip (fp16 table)
+  //   path 1  every other shape, and fp32: the generic 64-edge-tile kernel edge_kernel<PREC> of this file
+  // EGNN_EDGE=1 forces path 1 (the one switch kept: the fallback kernels' own parity test runs the reference widths on them)
   EdgeParams p;
   fill_edge_params(c, layer, prec, x, p);
-  static const int edge_sel = getenv("EGNN_EDGE") ? atoi(getenv("EGNN_EDGE")) : 4;   // A/B switch: 1, 2, 3 or 4
+  static const int edge_sel = getenv("EGNN_EDGE") ? atoi(getenv("EGNN_EDGE")) : 4;
   int path = 1;
   if (prec == EGNN_PREC_BF16X3) {   // split-operand kernels where the 128-edge tiling applies, else the exact fp32 path
     EdgeParams q = p;
     const float *w1c, *b1c;
     use_scaled_pack(c, layer, q, w1c, b1c);
-    if (edge_bf16x3_supported(q)) path = 5;
+    if (edge_sel >= 4 && edge_bf16x3_supported(q)) path = 5;
     else prec = EGNN_PREC_F32;
     fill_edge_params(c, layer, prec, x, p);
   }
   if (prec == EGNN_PREC_BF16 && edge_sel >= 4 && edge_bf16_v4_supported(p) && edge_bf16_v3_supported(p)) path = 4;
-  else if (prec == EGNN_PREC_BF16 && edge_sel >= 3 && edge_bf16_v3_supported(p)) path = 3;
-  else if (prec == EGNN_PREC_BF16 && edge_sel >= 2 && edge_bf16_v2_supported(p)) path = 2;
-  if (c->save_s1x && path != 4) { set_error("egcl_forward_save needs the 128-row bf16 edge kernels (EGNN_EDGE=4)"); return EGNN_EINVAL; }
+  if (c->save_s1x && path != 4) { set_error("egcl_forward_save needs the 128-edge-tile bf16 kernels"); return EGNN_EINVAL; }
   const float* w1catT = lp.w1catT;
   const float* b1cat = lp.b1cat;
-  if (path >= 2) use_scaled_pack(c, layer, p, w1catT, b1cat);
+  if (path >= 4) use_scaled_pack(c, layer, p, w1catT, b1cat);
 
   prof_begin(c, st, 1);
   {
-    static const int pre_sel = getenv("EGNN_PRE") ? atoi(getenv("EGNN_PRE")) : 3;   // A/B switch
     if (path == 5) {   // bf16x3: exact fp32 table of the scaled first layers
       dim3 grid((N + kPre2Nodes - 1) / kPre2Nodes, (c->TC + kPre2Cols - 1) / kPre2Cols);
       const size_t sm = (size_t)((c->H + 1) & ~1) * 33 * sizeof(float);
@@ -1173,10 +1173,10 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
       else
         hipLaunchKernelGGL(node_pre_kernel<float>, dim3((N + kPreNodes - 1) / kPreNodes, (c->TC + kThreads - 1) / kThreads),
                            dim3(kThreads), (size_t)kPreNodes * c->H * sizeof(float), st, h, N, c->H, w1catT, b1cat, c->TC, c->table);
-    } else if (path >= 3) {   // the v3 / v4 edge kernels read a half-precision table
+    } else if (path == 4) {   // half-precision table
       int rc = launch_node_pre_f16(c, st, layer, h, w1catT, b1cat);
       if (rc) return rc;
-    } else if (pre_sel >= 2 && c->H <= 64) {
+    } else if (c->H <= 64) {
       dim3 grid((N + kPre2Nodes - 1) / kPre2Nodes, (c->TC + kPre2Cols - 1) / kPre2Cols);
       const size_t sm = (size_t)((c->H + 1) & ~1) * 33 * sizeof(float);
       hipLaunchKernelGGL(node_pre_mfma_kernel<float>, grid, dim3(kThreads), sm, st, h, N, c->H, w1catT, b1cat, c->TC,
@@ -1208,35 +1208,18 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
       rc = launch_edge_bf16x3(p, st);
     } else if (path == 4) {
       R = edge_v4_rows();
-      nsplit_x = p.WxP >= 512 ? p.WxP / 512 : 1;
-      // coordinate kernels with the phase-opposed K loop of edge_bf16_v3.hip, message kernel with the in-wave pipeline
-      // of edge_bf16_v4.hip: each the faster one for its shape (EGNN_V4_X=1 selects the v4 coordinate kernel, A/B)
-      static const int v4x = getenv("EGNN_V4_X") ? atoi(getenv("EGNN_V4_X")) : 0;
-      // fork_candidate(): the message kernel goes to a side stream between two events (fork / join; under capture they
-      // become graph edges) and runs in the shadow of the coordinate kernel's last, partly filled round.
-      static const int fork_sel = getenv("EGNN_FORK") ? atoi(getenv("EGNN_FORK")) : 1;   // A/B switch
-      const bool fork = fork_sel && !v4x && !c->prof && st != nullptr && c->side != nullptr && fork_candidate(E, p.WxP);
-      // A/B switch: 256-column coordinate workgroups (four per tile, two per CU, edge_bf16_v4.hip).  Slower both when the
-      // chip is full (2.37 vs 2.02 ms at C2: the mlp_x activations are built four times instead of twice) and when the
-      // layer is fewer workgroups than CUs (one 64-atom graph: 0.353 vs 0.323 ms per reverse step).
-      static const int x4_sel = getenv("EGNN_X4") ? atoi(getenv("EGNN_X4")) : 0;
-      const bool x4 = p.WxP >= 512 && !v4x && x4_sel > 0;
-      // the coordinate kernel on v_mfma_f32_16x16x32_bf16 (edge_x_m16.hip, default: 5-6 % faster by wall on random data than
-      // the 32x32x16 kernel at the same workgroup tile, profiles/r03c_ab_xm16.log); EGNN_XM16=0 selects edge_bf16_v3.hip (A/B)
-      static const int xm16_sel = getenv("EGNN_XM16") ? atoi(getenv("EGNN_XM16")) : 1;
-      const bool xm16 = xm16_sel > 0 && !x4 && edge_x_m16_supported(p);
-      auto launch_x = [&](hipStream_t s) {
-        return x4 ? launch_edge_bf16_v4_x1(p, s) : (xm16 ? launch_edge_x_m16(p, s) : launch_edge_bf16_v3_x(p, s));
-      };
-      if (x4) nsplit_x = p.WxP / 256;
+      const bool xm16 = edge_x_m16_supported(p);   // hidden width 512 / 1024: v_mfma_f32_16x16x32_bf16 (512 columns per workgroup)
+      nsplit_x = xm16 ? p.WxP / 512 : 1;
+      // fork_candidate(): the message kernel goes to the caller's side stream between two events (fork / join; under capture
+      // they become graph edges) and runs in the shadow of the coordinate kernel's last, partly filled round
+      const bool fork = !c->prof && st != nullptr && c->side != nullptr && c->ev_fork != nullptr && fork_candidate(E, p.WxP);
+      auto launch_x = [&](hipStream_t s) { return xm16 ? launch_edge_x_m16(p, s) : launch_edge_bf16_v3_x(p, s); };
       if (c->save_s1x) {   // training forward (egcl_forward_save): the same kernels, which also store what the backward needs
-        nsplit_x = p.WxP >= 512 ? p.WxP / 512 : 1;
         p.s1_out = c->save_s1x; p.g_a2_out = c->save_t2x; p.s_half_out = c->save_s;
         rc = xm16 ? launch_edge_x_m16_save(p, st) : launch_edge_bf16_v3_x_save(p, st);
         p.s1_out = c->save_s1m; p.g_a2_out = c->save_t2m; p.s_half_out = nullptr;
         if (!rc) rc = launch_edge_bf16_v4_m_save(p, st);
-      } else if (v4x) rc = launch_edge_bf16_v4(p, st);
-      else if (fork) {
+      } else if (fork) {
         EGNN_HIP(hipEventRecord(c->ev_fork, st));
         EGNN_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
         rc = launch_x(st);
@@ -1247,12 +1230,7 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
         rc = launch_x(st);
         if (!rc) rc = launch_edge_bf16_v4_m(p, st);
       }
-    } else if (path == 3) {
-      R = edge_v3_rows();
-      nsplit_x = p.WxP >= 512 ? p.WxP / 512 : 1;
-      rc = launch_edge_bf16_v3(p, st);
-    } else if (path == 2) rc = launch_edge_bf16_v2(p, tiles, st);
-    else if (prec == EGNN_PREC_BF16) rc = launch_edge<EGNN_PREC_BF16, 2>(p, tiles, smem, st);
+    } else if (prec == EGNN_PREC_BF16) rc = launch_edge<EGNN_PREC_BF16, 2>(p, tiles, smem, st);
     else rc = launch_edge<EGNN_PREC_F32, 2>(p, tiles, smem, st);
     prof_end(c, st);
     if (rc) return rc;
@@ -1294,9 +1272,8 @@ int launch_layer_end(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_
     q.b1h = lp.b1h; q.b2h = lp.b2h; q.h_out = h_out; q.x_out = x_out;
     q.w1h_bf16 = lp.w1h_bf16; q.w2h_bf16p = lp.w2h_bf16p; q.K1Q = c->K1Q;
     q.h_partial = c->h_partial;
-    static const int post_sel = getenv("EGNN_POST") ? atoi(getenv("EGNN_POST")) : 2;   // A/B switch
     prof_begin(c, st, 1);
-    if (prec == EGNN_PREC_BF16 && post_sel >= 2 && node_post_bf16_supported(q)) {
+    if (prec == EGNN_PREC_BF16 && node_post_bf16_supported(q)) {
       int rc = launch_node_post_bf16(q, st);
       if (rc) return rc;
     } else {

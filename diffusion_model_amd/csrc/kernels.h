@@ -276,13 +276,9 @@ int launch_node_post_bf16(const PostParams& q, hipStream_t st);
 bool node_post_bf16_supported(const PostParams& q);
 int init_node_bf16_attributes();
 
-int launch_edge_bf16_v2(const EdgeParams& p, int tiles, hipStream_t st);
-int launch_edge_bf16_v3(const EdgeParams& p, hipStream_t st);
 bool edge_bf16_v3_supported(const EdgeParams& p);
 int edge_v3_rows();
-int launch_edge_bf16_v4(const EdgeParams& p, hipStream_t st);
 int launch_edge_bf16_v4_m(const EdgeParams& p, hipStream_t st);
-int launch_edge_bf16_v4_x1(const EdgeParams& p, hipStream_t st);   // 256-column coordinate workgroups (A/B switch EGNN_X4)
 int launch_edge_bf16_v3_x(const EdgeParams& p, hipStream_t st);
 int launch_edge_bf16_v3_x_bwd(const EdgeParams& p, hipStream_t st);
 int launch_edge_bf16_v4_m_bwd(const EdgeParams& p, hipStream_t st);
@@ -291,9 +287,7 @@ int launch_edge_bf16_v4_m_save(const EdgeParams& p, hipStream_t st);
 bool edge_bf16_v4_supported(const EdgeParams& p);
 int edge_v4_rows();
 int init_edge_bf16_v4_attributes();
-int init_edge_bf16_v2_attributes();
 int init_edge_bf16_v3_attributes();
-bool edge_bf16_v2_supported(const EdgeParams& p);
 int launch_edge_x_m16(const EdgeParams& p, hipStream_t st);   // coordinate kernel on v_mfma_f32_16x16x32_bf16
 int launch_edge_x_m16_save(const EdgeParams& p, hipStream_t st);
 bool edge_x_m16_supported(const EdgeParams& p);
