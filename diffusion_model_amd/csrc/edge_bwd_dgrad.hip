@@ -101,13 +101,18 @@ __global__ __launch_bounds__(kTD, (CB == 1 ? 4 : 2)) void edge_dgrad_kernel(cons
     const int c = cq < NC ? cq : NC - 1;   // past the end: a harmless repeat of the last chunk
     return ldbuf_bf16x8(rs_g, vrow, (unsigned)c * kKCD * 2u);
   };
+  // dL/da2 streams from HBM (no reuse beyond the column-share workgroups): a piece is requested THREE chunks (~3 us of
+  // K loop) before it is written to the ring -- round 2 kept one chunk of distance, which covers an L2 hit but not an HBM
+  // miss under load: 40 % of the wave cycles were spent parked at the wait in front of the LDS store (profiles/r03h).
   bf16x8 g0 = gload(vrow0, 0), g1 = gload(vrow1, 0);
   *reinterpret_cast<bf16x8*>(slot0) = g0;
   *reinterpret_cast<bf16x8*>(slot1) = g1;
   g0 = gload(vrow0, 1); g1 = gload(vrow1, 1);
   *reinterpret_cast<bf16x8*>(slot0 + kA1D) = g0;
   *reinterpret_cast<bf16x8*>(slot1 + kA1D) = g1;
-  g0 = gload(vrow0, 2); g1 = gload(vrow1, 2);
+  bf16x8 ga0 = gload(vrow0, 2), ga1 = gload(vrow1, 2);   // register sets A, B, C: chunks 2, 3, 4
+  bf16x8 gb0 = gload(vrow0, 3), gb1 = gload(vrow1, 3);
+  bf16x8 gc0 = gload(vrow0, 4), gc1 = gload(vrow1, 4);
   bf16x8 bq[4][CB];
 #pragma unroll
   for (int s = 0; s < 4; ++s)
@@ -121,7 +126,8 @@ __global__ __launch_bounds__(kTD, (CB == 1 ? 4 : 2)) void edge_dgrad_kernel(cons
 #define LDS_WAIT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
   LDS_RD(a[0], lds_a1_base, 0); LDS_RD(a[1], lds_a1_base, 512); LDS_RD(a[2], lds_a1_base, 1024); LDS_RD(a[3], lds_a1_base, 1536);
 
-  auto chunk = [&](const int c, const bool copy, const bool last) {
+  // chunk c: multiply it; `copy`: write chunk c + 2 (register set x0 / x1) to the ring and request chunk c + 5 into the set
+  auto chunk = [&](const int c, const bool copy, const bool last, bf16x8& x0, bf16x8& x1) {
     const unsigned abase = lds_a1_base + off_cur, nbase = lds_a1_base + off_nxt;
 #define GROUP(S, RB)                                                                                          \
     {                                                                                                         \
@@ -137,8 +143,8 @@ __global__ __launch_bounds__(kTD, (CB == 1 ? 4 : 2)) void edge_dgrad_kernel(cons
     }
 #define KSTEP(S)                                                                                              \
     GROUP(S, 0) GROUP(S, 1) GROUP(S, 2) GROUP(S, 3)                                                           \
-    if (copy && (S) == 1) { *reinterpret_cast<bf16x8*>(slot0 + off_wr) = g0; g0 = gload(vrow0, c + 3); }      \
-    if (copy && (S) == 3) { *reinterpret_cast<bf16x8*>(slot1 + off_wr) = g1; g1 = gload(vrow1, c + 3); }      \
+    if (copy && (S) == 1) { *reinterpret_cast<bf16x8*>(slot0 + off_wr) = x0; x0 = gload(vrow0, c + 5); }      \
+    if (copy && (S) == 3) { *reinterpret_cast<bf16x8*>(slot1 + off_wr) = x1; x1 = gload(vrow1, c + 5); }      \
     if (!last) {                                                                                              \
       const unsigned ksn = (unsigned)((c + 1) * 4 + (S)) * 1024u;                                             \
       _Pragma("unroll") for (int cb = 0; cb < CB; ++cb)                                                       \
@@ -149,10 +155,20 @@ __global__ __launch_bounds__(kTD, (CB == 1 ? 4 : 2)) void edge_dgrad_kernel(cons
 #undef GROUP
     const unsigned tmp = off_cur; off_cur = off_nxt; off_nxt = off_wr; off_wr = tmp;
   };
-  for (int c = 0; c < NC - 2; ++c) { chunk(c, true, false); __syncthreads(); }
-  chunk(NC - 2, false, false);
+  {
+    const int ncopy = NC - 2;   // chunks that still write the ring; the register sets rotate A, B, C (static names: an
+    int c = 0;                  // indexed array of sets would live in scratch)
+    for (; c + 3 <= ncopy; c += 3) {
+      chunk(c, true, false, ga0, ga1); __syncthreads();
+      chunk(c + 1, true, false, gb0, gb1); __syncthreads();
+      chunk(c + 2, true, false, gc0, gc1); __syncthreads();
+    }
+    if (c < ncopy) { chunk(c, true, false, ga0, ga1); __syncthreads(); ++c; }
+    if (c < ncopy) { chunk(c, true, false, gb0, gb1); __syncthreads(); ++c; }
+  }
+  chunk(NC - 2, false, false, ga0, ga1);
   __syncthreads();
-  chunk(NC - 1, false, true);
+  chunk(NC - 1, false, true, ga0, ga1);
   __syncthreads();
 #undef LDS_WAIT
 #undef LDS_RD

@@ -1,0 +1,47 @@
+"""Host wrappers of the library's hand-written GEMMs used by the training backward (no BLAS library on the bf16 path)."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+_workspaces = {}
+
+
+def _workspace(device, nbytes):
+    ws = _workspaces.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[device] = ws
+    return ws
+
+
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, rows: int | None = None, cols: int | None = None, scale: float = 1.0,
+            out: torch.Tensor | None = None, accumulate: bool = False) -> torch.Tensor:
+    """out[:rows, :cols] (+)= scale * a[:, :rows]^T @ b[:, :cols] in fp32, for bf16 row-major a [E, lda], b [E, ldb] whose row
+    strides are multiples of 8 and whose widths, rounded up to 256 (a) / 128 (b), stay inside the row stride
+    (egnn_gemm_tn_bf16: the reduction over E runs on the matrix cores, slices of E are added in a fixed order)."""
+    if not (a.is_cuda and b.is_cuda) or a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16:
+        raise RuntimeError("gemm_tn needs bf16 CUDA(ROCm) tensors; there is no CPU fallback")
+    if a.dim() != 2 or b.dim() != 2 or a.shape[0] != b.shape[0] or a.stride(1) != 1 or b.stride(1) != 1:
+        raise ValueError("gemm_tn: a [E, lda] and b [E, ldb] row-major with the same E")
+    E, lda, ldb = a.shape[0], a.stride(0), b.stride(0)
+    rows = a.shape[1] if rows is None else rows
+    cols = b.shape[1] if cols is None else cols
+    M, N = (rows + 255) // 256 * 256, (cols + 127) // 128 * 128
+    if M > lda or N > ldb:
+        raise ValueError(f"gemm_tn: operand widths padded to {M} / {N} exceed the row strides {lda} / {ldb}")
+    L = _lib.lib()
+    need = int(L.egnn_gemm_tn_workspace_bytes(E, M, N))
+    if need == 0:
+        raise ValueError("gemm_tn: unsupported shape")
+    ws = _workspace(a.device, need)
+    if out is None:
+        out = torch.empty(rows, cols, dtype=torch.float32, device=a.device)
+        accumulate = False
+    if out.dtype != torch.float32 or out.stride(1) != 1 or out.shape[0] < rows or out.shape[1] < cols:
+        raise ValueError("gemm_tn: out must be fp32 [>= rows, >= cols] with unit column stride")
+    _lib.check(L.egnn_gemm_tn_bf16(_lib.stream_ptr(), E, M, N, _lib.ptr(a), lda, _lib.ptr(b), ldb, float(scale), _lib.ptr(out),
+                                   out.stride(0), rows, cols, 1 if accumulate else 0, _lib.ptr(ws), ws.numel()))
+    ws.record_stream(torch.cuda.current_stream())
+    return out

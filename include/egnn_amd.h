@@ -192,6 +192,18 @@ int egcl_backward_heads_saved(egnn_ctx* ctx, void* stream, int layer, const floa
 int egcl_backward_dgrad(egnn_ctx* ctx, void* stream, int layer, const float* d_x, int e_first, int n_edges,
                         const void* d_g_a2x, const void* d_g_a2m, void* d_g_a1x_out, void* d_g_a1m_out);
 
+/* Weight gradients of the backward (loss.backward() of parts/train_per_iretation.py:172 through the Linear layers of
+ * EquivariantGraphNeuralNetwork.py:13-30): a reduction over ALL edges (or nodes) on the matrix cores,
+ *     C[m][n] (+)= scale * sum_e A[e][m] * B[e][n],   m < rows, n < cols,
+ * A [E, lda] and B [E, ldb] row-major bf16 with the reduction index as ROWS (the operands as the other backward kernels
+ * leave them: dL/da2 and the activations s1; dL/da1 and the gathered inputs), C fp32 with leading dimension ldc.  M and N are
+ * the operand widths the kernel reads (M % 256 == 0, N % 128 == 0, M <= lda, N <= ldb; columns beyond rows / cols are
+ * computed and dropped), split over slices of E whose fp32 partial tiles go through d_workspace
+ * (egnn_gemm_tn_workspace_bytes) and are added in slice order: deterministic.  Replaces torch.mm / bmm (round 2). */
+size_t egnn_gemm_tn_workspace_bytes(int E, int M, int N);
+int egnn_gemm_tn_bf16(void* stream, int E, int M, int N, const void* d_A, int lda, const void* d_B, int ldb, float scale,
+                      float* d_C, int ldc, int rows, int cols, int accumulate, void* d_workspace, size_t workspace_bytes);
+
 /* EquivariantGNN.forward(edge_index, h, x) -> (h_L, x_L) (:85-88): all L layers. */
 int egnn_forward(egnn_ctx* ctx, void* stream, int prec, int norm_scope,
                  const float* d_h, const float* d_x, float* d_h_out, float* d_x_out);

@@ -22,7 +22,7 @@ G_DIFF = load_golden("diffusion_golden.npz")
 def _header_functions():
     txt = open(os.path.join(ROOT, "include", "egnn_amd.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|const char\*)\s+(\w+)\s*\(", txt)))
+    return sorted(set(re.findall(r"^(?:int|size_t|const char\*)\s+(\w+)\s*\(", txt, flags=re.M)))
 
 
 def test_library_exports_every_header_symbol():

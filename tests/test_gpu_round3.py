@@ -297,3 +297,31 @@ def test_config4_full_size_slab_partitioned_equals_single(precision, tol):
         assert int(b.sum()) == 0
         assert rel_err(pos.cpu(), p_ref.cpu()) <= tol and rel_err(xt.cpu(), x_ref.cpu()) <= tol
         assert torch.equal(pos, outs[0][0]) and torch.equal(xt, outs[0][1])      # replicated state stays bit-identical
+
+
+@pytest.mark.parametrize("E,M,N,lda,ldb", [
+    (4096, 256, 128, 256, 128),          # one tile, BN = 128
+    (10000, 1024, 1024, 1024, 1024),     # mlp_x.2 weight gradient shape, ragged E (last step partly out of range)
+    (33333, 256, 1024, 256, 1024),       # mlp_m.2
+    (20001, 1024, 74, 1024, 128),        # first layer: 74 real columns in a 128-column operand
+    (5000, 292, 36, 512, 128),           # node MLP sizes inside padded operands
+])
+def test_gemm_tn_matches_fp64_reference(E, M, N, lda, ldb):
+    """egnn_gemm_tn_bf16 (split-K reduction over rows on the matrix cores, transposed LDS reads for both operands) against
+    a float64 product of the same bf16 values: exact up to fp32 accumulation order (1e-5 of the largest entry), with
+    asymmetric random operands (a transposed or row / column swapped result cannot pass), accumulate and scale."""
+    from diffusion_model_amd.gemm import gemm_tn
+    g = torch.Generator().manual_seed(E + M)
+    a = torch.randn(E, lda, generator=g).to(torch.bfloat16).to(DEV)
+    b = (torch.randn(E, ldb, generator=g) * torch.linspace(0.5, 2.0, ldb)).to(torch.bfloat16).to(DEV)
+    want = (a[:, :M].double().t() @ b[:, :N].double()).cpu()
+    got = gemm_tn(a, b, rows=M, cols=N)
+    assert got.shape == (M, N)
+    err = float((got.cpu().double() - want).abs().max() / want.abs().max())
+    print(f"gemm_tn E={E} M={M} N={N}: max err / max |C| = {err:.2e}")
+    assert err <= 1e-5
+    out = torch.full((M, N), 3.0, device=DEV)
+    gemm_tn(a, b, rows=M, cols=N, scale=-0.5, out=out, accumulate=True)
+    err2 = float((out.cpu().double() - (3.0 - 0.5 * want)).abs().max() / want.abs().max())
+    assert err2 <= 1e-5
+    assert torch.equal(gemm_tn(a, b, rows=M, cols=N), got)          # slices are added in a fixed order: bitwise repeatable
