@@ -53,10 +53,11 @@ def _round_up(v, m):
 class _Workspace:
     """[chunk, width] buffers of the edge part, allocated once per backward call"""
 
-    def __init__(self, rows, H, Wx, Wm, M, dtype, device, saved_activations=False):
+    def __init__(self, rows, H, Wx, Wm, M, dtype, device, saved_activations=False, hip_gemms=False):
         rows = _round_up(rows, 64)
         e = lambda *shape, dt=dtype: torch.empty(*shape, dtype=dt, device=device)
-        self.K1P = _round_up(2 * H + 2, 8)
+        # [h_i | h_j | d2 | 1 | 0...]: 128 columns when the hand-written GEMMs run (their operand width), else padded to 8
+        self.K1P = 128 if hip_gemms else _round_up(2 * H + 2, 8)
         self.rows, self.dtype = rows, dtype
         if not saved_activations:   # (the saved-activation backward reads s1 / a2 from what the forward kept)
             self.s1x, self.s1m = e(rows, Wx), e(rows, Wm)
@@ -65,6 +66,12 @@ class _Workspace:
         self.inp, self.g_in = e(rows, self.K1P), e(rows, self.K1P)
         self.d2 = e(rows, dt=torch.float32)
         self.g_diff = e(rows, 3, dt=torch.float32)
+
+
+def _hip_gemm_shapes(H, Wx, Wm, M):
+    """the bf16 backward's GEMMs run on the library's own kernels (gemm_tn.hip, gemm_rows.hip) when the widths fit their
+    tiles: reduction widths multiples of 64, output widths multiples of 256 / 128"""
+    return Wx % 256 == 0 and Wm % 256 == 0 and M % 256 == 0 and 2 * H + 2 <= 128
 
 
 def _wgrad(g, a, n_pad, splits):
@@ -95,8 +102,14 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_
     Wx, Wm, M = lin_x0.out_features, lin_m0.out_features, lin_m2.out_features
     f32 = dict(dtype=torch.float32, device=h.device)
 
+    hip = fused is not None and dt == torch.bfloat16 and K1P == 128 and _hip_gemm_shapes(H, Wx, Wm, M)
+    if hip:
+        from .gemm import gemm_rows, gemm_tn, pack_rows_weights
+
     def tables(lin):   # per-node halves of the first Linear layer (:56's concatenation factorised)
         w = lin.weight.detach()
+        if hip:        # the fused kernels take P / Q from the forward's table; the dgrad runs on packed fragments
+            return None, None, None, pack_rows_weights(w.float().contiguous(), 2 * H + 1)
         Pn = torch.addmm(lin.bias.detach(), h, w[:, :H].t()).contiguous()
         Qn = torch.mm(h, w[:, H:2 * H].t()).contiguous()
         wpad = torch.zeros(w.shape[0], K1P, dtype=dt, device=h.device)
@@ -129,7 +142,7 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_
             S1X, S1M, A2X, A2M = ws.s1x, ws.s1m, ws.a2x, ws.a2m
         s1x, s1m, a2x, a2m, g1x, g1m = S1X[:n], S1M[:n], A2X[:n], A2M[:n], ws.g1x[:n], ws.g1m[:n]
         inp, g_in, d2, g_diff = ws.inp[:n], ws.g_in[:n], ws.d2[:n], ws.g_diff[:n]
-        if n_pad > n:   # rows the split wgrad products read beyond the chunk
+        if n_pad > n and not hip:   # rows the split library products read beyond the chunk (the own GEMMs stop at row n)
             for t in ((ws.g1x, ws.g1m, ws.inp) if kept is not None else (ws.s1x, ws.s1m, ws.a2x, ws.a2m, ws.g1x, ws.g1m, ws.inp)):
                 t[n:n_pad].zero_()
         _lib.check(L.egcl_backward_gather_in(st, prec, n, H, K1P, P(d32), P(s32), P(h), P(x), P(inp), P(d2)))
@@ -152,8 +165,12 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_
                                              P(b2x), P(w3), P(b3), P(b2m), P(wa), P(ba), P(g_diff), P(g_b2x), P(g_w3),
                                              P(g_b3), P(g_b2m), P(g_wa), P(g_ba)))
         # a2x / a2m now hold dL/da2: wgrad and dgrad of the second Linear layers
-        g_w2x += _wgrad(A2X, S1X, n_pad, 16)
-        g_w2m += _wgrad(A2M, S1M, n_pad, 32)
+        if hip:   # reductions over the chunk's edges on the library's own split-K kernel (gemm_tn.hip), fp32 accumulate
+            gemm_tn(a2x, s1x, out=g_w2x, accumulate=True)
+            gemm_tn(a2m, s1m, out=g_w2m, accumulate=True)
+        else:
+            g_w2x += _wgrad(A2X, S1X, n_pad, 16)
+            g_w2m += _wgrad(A2M, S1M, n_pad, 32)
         if fused is not None:
             # dgrad of the second layers with SiLU'(a1) in the epilogue, on MFMA (no [n, W] round trip in between)
             _lib.check(L.egcl_backward_dgrad(fused[0], st, fused[1], P(x), a, n, P(a2x), P(a2m), P(g1x), P(g1m)))
@@ -163,10 +180,15 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_
             _lib.check(L.egcl_backward_l1_grad(st, prec, n, Wx, P(d32), P(s32), P(Px), P(Qx), P(wdx), P(d2), P(g1x)))
             _lib.check(L.egcl_backward_l1_grad(st, prec, n, Wm, P(d32), P(s32), P(Pm), P(Qm), P(wdm), P(d2), P(g1m)))
         # first Linear layers: wgrad against in = [h_i | h_j | d2 | 1], dgrad back to the gathered inputs
-        g_w1x += _wgrad(ws.g1x, ws.inp, n_pad, 32)
-        g_w1m += _wgrad(ws.g1m, ws.inp, n_pad, 32)
-        torch.mm(g1x, w1x, out=g_in)
-        g_in.addmm_(g1m, w1m)
+        if hip:
+            gemm_tn(g1x, inp, cols=2 * H + 2, out=g_w1x, accumulate=True)
+            gemm_tn(g1m, inp, cols=2 * H + 2, out=g_w1m, accumulate=True)
+            gemm_rows(g1x, w1x, g1m, w1m, out=g_in)      # row-streaming product (gemm_rows.hip): every dL/da1 row read once
+        else:
+            g_w1x += _wgrad(ws.g1x, ws.inp, n_pad, 32)
+            g_w1m += _wgrad(ws.g1m, ws.inp, n_pad, 32)
+            torch.mm(g1x, w1x, out=g_in)
+            g_in.addmm_(g1m, w1m)
         _lib.check(L.egcl_backward_scatter(st, prec, n, H, K1P, P(d32), P(s32), P(x), P(g_in), P(g_diff), P(g_S),
                                            P(node_seg), P(g_h), P(g_x)))
 
@@ -265,9 +287,7 @@ class _EGNNFunction(torch.autograd.Function):
         # the same graph (retain_graph=True) falls back to the recompute path
         kept = ctx.kept if ctx.kept is not None and all(k is not None for k in ctx.kept) else None
         if E > 0:
-            ws = _Workspace(min(EDGE_CHUNK, E), d0["H"], layers[0].mlp_x[0].out_features, layers[0].mlp_m[0].out_features, d0["M"],
-                            torch.bfloat16 if prec == _lib.PREC_BF16 else torch.float32, gh.device,
-                            saved_activations=kept is not None)
+            pass
         # bf16 at the reference widths: the recompute half of the edge backward runs on the forward's MFMA edge kernels
         c = ctx.egnn_ctx
         use_fused = kept is not None or (E > 0 and prec == _lib.PREC_BF16 and os.environ.get("EGNN_BWD_FUSED", "1") != "0")
@@ -275,6 +295,12 @@ class _EGNNFunction(torch.autograd.Function):
             c.set_graph(plan)
             c.pack(layers)
             use_fused = bool(_lib.lib().egcl_backward_fused_supported(c.handle))
+        if E > 0:
+            Wx_, Wm_ = layers[0].mlp_x[0].out_features, layers[0].mlp_m[0].out_features
+            ws = _Workspace(min(EDGE_CHUNK, E), d0["H"], Wx_, Wm_, d0["M"],
+                            torch.bfloat16 if prec == _lib.PREC_BF16 else torch.float32, gh.device,
+                            saved_activations=kept is not None,
+                            hip_gemms=use_fused and prec == _lib.PREC_BF16 and _hip_gemm_shapes(d0["H"], Wx_, Wm_, d0["M"]))
         for l in reversed(range(len(layers))):
             layer = layers[l]
             h_l, x_l, sum_m, sum_x, S = saved[5 * l:5 * l + 5]

@@ -45,3 +45,31 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, rows: int | None = None, cols: int
                                    out.stride(0), rows, cols, 1 if accumulate else 0, _lib.ptr(ws), ws.numel()))
     ws.record_stream(torch.cuda.current_stream())
     return out
+
+
+def pack_rows_weights(w: torch.Tensor, ncols: int | None = None) -> torch.Tensor:
+    """fragment pack of an fp32 [K, >= ncols] matrix for ``gemm_rows`` (K % 64 == 0, ncols <= 128)"""
+    if not w.is_cuda or w.dtype != torch.float32 or w.dim() != 2 or w.stride(1) != 1:
+        raise ValueError("pack_rows_weights: fp32 CUDA(ROCm) [K, n] matrix with unit column stride")
+    K = w.shape[0]
+    ncols = w.shape[1] if ncols is None else ncols
+    out = torch.empty(K * 128, dtype=torch.bfloat16, device=w.device)
+    _lib.check(_lib.lib().egnn_gemm_rows_pack(_lib.stream_ptr(), K, ncols, _lib.ptr(w), w.stride(0), _lib.ptr(out)))
+    return out
+
+
+def gemm_rows(a0: torch.Tensor, w0: torch.Tensor, a1: torch.Tensor | None = None, w1: torch.Tensor | None = None,
+              out: torch.Tensor | None = None) -> torch.Tensor:
+    """out[e, :128] = a0[e] @ W0 (+ a1[e] @ W1) in bf16 (fp32 accumulate), W as packed by ``pack_rows_weights``
+    (egnn_gemm_rows_bf16: every operand row is streamed once)."""
+    if not a0.is_cuda or a0.dtype != torch.bfloat16 or a0.dim() != 2 or a0.stride(1) != 1:
+        raise RuntimeError("gemm_rows needs bf16 CUDA(ROCm) row-major operands; there is no CPU fallback")
+    E = a0.shape[0]
+    if out is None:
+        out = torch.empty(E, 128, dtype=torch.bfloat16, device=a0.device)
+    if out.dtype != torch.bfloat16 or out.shape[0] < E or out.stride(1) != 1 or out.stride(0) < 128:
+        raise ValueError("gemm_rows: out must be bf16 [>= E, >= 128 columns of row stride]")
+    _lib.check(_lib.lib().egnn_gemm_rows_bf16(_lib.stream_ptr(), E, _lib.ptr(a0), a0.stride(0), a0.shape[1], _lib.ptr(w0),
+                                              _lib.ptr(a1), 0 if a1 is None else a1.stride(0), 0 if a1 is None else a1.shape[1],
+                                              _lib.ptr(w1), _lib.ptr(out), out.stride(0)))
+    return out

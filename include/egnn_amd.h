@@ -204,6 +204,15 @@ size_t egnn_gemm_tn_workspace_bytes(int E, int M, int N);
 int egnn_gemm_tn_bf16(void* stream, int E, int M, int N, const void* d_A, int lda, const void* d_B, int ldb, float scale,
                       float* d_C, int ldc, int rows, int cols, int accumulate, void* d_workspace, size_t workspace_bytes);
 
+/* First-layer dgrad of the backward (autograd through the first Linear of mlp_x / mlp_m, :13, :19): a row-streaming product
+ *     out[e][n] = sum_c A0[e][c] W0[c][n] + sum_c A1[e][c] W1[c][n],   n < 128,
+ * A0 / A1 row-major bf16 [E, lda] (dL/da1 of the two MLPs; A1 may be NULL), out bf16 [E, ldo] (128 columns written);
+ * W0 / W1 are fragment packs made by egnn_gemm_rows_pack from fp32 [K, ldw] matrices whose first ncols (<= 128) columns are
+ * used (K * 128 bf16 each).  K % 64 == 0.  Replaces torch.mm + addmm_ (round 2). */
+int egnn_gemm_rows_pack(void* stream, int K, int ncols, const float* d_W, int ldw, void* d_frags_out);
+int egnn_gemm_rows_bf16(void* stream, int E, const void* d_A0, int lda0, int K0, const void* d_W0, const void* d_A1, int lda1,
+                        int K1, const void* d_W1, void* d_out, int ldo);
+
 /* EquivariantGNN.forward(edge_index, h, x) -> (h_L, x_L) (:85-88): all L layers. */
 int egnn_forward(egnn_ctx* ctx, void* stream, int prec, int norm_scope,
                  const float* d_h, const float* d_x, float* d_h_out, float* d_x_out);
