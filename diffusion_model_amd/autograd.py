@@ -207,6 +207,40 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_
     acc(att.weight, g_wa); acc(att.bias, g_ba)
 
 
+def _node_backward_hip(layer, h_l, sum_m, gh, grads):
+    """backward of h' = mlp_h([h | sum_m]) (EquivariantGraphNeuralNetwork.py:26-30, :69) on the library's own GEMM kernels
+    (bf16 operands, fp32 accumulate and fp32 pre-activations): recompute z1 = W1 [h | sum_m] + b1, then
+        dL/ds = gh W2,  dL/dz1 = dL/ds * SiLU'(z1),  dL/d[h | sum_m] = dL/dz1 W1,
+        dL/dW2 = gh^T SiLU(z1),  dL/dW1 = dL/dz1^T [h | sum_m],  bias gradients = column sums.
+    Returns (dL/dh [N, H], dL/d sum_m [N, M]); parameter gradients are added to `grads`."""
+    from .gemm import gemm_tn, linear_rows
+    lin1, lin2 = layer.mlp_h[0], layer.mlp_h[2]
+    N, H = h_l.shape
+    M = sum_m.shape[1]
+    K1 = H + M
+    K1k, K1n = _round_up(K1, 64), _round_up(K1, 128)              # reduction width (gemm_rows) / operand width (gemm_tn)
+    bf = dict(dtype=torch.bfloat16, device=h_l.device)
+    hcat = torch.zeros(N, max(K1k, K1n), **bf)
+    hcat[:, :H] = h_l
+    hcat[:, H:K1] = sum_m
+    z1 = linear_rows(hcat, lin1.weight, k=K1k) + lin1.bias.detach()
+    sg = torch.sigmoid(z1)
+    s_act = z1 * sg
+    ghb = torch.zeros(N, 128, **bf)                               # gh as a GEMM operand: H <= 64 real columns
+    ghb[:, :H] = gh
+    g_s = linear_rows(ghb, lin2.weight.detach().t(), k=64)        # [N, Wh] = gh @ W2
+    g_z1 = g_s * (sg * (1.0 + z1 * (1.0 - sg)))
+    g_z1b, s_b = g_z1.to(torch.bfloat16), s_act.to(torch.bfloat16)
+    Wh = lin1.weight.shape[0]
+    acc = lambda p_, g_: grads.__setitem__(p_, grads.get(p_, 0) + g_)
+    acc(lin2.bias, gh.sum(0))
+    acc(lin1.bias, g_z1.sum(0))
+    acc(lin2.weight, gemm_tn(s_b, ghb, rows=Wh, cols=H).t())                     # [Wh, H]^T
+    acc(lin1.weight, gemm_tn(g_z1b, hcat, rows=Wh, cols=K1))                     # [Wh, H + M]
+    g_cat = linear_rows(g_z1b, lin1.weight.detach().t())                         # [N, H + M] = dL/dz1 @ W1
+    return g_cat[:, :H].contiguous(), g_cat[:, H:K1].contiguous()
+
+
 class _EGNNFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, owner, layers, plan, prec, scope, h, x, *params):
@@ -305,22 +339,33 @@ class _EGNNFunction(torch.autograd.Function):
             layer = layers[l]
             h_l, x_l, sum_m, sum_x, S = saved[5 * l:5 * l + 5]
             # node part
-            node_params = list(layer.mlp_h.parameters())
-            with torch.enable_grad():
-                h_leaf = h_l.detach().requires_grad_(True)
-                x_leaf = x_l.detach().requires_grad_(True)
-                am, ax = sum_m.detach().requires_grad_(True), sum_x.detach().requires_grad_(True)
-                S_leaf = S.detach().requires_grad_(True)
-                h_new = layer.mlp_h(torch.cat((h_leaf, am), dim=1))
-                x_new = x_leaf + ax * _segment_scale(S_leaf, scope_graph, node_graph)
-                outs = torch.autograd.grad([h_new, x_new], [h_leaf, x_leaf, am, ax, S_leaf] + node_params, [gh, gx],
-                                           allow_unused=True)
             zero = lambda o, like: o.clone() if o is not None else torch.zeros_like(like)
-            g_h, g_x = zero(outs[0], h_l), zero(outs[1], x_l)
-            g_am, g_ax, g_S = zero(outs[2], sum_m), zero(outs[3], sum_x), zero(outs[4], S)
-            for p, g in zip(node_params, outs[5:]):
-                if g is not None:
-                    grads[p] = grads.get(p, 0) + g
+            node_hip = (ws is not None and ws.K1P == 128 and h_l.shape[1] <= 64 and layer.mlp_h[0].weight.shape[0] % 256 == 0)
+            if node_hip:
+                # x' = x + sum_x / (G + 1) (:64, :70): element-wise, differentiated by torch; the node MLP on the own GEMMs
+                with torch.enable_grad():
+                    x_leaf = x_l.detach().requires_grad_(True)
+                    ax, S_leaf = sum_x.detach().requires_grad_(True), S.detach().requires_grad_(True)
+                    x_new = x_leaf + ax * _segment_scale(S_leaf, scope_graph, node_graph)
+                    o = torch.autograd.grad([x_new], [x_leaf, ax, S_leaf], [gx], allow_unused=True)
+                g_x, g_ax, g_S = zero(o[0], x_l), zero(o[1], sum_x), zero(o[2], S)
+                g_h, g_am = _node_backward_hip(layer, h_l, sum_m, gh, grads)
+            else:
+                node_params = list(layer.mlp_h.parameters())
+                with torch.enable_grad():
+                    h_leaf = h_l.detach().requires_grad_(True)
+                    x_leaf = x_l.detach().requires_grad_(True)
+                    am, ax = sum_m.detach().requires_grad_(True), sum_x.detach().requires_grad_(True)
+                    S_leaf = S.detach().requires_grad_(True)
+                    h_new = layer.mlp_h(torch.cat((h_leaf, am), dim=1))
+                    x_new = x_leaf + ax * _segment_scale(S_leaf, scope_graph, node_graph)
+                    outs = torch.autograd.grad([h_new, x_new], [h_leaf, x_leaf, am, ax, S_leaf] + node_params, [gh, gx],
+                                               allow_unused=True)
+                g_h, g_x = zero(outs[0], h_l), zero(outs[1], x_l)
+                g_am, g_ax, g_S = zero(outs[2], sum_m), zero(outs[3], sum_x), zero(outs[4], S)
+                for p, g in zip(node_params, outs[5:]):
+                    if g is not None:
+                        grads[p] = grads.get(p, 0) + g
             # edge part
             if E > 0:
                 _edge_backward(layer, prec, ws, h_l, x_l, dst32, src32, node_seg, g_am, g_ax, g_S.contiguous(), g_h, g_x, grads,

@@ -20,8 +20,9 @@ struct GemmRowsParams {
   int lda[2], K[2];     // K % 64 == 0 (K[1] = 0: one operand)
   const void* W[2];     // bf16 fragments [K / 64][4 k-steps][4 column blocks][64][8]: B[k = c][n]
   int E;
-  void* out;            // bf16 [E][ldo], 128 columns written
+  void* out;            // bf16 (or fp32) [E][ldo], 128 columns written
   int ldo;
+  int out_f32;          // 1: fp32 output (node MLP products, where the result feeds a nonlinearity's derivative)
 };
 
 namespace {
@@ -98,6 +99,18 @@ __global__ __launch_bounds__(kTR, 2) void gemm_rows_kernel(const GemmRowsParams 
   VM_WAIT(0);
   __builtin_amdgcn_s_barrier();                // the ring is free: reused as store staging
 #undef VM_WAIT
+  if (p.out_f32) {   // accumulator layout straight to memory: 128 contiguous bytes per half-wave and row
+    float* out = static_cast<float*>(p.out) + (size_t)(e0 + 32 * wave) * p.ldo;
+    const int nrows = p.E - (e0 + 32 * wave);
+#pragma unroll
+    for (int nb = 0; nb < kNB; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = acc_row(i, lane);
+        if (row < nrows) out[(size_t)row * p.ldo + 32 * nb + r] = acc[nb][i];
+      }
+    return;
+  }
   // ---- store: 32 rows x 128 columns per wave as row-major bf16 (two 64-column halves through the per-wave staging tile) ----
   __bf16* stg = reinterpret_cast<__bf16*>(smem) + (size_t)wave * 32 * 72;
   __bf16* out = static_cast<__bf16*>(p.out) + (size_t)(e0 + 32 * wave) * p.ldo;
@@ -157,8 +170,8 @@ int egnn_gemm_rows_pack(void* stream, int K, int ncols, const float* d_W, int ld
 }
 
 int egnn_gemm_rows_bf16(void* stream, int E, const void* d_A0, int lda0, int K0, const void* d_W0, const void* d_A1, int lda1, int K1,
-                        const void* d_W1, void* d_out, int ldo) {
-  if (E < 1 || !d_A0 || !d_W0 || !d_out || K0 < 64 || K0 % 64 != 0 || lda0 < K0 || lda0 % 8 != 0 || ldo < 128 || ldo % 8 != 0 ||
+                        const void* d_W1, void* d_out, int ldo, int out_f32) {
+  if (E < 1 || !d_A0 || !d_W0 || !d_out || K0 < 64 || K0 % 64 != 0 || lda0 < K0 || lda0 % 8 != 0 || ldo < 128 || ldo % 4 != 0 ||
       (d_A1 && (!d_W1 || K1 < 64 || K1 % 64 != 0 || lda1 < K1 || lda1 % 8 != 0))) {
     set_error("egnn_gemm_rows_bf16: unsupported shape E=%d K0=%d K1=%d", E, K0, K1);
     return EGNN_EINVAL;
@@ -170,7 +183,7 @@ int egnn_gemm_rows_bf16(void* stream, int E, const void* d_A0, int lda0, int K0,
   GemmRowsParams p;
   p.A[0] = d_A0; p.lda[0] = lda0; p.K[0] = K0; p.W[0] = d_W0;
   p.A[1] = d_A1; p.lda[1] = d_A1 ? lda1 : 0; p.K[1] = d_A1 ? K1 : 0; p.W[1] = d_A1 ? d_W1 : nullptr;
-  p.E = E; p.out = d_out; p.ldo = ldo;
+  p.E = E; p.out = d_out; p.ldo = ldo; p.out_f32 = out_f32 ? 1 : 0;
   return launch_gemm_rows(p, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -211,7 +211,7 @@ int egnn_gemm_tn_bf16(void* stream, int E, int M, int N, const void* d_A, int ld
  * used (K * 128 bf16 each).  K % 64 == 0.  Replaces torch.mm + addmm_ (round 2). */
 int egnn_gemm_rows_pack(void* stream, int K, int ncols, const float* d_W, int ldw, void* d_frags_out);
 int egnn_gemm_rows_bf16(void* stream, int E, const void* d_A0, int lda0, int K0, const void* d_W0, const void* d_A1, int lda1,
-                        int K1, const void* d_W1, void* d_out, int ldo);
+                        int K1, const void* d_W1, void* d_out, int ldo, int out_f32);   /* out_f32: fp32 [E, ldo] output */
 
 /* EquivariantGNN.forward(edge_index, h, x) -> (h_L, x_L) (:85-88): all L layers. */
 int egnn_forward(egnn_ctx* ctx, void* stream, int prec, int norm_scope,
