@@ -243,7 +243,10 @@ int launch_edge_dgrad(int N, int E, const int* dst, const int* src, const float*
   p.N = N; p.E = E; p.edge_dst = dst; p.edge_src = src; p.x = x; p.table = table; p.TC = TC; p.offP = offP; p.offQ = offQ;
   p.wd = wd; p.g_a2 = g_a2; p.Kd = Kd; p.w2t = w2t; p.KP = KP; p.g_a1_out = g_a1_out;
   const int tiles = (E + kRD - 1) / kRD;
-  if (KP >= 512) hipLaunchKernelGGL(edge_dgrad_kernel<2>, dim3(tiles * (KP / 512)), dim3(kTD), kSmemD, st, p);
+  // 512-column workgroups (one per CU) for the long reduction of mlp_x; the message branch reduces over 256 only (4 chunks):
+  // its workgroup is mostly prologue + SiLU' epilogue, so 256-column workgroups at <= 128 VGPRs, TWO per CU, let one's
+  // epilogue run under the other's K loop
+  if (KP >= 512 && Kd > 256) hipLaunchKernelGGL(edge_dgrad_kernel<2>, dim3(tiles * (KP / 512)), dim3(kTD), kSmemD, st, p);
   else hipLaunchKernelGGL(edge_dgrad_kernel<1>, dim3(tiles * (KP / 256)), dim3(kTD), kSmemD, st, p);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
