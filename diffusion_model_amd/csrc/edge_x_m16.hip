@@ -123,35 +123,36 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
   __syncthreads();
 
   // matrix phase of chunk c: 2 k-steps x (8 row blocks x 4 column blocks).  Operand pipeline as in edge_bf16_v3.hip: the
-  // A pieces by inline-asm ds_read_b128 (hipcc sinks compiler-visible LDS reads to their use) through a ring of 4 register
-  // sets, each refilled in place for the use 4 row blocks later right after its MFMAs were issued; LDS returns in order,
-  // so lgkmcnt(3) before a use means "all but the 3 younger reads have landed".  The weight fragments of k-step s of chunk c + 1 are requested after the MFMAs of
+  // A pieces by inline-asm ds_read_b128 (hipcc sinks compiler-visible LDS reads to their use) through a ring of 3 register
+  // sets, each refilled in place for the use 3 row blocks later right after its MFMAs were issued; LDS returns in order,
+  // so lgkmcnt(2) before a use means "all but the 2 younger reads have landed".  The weight fragments of k-step s of chunk c + 1 are requested after the MFMAs of
   // k-step s of chunk c (a whole chunk of distance).
   auto mphase = [&](const int c, const bool last) {
     const unsigned boff = (unsigned)(c & 1) * (unsigned)kA1;
     const unsigned ab0 = abase0 + boff, ab1 = abase1 + boff;
-    bf16x8 a[4];   // ring of 4 operand pieces: use u = 8 s + rb takes a[u & 3], which is refilled for use u + 4 right after
+    bf16x8 a[3];   // ring of 3 operand pieces: use u = 8 s + rb takes a[u % 3], which is refilled for use u + 3 right after
+                   // (a fourth set costs the 4 registers that made hipcc spill around the K loop: 63 MB of scratch traffic per launch)
 #define LDS_RD(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(off))
 #define LDS_WAIT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
-    LDS_RD(a[0], ab0, 0); LDS_RD(a[1], ab0, 256); LDS_RD(a[2], ab0, 512); LDS_RD(a[3], ab0, 768);
+    LDS_RD(a[0], ab0, 0); LDS_RD(a[1], ab0, 256); LDS_RD(a[2], ab0, 512);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
 #pragma unroll
       for (int rb = 0; rb < 8; ++rb) {
         const int u = 8 * s + rb;
-        if (u <= 12) LDS_WAIT(3);
-        else if (u == 13) LDS_WAIT(2);
+        if (u <= 13) LDS_WAIT(2);
         else if (u == 14) LDS_WAIT(1);
         else LDS_WAIT(0);
-        asm volatile("" : "+v"(a[u & 3]));   // uses of the piece stay below the wait
+        asm volatile("" : "+v"(a[u % 3]));   // uses of the piece stay below the wait
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
-          acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u & 3], bq[s][cb], acc[rb][cb], 0, 0, 0);
-        // refill in place for use u + 4 (the MFMAs above have read the registers at issue)
-        if (u == 0) LDS_RD(a[0], ab0, 1024); if (u == 1) LDS_RD(a[1], ab0, 1280); if (u == 2) LDS_RD(a[2], ab0, 1536);
-        if (u == 3) LDS_RD(a[3], ab0, 1792); if (u == 4) LDS_RD(a[0], ab1, 0); if (u == 5) LDS_RD(a[1], ab1, 256);
-        if (u == 6) LDS_RD(a[2], ab1, 512); if (u == 7) LDS_RD(a[3], ab1, 768); if (u == 8) LDS_RD(a[0], ab1, 1024);
-        if (u == 9) LDS_RD(a[1], ab1, 1280); if (u == 10) LDS_RD(a[2], ab1, 1536); if (u == 11) LDS_RD(a[3], ab1, 1792);
+          acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u % 3], bq[s][cb], acc[rb][cb], 0, 0, 0);
+        // refill in place for use u + 3 (the MFMAs above have read the registers at issue): row block (u + 3) & 7 of k-step (u + 3) >> 3
+        if (u == 0) LDS_RD(a[0], ab0, 768); if (u == 1) LDS_RD(a[1], ab0, 1024); if (u == 2) LDS_RD(a[2], ab0, 1280);
+        if (u == 3) LDS_RD(a[0], ab0, 1536); if (u == 4) LDS_RD(a[1], ab0, 1792); if (u == 5) LDS_RD(a[2], ab1, 0);
+        if (u == 6) LDS_RD(a[0], ab1, 256); if (u == 7) LDS_RD(a[1], ab1, 512); if (u == 8) LDS_RD(a[2], ab1, 768);
+        if (u == 9) LDS_RD(a[0], ab1, 1024); if (u == 10) LDS_RD(a[1], ab1, 1280); if (u == 11) LDS_RD(a[2], ab1, 1536);
+        if (u == 12) LDS_RD(a[0], ab1, 1792);
       }
       if (!last) {
         const unsigned ksn = (unsigned)((c + 1) * 2 + s) * 1024u;
