@@ -237,15 +237,29 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
       __builtin_amdgcn_wave_barrier();
     }
   }
+  // SiLU and the w3 product on register PAIRS (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32: two elements per issue slot; only
+  // the transcendentals stay scalar).  Packed fp32 is an anti-lever beside MFMAs, but the epilogue has none.
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
 #pragma unroll
   for (int cb = 0; cb < 4; ++cb) {
     const int n = 16 * (cb0 + cb) + r15;
     const float bb = p.b2x[n], w = p.w3x[n];
+    const f32x2 bb2 = {bb, bb}, w2 = {w, w}, k2 = {kNegLog2e, kNegLog2e}, one2 = {1.0f, 1.0f};
 #pragma unroll
     for (int rb = 0; rb < 8; ++rb)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        part[rb * 4 + i] = fmaf(w, silu_s(SAVE ? acc[rb][cb][i] : fmaf(acc[rb][cb][i], kNegLog2e, bb)), part[rb * 4 + i]);
+      for (int i = 0; i < 4; i += 2) {
+        const f32x2 a2 = {acc[rb][cb][i], acc[rb][cb][i + 1]};
+        const f32x2 t = SAVE ? a2 : __builtin_elementwise_fma(a2, k2, bb2);
+        const f32x2 e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+        const f32x2 d = e + one2;
+        const f32x2 rr = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+        const f32x2 sv = t * rr;
+        f32x2 pp = {part[rb * 4 + i], part[rb * 4 + i + 1]};
+        pp = __builtin_elementwise_fma(w2, sv, pp);
+        part[rb * 4 + i] = pp.x;
+        part[rb * 4 + i + 1] = pp.y;
+      }
   }
   {
     float t0, t1;
