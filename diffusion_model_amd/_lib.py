@@ -45,6 +45,8 @@ SIGNATURES = {
     "egnn_gemm_tn_bf16": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _f, _vp, _i, _i, _i, _i, _vp, C.c_size_t]),
     "egnn_gemm_rows_pack": (_i, [_vp, _i, _i, _vp, _i, _vp]),
     "egnn_gemm_rows_bf16": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i]),
+    "egnn_gamma_tilde": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "egnn_dense_rows": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "egnn_eps": (_i, [_vp, _i, _i, _i, _vp, _i] + [_vp] * 5),
     "egnn_remove_mean": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
     "schedule_table_build": (_i, [_i, C.c_double, C.c_double, _fp, _fp, _fp]),

@@ -1,6 +1,9 @@
 """Learned noise schedule gamma(t) with the reference's parameter names (SNR.py:5-64).  It is
 tabulated over the T+1 grid once per parameter version (diffusion.E3DiffusionProcess), so it never
-sits on the per-step path; its three tiny dense layers use torch ops."""
+sits on the per-step path.  On the GPU gamma_tilde runs in the library's kernel (egnn_gamma_tilde); the
+softplus-positive weights carry no gradient in the reference (PositiveLinear wraps them in a fresh
+Parameter), so only the final affine map to [gamma_0, gamma_1] is under autograd either way.  CPU tensors (host-side
+tabulation, CPU tests) use torch ops."""
 import math
 
 import torch
@@ -40,8 +43,22 @@ class GammaNetwork(nn.Module):
         l1_t = self.l1(t)
         return l1_t + self.l3(torch.sigmoid(self.l2(l1_t)))
 
+    def _gamma_tilde_device(self, t):
+        """gamma_tilde of [t | 0 | 1] in one launch of the library's kernel (t [n, 1] on the GPU) -> (gt [n,1], g0, g1)"""
+        from . import _lib
+        n = t.shape[0]
+        pts = torch.cat((t.detach().reshape(-1).float(), torch.tensor([0.0, 1.0], device=t.device))).contiguous()
+        out = torch.empty(n + 2, device=t.device)
+        w1, w2, w3 = (m.weight.detach().float().contiguous().reshape(-1) for m in (self.l1, self.l2, self.l3))
+        _lib.check(_lib.lib().egnn_gamma_tilde(_lib.stream_ptr(), n + 2, w2.numel(), _lib.ptr(pts), _lib.ptr(w1), _lib.ptr(w2),
+                                               _lib.ptr(w3), _lib.ptr(out)))
+        return out[:n].view(n, 1), out[n], out[n + 1]
+
     def forward(self, t):
-        g0 = self.gamma_tilde(torch.zeros_like(t))
-        g1 = self.gamma_tilde(torch.ones_like(t))
-        gt = self.gamma_tilde(t)
+        if t.is_cuda and t.dim() == 2 and t.shape[1] == 1 and self.l2.weight.is_cuda:
+            gt, g0, g1 = self._gamma_tilde_device(t)
+        else:
+            g0 = self.gamma_tilde(torch.zeros_like(t))
+            g1 = self.gamma_tilde(torch.ones_like(t))
+            gt = self.gamma_tilde(t)
         return self.gamma_0 + (self.gamma_1 - self.gamma_0) * ((gt - g0) / (g1 - g0))

@@ -318,6 +318,17 @@ int egnn_rdf(void* stream, int B, const float* d_pos, const int32_t* d_graph_ptr
 int egnn_si_o_si(void* stream, int B, int A, const float* d_pos, const int32_t* d_onehot,
                  const int32_t* d_graph_ptr, float cutoff, float* d_out);
 
+/* ---- the two small networks at the edge of the path ---------------------------------------------------
+ * gamma_tilde(t_i) = l1(t_i) + l3(sigmoid(l2(l1(t_i)))) of GammaNetwork (SNR.py:50-52) with PositiveLinear's softplus weights
+ * (:5-22) for n time points; d_l1_w [1], d_l2_w [hidden], d_l3_w [hidden] are the RAW parameters (l1.weight, l2.weight,
+ * l3.weight).  The caller normalises with gamma_tilde(0), gamma_tilde(1) and rescales to [gamma_0, gamma_1] (:54-64). */
+int egnn_gamma_tilde(void* stream, int n, int hidden, const float* d_t, const float* d_l1_w, const float* d_l2_w,
+                     const float* d_l3_w, float* d_out);
+/* One Linear (+ ReLU) over node rows: out [N, J] = act(in [N, K] . W^T + b), W in nn.Linear layout [J, K]
+ * (SpectrumCompressor, DataPreprocessor.py:10-19, layer by layer). */
+int egnn_dense_rows(void* stream, int N, int K, int J, const float* d_in, const float* d_W, const float* d_b, int relu,
+                    float* d_out);
+
 /* timing helper for bench.py: average duration (ms) of the fused edge kernel over the launches
  * recorded since the last reset, measured with HIP events on the launch stream. */
 /* diagnostic builds only (-DEGNN_EXP_STAMP): s_memtime stamps [2][8][32][4] of one edge workgroup */

@@ -347,3 +347,35 @@ def test_gemm_rows_matches_fp64_reference(E, K0, K1, ncols):
     print(f"gemm_rows E={E} K={K0}+{K1} n={ncols}: max err / max |out| = {err:.2e}")
     assert err <= 6e-3                                     # bf16 output rounding
     assert float(out[:, ncols:].abs().max()) == 0.0 if ncols < 128 else True
+
+
+def test_gamma_network_and_compressor_device_kernels_match_reference_golden():
+    """a18 / a19 on the device: GammaNetwork's gamma_tilde in egnn_gamma_tilde and SpectrumCompressor's ReLU MLP in
+    egnn_dense_rows against the outputs of the reference modules executed by make_golden.py (aux_golden.npz).  gamma: 2e-3
+    absolute (the reference's own fp32 evaluation moves by 5e-4 with the host's thread count, see the learned-schedule test);
+    compressor 1e-5."""
+    G = load_golden("aux_golden.npz")
+    g = dma.GammaNetwork()
+    g.load_state_dict({k[len("gamma.W."):]: torch.from_numpy(G[k]) for k in G.files if k.startswith("gamma.W.")})
+    g.to(DEV)
+    t = torch.from_numpy(G["gamma.t"]).to(DEV)
+    with torch.no_grad():
+        out = g(t)
+    assert out.shape == t.shape
+    assert float((out.cpu() - torch.from_numpy(G["gamma.out"])).abs().max()) <= 2e-3
+    # the affine map to [gamma_0, gamma_1] stays under autograd (the only trainable part, SURVEY Q7)
+    out2 = g(t)
+    out2.sum().backward()
+    assert g.gamma_0.grad is not None and g.gamma_1.grad is not None and g.l2.weight.grad is None
+    c = dma.SpectrumCompressor(200, [150, 100, 50], 32)
+    c.load_state_dict({k[len("comp.W."):]: torch.from_numpy(G[k]) for k in G.files if k.startswith("comp.W.")})
+    c.to(DEV).eval()
+    x = torch.from_numpy(G["comp.in"]).to(DEV)
+    with torch.no_grad():
+        outc = c(x)
+    assert max_rel(outc.cpu(), torch.from_numpy(G["comp.out"])) <= 1e-5
+    big = torch.rand(1000, 200, generator=torch.Generator().manual_seed(3)).to(DEV)      # rows not a multiple of the 16-row tile
+    with torch.no_grad():
+        got = c(big)
+    want = c.mlp(big)                                                                     # torch ops (autograd path)
+    assert max_rel(got.cpu(), want.detach().cpu()) <= 1e-5
