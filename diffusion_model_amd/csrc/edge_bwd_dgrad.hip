@@ -46,8 +46,34 @@ struct DgradParams {
 // CB = 32-column blocks per wave: 2 = 512 output columns per workgroup (252 VGPRs, one workgroup per CU); 1 = 256 columns
 // (<= 128 VGPRs, TWO workgroups per CU: one's SiLU' epilogue runs under the other's K loop; the dL/da2 tile is then
 // copied by four workgroups instead of two, which costs L2 reads only -- there is no vector arithmetic to duplicate).
-template <int CB>
-__global__ __launch_bounds__(kTD, (CB == 1 ? 4 : 2)) void edge_dgrad_kernel(const DgradParams p) {
+#ifdef EGNN_EXP_DGSTAMP   // diagnostic build only (tools/dgrad_stamps.py): 100 MHz wall stamps of EVERY workgroup's phases + where it ran
+__device__ unsigned long long g_dg_stamps[2][40000][12];
+#define DG_STAMP(k)                                                                                   \
+  do {                                                                                                \
+    unsigned long long t_;                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    if (tid == 0 && blockIdx.x < 40000) g_dg_stamps[CB == 2 ? 0 : 1][blockIdx.x][k] = t_;             \
+  } while (0)
+#else
+#define DG_STAMP(k)
+#endif
+
+// NW = waves per workgroup (8 = 512 threads; 4 = 256 threads, 128 edges x 256 columns at CB = 2, TWO independent workgroups per
+// CU with one wave per SIMD each: the form that is launched).  What the timing builds of this file and the per-workgroup
+// stamps say at C4 shapes (tools/dgrad_ab.sh, tools/dgrad_stamps.py):
+//   * 8-wave form: K loop alone 1.94 ms (0.45 of the MFMA peak, as the forward's), prologue + SiLU' epilogue alone 1.30 ms
+//     (nothing to hide under inside its own workgroup), together 2.74 ms; dL/da2 served from L2 instead of HBM 2.46 ms (real
+//     data: with a zero-size descriptor the zeros also raise the clock), table loads answered at once 2.72 ms;
+//   * 4-wave form: the pair of workgroups of a CU settles in opposite phase by itself (a forced half-period offset changed
+//     nothing); per workgroup: prologue 3.9 us, K loop 19.8 us, epilogue 14.1 us (19.2 us while its d^2 weights were re-read
+//     from global memory behind every store; packed fp32 arithmetic alone changed nothing: the epilogue wave competes for
+//     issue with the partner workgroup's MFMA wave and runs at ~40 % of its own issue rate).
+template <int CB, int NW>
+__global__ __launch_bounds__(64 * NW, (CB == 1 ? 4 : 2)) void edge_dgrad_kernel(const DgradParams p) {
+  constexpr int PP = 1024 / (64 * NW);   // 16-byte pieces of an A chunk per thread
+  constexpr int NSET = NW == 8 ? 3 : 2;  // register sets of pieces in flight
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* s_dst = reinterpret_cast<int*>(smem + kOffDstD);
   int* s_src = reinterpret_cast<int*>(smem + kOffSrcD);
@@ -56,7 +82,15 @@ __global__ __launch_bounds__(kTD, (CB == 1 ? 4 : 2)) void edge_dgrad_kernel(cons
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, hh = lane >> 5;
-  const int nsplit = p.KP / (256 * CB);
+  DG_STAMP(0);
+  // the epilogue's kernel arguments are fetched with everything else at the start (left to the compiler their scalar loads
+  // sit in front of the epilogue: one more exposed memory latency per workgroup)
+  const float* wd_ptr = p.wd;
+  const void* tab_ptr = p.table;
+  void* out_ptr = p.g_a1_out;
+  unsigned tab_bytes = (unsigned)((size_t)p.N * p.TC * 2);
+  asm volatile("" : "+s"(wd_ptr), "+s"(tab_ptr), "+s"(out_ptr), "+s"(tab_bytes));
+  const int nsplit = p.KP / (32 * NW * CB);
   const int j = xcd_tile(blockIdx.x, gridDim.x);
   const int tile = j / nsplit, half = j - tile * nsplit;
   const int e0 = tile * kRD;
@@ -76,17 +110,33 @@ __global__ __launch_bounds__(kTD, (CB == 1 ? 4 : 2)) void edge_dgrad_kernel(cons
     s_src[tid] = (int)(((unsigned)s * (unsigned)p.TC + (unsigned)p.offQ) * 2u);
     s_d2[tid] = dd;
   }
+#ifdef EGNN_EXP_DG_NOK   // timing experiment: two chunks of K loop only (prologue + epilogue time)
+  const int NC = 2, KS = p.Kd / 16;
+#else
   const int NC = p.Kd / kKCD, KS = p.Kd / 16;
-  const int brow = tid >> 3, kg = tid & 7;   // this thread copies rows brow and brow + 64, k-group kg of every chunk
+#endif
+  const int brow = tid >> 3, kg = tid & 7;   // this thread copies rows brow + 8 NW i (i < PP), k-group kg of every chunk
+#ifdef EGNN_EXP_DG_NOG   // timing experiments only (tools/exp_build.sh): zero-size descriptors = loads that never leave the CU
+  const rsrc_t rs_g = make_rsrc(p.g_a2, 0u);
+#else
   const rsrc_t rs_g = make_rsrc(p.g_a2, (unsigned)((size_t)p.E * p.Kd * 2));   // rows past the chunk read as zero
+#endif
+#ifdef EGNN_EXP_DG_NOW
+  const rsrc_t rs_w = make_rsrc(p.w2t, 0u);
+#else
   const rsrc_t rs_w = make_rsrc(p.w2t, (unsigned)((size_t)p.KP * p.Kd * 2));
+#endif
+#ifdef EGNN_EXP_DG_L2G   // timing experiment: every tile streams tile 0's rows (real data, served from L2)
+  const unsigned vrow0 = (unsigned)(brow) * (unsigned)p.Kd * 2u + (unsigned)kg * 16u;
+#else
   const unsigned vrow0 = (unsigned)(e0 + brow) * (unsigned)p.Kd * 2u + (unsigned)kg * 16u;
-  const unsigned vrow1 = vrow0 + 64u * (unsigned)p.Kd * 2u;
+#endif
+  const unsigned vstep = (unsigned)(8 * NW) * (unsigned)p.Kd * 2u;
   char* slot0 = s_a1 + ((size_t)kg * kRPADD + brow) * 16;
-  char* slot1 = slot0 + 64 * 16;
+  constexpr unsigned kSlotStep = 8 * NW * 16;
   const unsigned lane16 = lane * 16u;
   const unsigned lds_a1_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(s_a1 + ((size_t)hh * kRPADD + r) * 16);
-  const int colblk0 = half * 8 * CB + wave * CB;
+  const int colblk0 = half * NW * CB + wave * CB;
   const unsigned w0off = (unsigned)colblk0 * KS * 1024u;
 
   f32x16 acc[kRBD][CB];
@@ -104,21 +154,25 @@ __global__ __launch_bounds__(kTD, (CB == 1 ? 4 : 2)) void edge_dgrad_kernel(cons
   // dL/da2 streams from HBM (no reuse beyond the column-share workgroups): a piece is requested THREE chunks (~3 us of
   // K loop) before it is written to the ring -- round 2 kept one chunk of distance, which covers an L2 hit but not an HBM
   // miss under load: 40 % of the wave cycles were spent parked at the wait in front of the LDS store (profiles/r03h).
-  bf16x8 g0 = gload(vrow0, 0), g1 = gload(vrow1, 0);
-  *reinterpret_cast<bf16x8*>(slot0) = g0;
-  *reinterpret_cast<bf16x8*>(slot1) = g1;
-  g0 = gload(vrow0, 1); g1 = gload(vrow1, 1);
-  *reinterpret_cast<bf16x8*>(slot0 + kA1D) = g0;
-  *reinterpret_cast<bf16x8*>(slot1 + kA1D) = g1;
-  bf16x8 ga0 = gload(vrow0, 2), ga1 = gload(vrow1, 2);   // register sets A, B, C: chunks 2, 3, 4
-  bf16x8 gb0 = gload(vrow0, 3), gb1 = gload(vrow1, 3);
-  bf16x8 gc0 = gload(vrow0, 4), gc1 = gload(vrow1, 4);
+  bf16x8 gs[NSET][PP];
+#pragma unroll
+  for (int c0 = 0; c0 < 2; ++c0) {
+#pragma unroll
+    for (int i = 0; i < PP; ++i) gs[0][i] = gload(vrow0 + i * vstep, c0);
+#pragma unroll
+    for (int i = 0; i < PP; ++i) *reinterpret_cast<bf16x8*>(slot0 + i * kSlotStep + c0 * kA1D) = gs[0][i];
+  }
+#pragma unroll
+  for (int q = 0; q < NSET; ++q)   // register sets: chunks 2 .. 1 + NSET
+#pragma unroll
+    for (int i = 0; i < PP; ++i) gs[q][i] = gload(vrow0 + i * vstep, 2 + q);
   bf16x8 bq[4][CB];
 #pragma unroll
   for (int s = 0; s < 4; ++s)
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) bq[s][cb] = ldbuf_bf16x8(rs_w, lane16, w0off + ((unsigned)cb * KS + s) * 1024u);
   __syncthreads();
+  DG_STAMP(1);
 
   unsigned off_cur = 0u, off_nxt = (unsigned)kA1D, off_wr = 2u * (unsigned)kA1D;
   bf16x8 a[kRBD];
@@ -127,7 +181,7 @@ __global__ __launch_bounds__(kTD, (CB == 1 ? 4 : 2)) void edge_dgrad_kernel(cons
   LDS_RD(a[0], lds_a1_base, 0); LDS_RD(a[1], lds_a1_base, 512); LDS_RD(a[2], lds_a1_base, 1024); LDS_RD(a[3], lds_a1_base, 1536);
 
   // chunk c: multiply it; `copy`: write chunk c + 2 (register set x0 / x1) to the ring and request chunk c + 5 into the set
-  auto chunk = [&](const int c, const bool copy, const bool last, bf16x8& x0, bf16x8& x1) {
+  auto chunk = [&](const int c, const bool copy, const bool last, bf16x8 (&xs)[PP]) {
     const unsigned abase = lds_a1_base + off_cur, nbase = lds_a1_base + off_nxt;
 #define GROUP(S, RB)                                                                                          \
     {                                                                                                         \
@@ -143,8 +197,11 @@ __global__ __launch_bounds__(kTD, (CB == 1 ? 4 : 2)) void edge_dgrad_kernel(cons
     }
 #define KSTEP(S)                                                                                              \
     GROUP(S, 0) GROUP(S, 1) GROUP(S, 2) GROUP(S, 3)                                                           \
-    if (copy && (S) == 1) { *reinterpret_cast<bf16x8*>(slot0 + off_wr) = x0; x0 = gload(vrow0, c + 5); }      \
-    if (copy && (S) == 3) { *reinterpret_cast<bf16x8*>(slot1 + off_wr) = x1; x1 = gload(vrow1, c + 5); }      \
+    if (copy && ((S) % (4 / PP)) == 4 / PP - 1) {                                                             \
+      constexpr int pi = (S) / (4 / PP);                                                                      \
+      *reinterpret_cast<bf16x8*>(slot0 + pi * kSlotStep + off_wr) = xs[pi];                                   \
+      xs[pi] = gload(vrow0 + pi * vstep, c + 2 + NSET);                                                       \
+    }                                                                                                         \
     if (!last) {                                                                                              \
       const unsigned ksn = (unsigned)((c + 1) * 4 + (S)) * 1024u;                                             \
       _Pragma("unroll") for (int cb = 0; cb < CB; ++cb)                                                       \
@@ -156,20 +213,21 @@ __global__ __launch_bounds__(kTD, (CB == 1 ? 4 : 2)) void edge_dgrad_kernel(cons
     const unsigned tmp = off_cur; off_cur = off_nxt; off_nxt = off_wr; off_wr = tmp;
   };
   {
-    const int ncopy = NC - 2;   // chunks that still write the ring; the register sets rotate A, B, C (static names: an
-    int c = 0;                  // indexed array of sets would live in scratch)
-    for (; c + 3 <= ncopy; c += 3) {
-      chunk(c, true, false, ga0, ga1); __syncthreads();
-      chunk(c + 1, true, false, gb0, gb1); __syncthreads();
-      chunk(c + 2, true, false, gc0, gc1); __syncthreads();
+    const int ncopy = NC - 2;   // chunks that still write the ring; the register sets rotate (static indices: an indexed
+    int c = 0;                  // array of sets would live in scratch)
+    for (; c + NSET <= ncopy; c += NSET) {
+#pragma unroll
+      for (int q = 0; q < NSET; ++q) { chunk(c + q, true, false, gs[q]); __syncthreads(); }
     }
-    if (c < ncopy) { chunk(c, true, false, ga0, ga1); __syncthreads(); ++c; }
-    if (c < ncopy) { chunk(c, true, false, gb0, gb1); __syncthreads(); ++c; }
+#pragma unroll
+    for (int q = 0; q < NSET - 1; ++q)
+      if (c < ncopy) { chunk(c, true, false, gs[q]); __syncthreads(); ++c; }
   }
-  chunk(NC - 2, false, false, ga0, ga1);
+  chunk(NC - 2, false, false, gs[0]);
   __syncthreads();
-  chunk(NC - 1, false, true, ga0, ga1);
+  chunk(NC - 1, false, true, gs[0]);
   __syncthreads();
+  DG_STAMP(2);
 #undef LDS_WAIT
 #undef LDS_RD
 
@@ -180,55 +238,110 @@ __global__ __launch_bounds__(kTD, (CB == 1 ? 4 : 2)) void edge_dgrad_kernel(cons
   // gathers per accumulator element (round 2: 256 scalar-width vector-memory instructions per wave and row block, the
   // epilogue as long as the K loop).  SiLU' is applied on the row-major values; the table entries are added in fp16 as the
   // forward adds them (same a1 bit for bit).
-  const rsrc_t rs_tab = make_rsrc(p.table, (unsigned)((size_t)p.N * p.TC * 2));
+#ifdef EGNN_EXP_DG_NOTAB
+  const rsrc_t rs_tab = make_rsrc(p.table, 0u);
+#elif defined(EGNN_EXP_DG_NOEPI)   // timing experiment: K loop only, one value per lane stored so that nothing is dropped
+  {
+    float sum = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < kRBD; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sum += acc[rb][cb][i];
+    if (sum == 123.456f) static_cast<__bf16*>(p.g_a1_out)[tid] = (__bf16)sum;
+    return;
+  }
+  const rsrc_t rs_tab = make_rsrc(p.table, 0u);
+#else
+  const rsrc_t rs_tab = make_rsrc(tab_ptr, tab_bytes);
+#endif
   __bf16* stg = reinterpret_cast<__bf16*>(s_a1) + (size_t)wave * 32 * 72;
-  __bf16* gout = static_cast<__bf16*>(p.g_a1_out) + (size_t)e0 * p.KP + 32 * colblk0;
+  __bf16* gout = static_cast<__bf16*>(out_ptr) + (size_t)e0 * p.KP + 32 * colblk0;
   constexpr int kPieces = CB * 4;            // 16-byte pieces per row of this wave's block
   constexpr int kPer = 32 * kPieces / 64;    // pieces per lane and row block
+  static_assert(64 % kPieces == 0, "a lane keeps the same 8 columns in every piece it handles");
+  // A lane's pieces all cover the same 8 columns (seg = lane % kPieces): their d^2 weights are loaded ONCE.  (Loaded next to
+  // their use they were re-read from global memory behind every store -- the stores may alias them for all the compiler
+  // knows -- i.e. 16 exposed load latencies per wave: the epilogue took 19 us against 17 us of K loop, tools/dgrad_stamps.py.)
+  const int seg = lane % kPieces, row0 = lane / kPieces;
+  const int col0 = 32 * colblk0 + 8 * seg;
+  const unsigned cbyte = 2u * (unsigned)col0;
+  const f32x4 w0 = *reinterpret_cast<const f32x4*>(wd_ptr + col0), w1 = *reinterpret_cast<const f32x4*>(wd_ptr + col0 + 4);
+  // first-layer table rows of row block rb + 1 are requested before row block rb is worked on (two register sets)
+  f16x8 tp[2][kPer], tq[2][kPer];
+  auto tload = [&](const int rb, f16x8 (&xp)[kPer], f16x8 (&xq)[kPer]) {
+#pragma unroll
+    for (int t = 0; t < kPer; ++t) {
+      const int row = row0 + (64 / kPieces) * t;
+      xp[t] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_tab, (unsigned)s_dst[32 * rb + row] + cbyte, 0, 0));
+      xq[t] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_tab, (unsigned)s_src[32 * rb + row] + cbyte, 0, 0));
+    }
+  };
+  tload(0, tp[0], tq[0]);
 #pragma unroll
   for (int rb = 0; rb < kRBD; ++rb) {
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) stg[acc_row(i, lane) * 72 + 32 * cb + r] = (__bf16)acc[rb][cb][i];
+    if (rb + 1 < kRBD) tload(rb + 1, tp[(rb + 1) & 1], tq[(rb + 1) & 1]);
     __builtin_amdgcn_wave_barrier();
-    f16x8 tp[kPer], tq[kPer];
+    if (rb == 0) DG_STAMP(6);
+    if (rb == 1) DG_STAMP(9);
 #pragma unroll
     for (int t = 0; t < kPer; ++t) {
-      const int q = lane + 64 * t, row = q / kPieces, seg = q - row * kPieces;
-      const unsigned cbyte = 2u * (unsigned)(32 * colblk0 + 8 * seg);
-      tp[t] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_tab, (unsigned)s_dst[32 * rb + row] + cbyte, 0, 0));
-      tq[t] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_tab, (unsigned)s_src[32 * rb + row] + cbyte, 0, 0));
-    }
-#pragma unroll
-    for (int t = 0; t < kPer; ++t) {
-      const int q = lane + 64 * t, row = q / kPieces, seg = q - row * kPieces;
-      const int grow = 32 * rb + row, col0 = 32 * colblk0 + 8 * seg;
-      const f32x4 w0 = *reinterpret_cast<const f32x4*>(p.wd + col0), w1 = *reinterpret_cast<const f32x4*>(p.wd + col0 + 4);
+      const int row = row0 + (64 / kPieces) * t;
+      const int grow = 32 * rb + row;
       const float d2 = s_d2[grow];
       const bf16x8 g = *reinterpret_cast<const bf16x8*>(stg + row * 72 + 8 * seg);
-      const f16x8 a1 = tp[t] + tq[t];
+      const f16x8 a1 = tp[rb & 1][t] + tq[rb & 1][t];
+      // g * SiLU'(a1) on register PAIRS (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: two elements per issue slot, only exp2 and
+      // rcp stay scalar)
+      typedef __attribute__((ext_vector_type(2))) float f32x2;
+      const f32x2 one2 = {1.0f, 1.0f}, k2 = {kNegInvLog2e, kNegInvLog2e};
       bf16x8 o;
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        float sv, ds;
-        silu_grad_s(fmaf(w0[jj], d2, (float)a1[jj]), sv, ds);
-        o[jj] = (__bf16)((float)g[jj] * ds);
-        silu_grad_s(fmaf(w1[jj], d2, (float)a1[jj + 4]), sv, ds);
-        o[jj + 4] = (__bf16)((float)g[jj + 4] * ds);
+      for (int jj = 0; jj < 8; jj += 2) {
+        const float wa = jj < 4 ? w0[jj] : w1[jj - 4], wb = jj < 4 ? w0[jj + 1] : w1[jj - 3];
+        const f32x2 t2 = {fmaf(wa, d2, (float)a1[jj]), fmaf(wb, d2, (float)a1[jj + 1])};
+        const f32x2 e = {__builtin_amdgcn_exp2f(t2.x), __builtin_amdgcn_exp2f(t2.y)};
+        const f32x2 den = e + one2;
+        const f32x2 sg = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+        const f32x2 sv = (t2 * k2) * sg;                                    // SiLU(a1)
+        const f32x2 ds = __builtin_elementwise_fma(sv, one2 - sg, sg);      // SiLU'(a1) = sig + s (1 - sig)
+        const f32x2 gg = {(float)g[jj], (float)g[jj + 1]};
+        const f32x2 r2 = gg * ds;
+        o[jj] = (__bf16)r2.x;
+        o[jj + 1] = (__bf16)r2.y;
       }
       if (grow < nvalid) *reinterpret_cast<bf16x8*>(gout + (size_t)grow * p.KP + 8 * seg) = o;
+      if (rb == 0 && t == 0) DG_STAMP(7);
     }
     __builtin_amdgcn_wave_barrier();
+    if (rb == 0) DG_STAMP(8);
+    if (rb == 1) DG_STAMP(10);
   }
+  DG_STAMP(3);
+#ifdef EGNN_EXP_DGSTAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  DG_STAMP(4);
+  if (tid == 0 && blockIdx.x < 40000)
+    g_dg_stamps[CB == 2 ? 0 : 1][blockIdx.x][5] =
+        (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
+#endif
 }
 
 }  // namespace
 
+#ifdef EGNN_EXP_DGSTAMP
+extern "C" int egnn_debug_dgrad_stamps(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dg_stamps), sizeof(unsigned long long) * 2 * 40000 * 12) == hipSuccess ? 0 : -1;
+}
+#endif
+
 int init_edge_dgrad_attributes() {
-  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_dgrad_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               160 * 1024));
-  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_dgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_dgrad_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                160 * 1024));
   return EGNN_OK;
 }
@@ -243,11 +356,10 @@ int launch_edge_dgrad(int N, int E, const int* dst, const int* src, const float*
   p.N = N; p.E = E; p.edge_dst = dst; p.edge_src = src; p.x = x; p.table = table; p.TC = TC; p.offP = offP; p.offQ = offQ;
   p.wd = wd; p.g_a2 = g_a2; p.Kd = Kd; p.w2t = w2t; p.KP = KP; p.g_a1_out = g_a1_out;
   const int tiles = (E + kRD - 1) / kRD;
-  // 512-column workgroups (one per CU) for the long reduction of mlp_x; the message branch reduces over 256 only (4 chunks):
-  // its workgroup is mostly prologue + SiLU' epilogue, so 256-column workgroups at <= 128 VGPRs, TWO per CU, let one's
-  // epilogue run under the other's K loop
-  if (KP >= 512 && Kd > 256) hipLaunchKernelGGL(edge_dgrad_kernel<2>, dim3(tiles * (KP / 512)), dim3(kTD), kSmemD, st, p);
-  else hipLaunchKernelGGL(edge_dgrad_kernel<1>, dim3(tiles * (KP / 256)), dim3(kTD), kSmemD, st, p);
+  // both MLPs on 4-wave workgroups (128 edges x 256 columns), two per CU: at C4 shapes mlp_x (K = 1024) 2.55 ms against 2.77 ms
+  // for one 8-wave 512-column workgroup per CU, the message branch (K = 256) 1.22 ms against 1.26 ms for 8-wave 256-column
+  // workgroups at <= 128 VGPRs (tools/dgrad_ab.sh, same box, interleaved)
+  hipLaunchKernelGGL((edge_dgrad_kernel<2, 4>), dim3(tiles * (KP / 256)), dim3(256), kSmemD, st, p);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }

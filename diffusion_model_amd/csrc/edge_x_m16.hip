@@ -103,6 +103,9 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
   // (both column shares build the same activations: only share 0 stores them)
   auto s1_store = [&](const bf16x8 o0, const bf16x8 o1, const int c) {
     if (half != 0) return;
+#ifdef EGNN_EXP_NO_S1   // timing experiment
+    return;
+#endif
     __bf16* base = static_cast<__bf16*>(p.s1_out) + (size_t)e0 * KP + c * kKC + kg * 8;
     if (brow < nvalid) *reinterpret_cast<bf16x8*>(base + (size_t)brow * KP) = o0;
     if (brow + 64 < nvalid) *reinterpret_cast<bf16x8*>(base + (size_t)(brow + 64) * KP) = o1;
@@ -231,7 +234,11 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int piece = lane + 64 * t, row = piece >> 3, seg = piece & 7;   // 16 rows x 8 pieces of 16 bytes
+#ifdef EGNN_EXP_NO_T2   // timing experiment
+        if (16 * rb + row < nvalid - 1000)
+#else
         if (16 * rb + row < nvalid)
+#endif
           *reinterpret_cast<bf16x8*>(tout + (size_t)(16 * rb + row) * p.WxP + 8 * seg) = *reinterpret_cast<const bf16x8*>(stg + row * 72 + 8 * seg);
       }
       __builtin_amdgcn_wave_barrier();
