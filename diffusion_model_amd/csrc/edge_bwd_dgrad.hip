@@ -60,6 +60,74 @@ __device__ unsigned long long g_dg_stamps[2][40000][12];
 #define DG_STAMP(k)
 #endif
 
+// SiLU' epilogue shared by the dgrad kernels: acc = this wave's [128 rows][32 CB columns] block of dL/da2 . W2 in accumulator
+// layout; times SiLU'(a1) from the first-layer table, row-major bf16 store.
+template <int CB>
+__device__ __forceinline__ void dgrad_epilogue(f32x16 (&acc)[kRBD][CB], const rsrc_t rs_tab, const int* s_dst, const int* s_src,
+                                               const float* s_d2, const float* wd_ptr, __bf16* stg, __bf16* gout, const int KP,
+                                               const int colblk0, const int nvalid, const int lane) {
+  const int r = lane & 31;
+  constexpr int kPieces = CB * 4;            // 16-byte pieces per row of this wave's block
+  constexpr int kPer = 32 * kPieces / 64;    // pieces per lane and row block
+  static_assert(64 % kPieces == 0, "a lane keeps the same 8 columns in every piece it handles");
+  // A lane's pieces all cover the same 8 columns (seg = lane % kPieces): their d^2 weights are loaded ONCE.  (Loaded next to
+  // their use they were re-read from global memory behind every store -- the stores may alias them for all the compiler
+  // knows -- i.e. 16 exposed load latencies per wave: the epilogue took 19 us against 17 us of K loop, tools/dgrad_stamps.py.)
+  const int seg = lane % kPieces, row0 = lane / kPieces;
+  const int col0 = 32 * colblk0 + 8 * seg;
+  const unsigned cbyte = 2u * (unsigned)col0;
+  const f32x4 w0 = *reinterpret_cast<const f32x4*>(wd_ptr + col0), w1 = *reinterpret_cast<const f32x4*>(wd_ptr + col0 + 4);
+  // first-layer table rows of row block rb + 1 are requested before row block rb is worked on (two register sets)
+  f16x8 tp[2][kPer], tq[2][kPer];
+  auto tload = [&](const int rb, f16x8 (&xp)[kPer], f16x8 (&xq)[kPer]) {
+#pragma unroll
+    for (int t = 0; t < kPer; ++t) {
+      const int row = row0 + (64 / kPieces) * t;
+      xp[t] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_tab, (unsigned)s_dst[32 * rb + row] + cbyte, 0, 0));
+      xq[t] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_tab, (unsigned)s_src[32 * rb + row] + cbyte, 0, 0));
+    }
+  };
+  tload(0, tp[0], tq[0]);
+#pragma unroll
+  for (int rb = 0; rb < kRBD; ++rb) {
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) stg[acc_row(i, lane) * 72 + 32 * cb + r] = (__bf16)acc[rb][cb][i];
+    if (rb + 1 < kRBD) tload(rb + 1, tp[(rb + 1) & 1], tq[(rb + 1) & 1]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < kPer; ++t) {
+      const int row = row0 + (64 / kPieces) * t;
+      const int grow = 32 * rb + row;
+      const float d2 = s_d2[grow];
+      const bf16x8 g = *reinterpret_cast<const bf16x8*>(stg + row * 72 + 8 * seg);
+      const f16x8 a1 = tp[rb & 1][t] + tq[rb & 1][t];
+      // g * SiLU'(a1) on register PAIRS (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: two elements per issue slot, only exp2 and
+      // rcp stay scalar)
+      typedef __attribute__((ext_vector_type(2))) float f32x2;
+      const f32x2 one2 = {1.0f, 1.0f}, k2 = {kNegInvLog2e, kNegInvLog2e};
+      bf16x8 o;
+#pragma unroll
+      for (int jj = 0; jj < 8; jj += 2) {
+        const float wa = jj < 4 ? w0[jj] : w1[jj - 4], wb = jj < 4 ? w0[jj + 1] : w1[jj - 3];
+        const f32x2 t2 = {fmaf(wa, d2, (float)a1[jj]), fmaf(wb, d2, (float)a1[jj + 1])};
+        const f32x2 e = {__builtin_amdgcn_exp2f(t2.x), __builtin_amdgcn_exp2f(t2.y)};
+        const f32x2 den = e + one2;
+        const f32x2 sg = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+        const f32x2 sv = (t2 * k2) * sg;                                    // SiLU(a1)
+        const f32x2 ds = __builtin_elementwise_fma(sv, one2 - sg, sg);      // SiLU'(a1) = sig + s (1 - sig)
+        const f32x2 gg = {(float)g[jj], (float)g[jj + 1]};
+        const f32x2 r2 = gg * ds;
+        o[jj] = (__bf16)r2.x;
+        o[jj + 1] = (__bf16)r2.y;
+      }
+      if (grow < nvalid) *reinterpret_cast<bf16x8*>(gout + (size_t)grow * KP + 8 * seg) = o;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // NW = waves per workgroup (8 = 512 threads; 4 = 256 threads, 128 edges x 256 columns at CB = 2, TWO independent workgroups per
 // CU with one wave per SIMD each: the form that is launched).  What the timing builds of this file and the per-workgroup
 // stamps say at C4 shapes (tools/dgrad_ab.sh, tools/dgrad_stamps.py):
@@ -258,70 +326,7 @@ __global__ __launch_bounds__(64 * NW, (CB == 1 ? 4 : 2)) void edge_dgrad_kernel(
 #endif
   __bf16* stg = reinterpret_cast<__bf16*>(s_a1) + (size_t)wave * 32 * 72;
   __bf16* gout = static_cast<__bf16*>(out_ptr) + (size_t)e0 * p.KP + 32 * colblk0;
-  constexpr int kPieces = CB * 4;            // 16-byte pieces per row of this wave's block
-  constexpr int kPer = 32 * kPieces / 64;    // pieces per lane and row block
-  static_assert(64 % kPieces == 0, "a lane keeps the same 8 columns in every piece it handles");
-  // A lane's pieces all cover the same 8 columns (seg = lane % kPieces): their d^2 weights are loaded ONCE.  (Loaded next to
-  // their use they were re-read from global memory behind every store -- the stores may alias them for all the compiler
-  // knows -- i.e. 16 exposed load latencies per wave: the epilogue took 19 us against 17 us of K loop, tools/dgrad_stamps.py.)
-  const int seg = lane % kPieces, row0 = lane / kPieces;
-  const int col0 = 32 * colblk0 + 8 * seg;
-  const unsigned cbyte = 2u * (unsigned)col0;
-  const f32x4 w0 = *reinterpret_cast<const f32x4*>(wd_ptr + col0), w1 = *reinterpret_cast<const f32x4*>(wd_ptr + col0 + 4);
-  // first-layer table rows of row block rb + 1 are requested before row block rb is worked on (two register sets)
-  f16x8 tp[2][kPer], tq[2][kPer];
-  auto tload = [&](const int rb, f16x8 (&xp)[kPer], f16x8 (&xq)[kPer]) {
-#pragma unroll
-    for (int t = 0; t < kPer; ++t) {
-      const int row = row0 + (64 / kPieces) * t;
-      xp[t] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_tab, (unsigned)s_dst[32 * rb + row] + cbyte, 0, 0));
-      xq[t] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_tab, (unsigned)s_src[32 * rb + row] + cbyte, 0, 0));
-    }
-  };
-  tload(0, tp[0], tq[0]);
-#pragma unroll
-  for (int rb = 0; rb < kRBD; ++rb) {
-#pragma unroll
-    for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) stg[acc_row(i, lane) * 72 + 32 * cb + r] = (__bf16)acc[rb][cb][i];
-    if (rb + 1 < kRBD) tload(rb + 1, tp[(rb + 1) & 1], tq[(rb + 1) & 1]);
-    __builtin_amdgcn_wave_barrier();
-    if (rb == 0) DG_STAMP(6);
-    if (rb == 1) DG_STAMP(9);
-#pragma unroll
-    for (int t = 0; t < kPer; ++t) {
-      const int row = row0 + (64 / kPieces) * t;
-      const int grow = 32 * rb + row;
-      const float d2 = s_d2[grow];
-      const bf16x8 g = *reinterpret_cast<const bf16x8*>(stg + row * 72 + 8 * seg);
-      const f16x8 a1 = tp[rb & 1][t] + tq[rb & 1][t];
-      // g * SiLU'(a1) on register PAIRS (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: two elements per issue slot, only exp2 and
-      // rcp stay scalar)
-      typedef __attribute__((ext_vector_type(2))) float f32x2;
-      const f32x2 one2 = {1.0f, 1.0f}, k2 = {kNegInvLog2e, kNegInvLog2e};
-      bf16x8 o;
-#pragma unroll
-      for (int jj = 0; jj < 8; jj += 2) {
-        const float wa = jj < 4 ? w0[jj] : w1[jj - 4], wb = jj < 4 ? w0[jj + 1] : w1[jj - 3];
-        const f32x2 t2 = {fmaf(wa, d2, (float)a1[jj]), fmaf(wb, d2, (float)a1[jj + 1])};
-        const f32x2 e = {__builtin_amdgcn_exp2f(t2.x), __builtin_amdgcn_exp2f(t2.y)};
-        const f32x2 den = e + one2;
-        const f32x2 sg = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-        const f32x2 sv = (t2 * k2) * sg;                                    // SiLU(a1)
-        const f32x2 ds = __builtin_elementwise_fma(sv, one2 - sg, sg);      // SiLU'(a1) = sig + s (1 - sig)
-        const f32x2 gg = {(float)g[jj], (float)g[jj + 1]};
-        const f32x2 r2 = gg * ds;
-        o[jj] = (__bf16)r2.x;
-        o[jj + 1] = (__bf16)r2.y;
-      }
-      if (grow < nvalid) *reinterpret_cast<bf16x8*>(gout + (size_t)grow * p.KP + 8 * seg) = o;
-      if (rb == 0 && t == 0) DG_STAMP(7);
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (rb == 0) DG_STAMP(8);
-    if (rb == 1) DG_STAMP(10);
-  }
+  dgrad_epilogue<CB>(acc, rs_tab, s_dst, s_src, s_d2, wd_ptr, stg, gout, p.KP, colblk0, nvalid, lane);
   DG_STAMP(3);
 #ifdef EGNN_EXP_DGSTAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
