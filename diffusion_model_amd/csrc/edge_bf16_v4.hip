@@ -36,6 +36,27 @@ namespace egnn {
 
 namespace {
 
+#ifdef EGNN_EXP_WGSTAMP   // diagnostic build only (tools/fwd_stamps.py): 100 MHz wall stamps of EVERY workgroup's phases + where it ran
+__device__ unsigned long long g_mwg_stamps[20000][6];
+#define WG_STAMP(k)                                                                                   \
+  do {                                                                                                \
+    unsigned long long t_;                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    if (threadIdx.x == 0 && blockIdx.x < 20000) g_mwg_stamps[blockIdx.x][k] = t_;                                \
+  } while (0)
+#define WG_STAMP_HW()                                                                                 \
+  do {                                                                                                \
+    if (threadIdx.x == 0 && blockIdx.x < 20000)                                                       \
+      g_mwg_stamps[blockIdx.x][5] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |             \
+                          ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);      \
+  } while (0)
+#else
+#define WG_STAMP(k)
+#define WG_STAMP_HW()
+#endif
+
 constexpr int kT3 = 512;
 constexpr int kR3 = 128, kRB3 = 4, kRPAD3 = kR3 + 1;
 constexpr int kKC3 = 64;
@@ -106,10 +127,12 @@ __global__ __launch_bounds__(kT3, ((CB == 1 && !BWD) ? EGNN_V4_M_WAVES : 2)) voi
 #define STAMP1(c, k) STAMP(c, k)
 #endif
   STAMP(30, 0);   // kernel entry
+  WG_STAMP(0);
   const int S = prologue(p, L, e0, nvalid, IS_M ? p.wdm : p.wdx, KP, s_wd, tid, lane, wave);
   (void)S;
 
   STAMP(30, 1);   // tile structure ready
+  WG_STAMP(1);
 
   // ---- K-loop ----
   const int NC = KP / kKC3, KS = KP / 16;
@@ -267,6 +290,7 @@ __global__ __launch_bounds__(kT3, ((CB == 1 && !BWD) ? EGNN_V4_M_WAVES : 2)) voi
   // (the steady-state loop body is branch-free so that hipcc's waitcnt insertion keeps counted vmcnt waits across
   // the back edge instead of draining the queue at every control-flow join)
   STAMP(30, 2);   // chunks 0 and 1 built, first weights requested
+  WG_STAMP(2);
   RSTAMP(31, 1);
   for (int c = 0; c < NC - 2; ++c) { chunk(c, true, false); __syncthreads(); STAMP(c, 3); }
   chunk(NC - 2, false, false);
@@ -279,6 +303,7 @@ __global__ __launch_bounds__(kT3, ((CB == 1 && !BWD) ? EGNN_V4_M_WAVES : 2)) voi
 #undef LDS_WAIT
 #undef LDS_RD
   STAMP(30, 3);   // K loop done
+  WG_STAMP(3);
 
 
   // row of value index q (q = rb*16 + reg) for this lane
@@ -380,6 +405,8 @@ __global__ __launch_bounds__(kT3, ((CB == 1 && !BWD) ? EGNN_V4_M_WAVES : 2)) voi
     message_epilogue<SAVE>(p, L, acc, S, tile, tid, lane, wave);
   }
   STAMP(31, 0);   // epilogue done
+  WG_STAMP(4);
+  WG_STAMP_HW();
 }
 
 template <int CB, bool IS_M, bool BWD = false, bool SAVE = false>
@@ -429,3 +456,9 @@ int launch_edge_bf16_v4_m(const EdgeParams& p, hipStream_t st) {
 }
 
 }  // namespace egnn
+
+#ifdef EGNN_EXP_WGSTAMP
+extern "C" int egnn_debug_mwg_stamps(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(egnn::g_mwg_stamps), sizeof(unsigned long long) * 20000 * 6) == hipSuccess ? 0 : -1;
+}
+#endif

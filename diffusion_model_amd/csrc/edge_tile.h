@@ -45,8 +45,10 @@ struct Lds {
 // 1 / 0 when the node's edges start here / continue from the previous tile (sum goes to the tile's partial slots, added
 // in tile order by node_post: bitwise deterministic, no atomics).  Returns the number of segments.
 // 512 threads; ends with every thread past the last barrier EXCEPT for seg_mode (read it after the caller's next barrier).
-__device__ __forceinline__ int prologue(const EdgeParams& p, const Lds& L, int e0, int nvalid, const float* wd, int KP,
-                                        float* s_wd, int tid, int lane, int wave) {
+// Split in two so that a kernel can put its first table / weight requests between the halves (prologue_rows ends behind the
+// barrier that publishes L.dst / L.src / L.d2; prologue_segments is two more barriers with only waves 0 and 1 busy).
+__device__ __forceinline__ void prologue_rows(const EdgeParams& p, const Lds& L, int e0, int nvalid, const float* wd, int KP,
+                                              float* s_wd, int tid) {
   if (tid < kR) {
     int d = 0, s = 0;
     float dx = 0.f, dy = 0.f, dz = 0.f;
@@ -65,6 +67,19 @@ __device__ __forceinline__ int prologue(const EdgeParams& p, const Lds& L, int e
   }
   for (int i = tid; i < KP; i += 512) s_wd[i] = wd[i];
   __syncthreads();
+}
+
+// seg_mode of segment `seg` (2 = all edges of its node, 1 = the node's edges start here, 0 = continue from the previous tile):
+// two row_ptr loads; prologue_segments<false> leaves it to the caller, who can put the loads under its K loop.
+__device__ __forceinline__ int segment_mode(const EdgeParams& p, const Lds& L, int e0, int seg) {
+  const int n = L.seg_node[seg];
+  const bool first = (e0 + L.seg_rs[seg]) == p.row_ptr[n];
+  const bool last = (e0 + L.seg_re[seg] + 1) == p.row_ptr[n + 1];
+  return (first && last) ? 2 : (first ? 1 : 0);
+}
+
+template <bool WITH_MODES = true>
+__device__ __forceinline__ int prologue_segments(const EdgeParams& p, const Lds& L, int e0, int nvalid, int tid, int lane, int wave) {
   bool is_start = false, is_end = false;
   unsigned long long starts = 0;
   if (tid < kR) {   // waves 0 and 1
@@ -85,13 +100,16 @@ __device__ __forceinline__ int prologue(const EdgeParams& p, const Lds& L, int e
   }
   __syncthreads();
   const int S = L.misc[0];
-  if (tid < S) {
-    const int n = L.seg_node[tid];
-    const bool first = (e0 + L.seg_rs[tid]) == p.row_ptr[n];
-    const bool last = (e0 + L.seg_re[tid] + 1) == p.row_ptr[n + 1];
-    L.seg_mode[tid] = (first && last) ? 2 : (first ? 1 : 0);
+  if constexpr (WITH_MODES) {
+    if (tid < S) L.seg_mode[tid] = segment_mode(p, L, e0, tid);
   }
   return S;
+}
+
+__device__ __forceinline__ int prologue(const EdgeParams& p, const Lds& L, int e0, int nvalid, const float* wd, int KP,
+                                        float* s_wd, int tid, int lane, int wave) {
+  prologue_rows(p, L, e0, nvalid, wd, KP, s_wd, tid);
+  return prologue_segments(p, L, e0, nvalid, tid, lane, wave);
 }
 
 // Coordinate messages of the tile (:62-65): sum over each segment's rows of (x_i - x_j) * s_ij (L.val) into the node's /
@@ -103,30 +121,28 @@ __device__ __forceinline__ void coordinate_segment_sums(const EdgeParams& p, con
   float* aggx = p.agg_x + (size_t)half * p.agg_x_stride;
   float* partx = p.part_x + (size_t)half * p.part_x_stride;
   if (S <= kSegFast) {
-    if (wave == 0) {
-      float c[2][4];
-      int myseg[2];
+    // one wave per segment (S <= 8 = the waves of the workgroup): the 6-step cross-lane sums of the segments run side by side
+    // (one wave doing the segments one after the other was 1.4 us of a 27 us workgroup, the other 7 waves idle:
+    // tools/fwd_stamps.py)
+    if (wave < S) {
+      const int seg = wave;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int row = lane + 64 * u;
-        myseg[u] = L.seg_of_row[row];
-        const float sv = L.val[row];
-        const float dx = L.diff[row], dy = L.diff[kR + row], dz = L.diff[2 * kR + row];
-        c[u][0] = dx * sv; c[u][1] = dy * sv; c[u][2] = dz * sv;
-        c[u][3] = dx * dx + dy * dy + dz * dz;
-      }
-      for (int seg = 0; seg < S; ++seg) {
-        float a0 = (myseg[0] == seg ? c[0][0] : 0.f) + (myseg[1] == seg ? c[1][0] : 0.f);
-        float a1 = (myseg[0] == seg ? c[0][1] : 0.f) + (myseg[1] == seg ? c[1][1] : 0.f);
-        float a2 = (myseg[0] == seg ? c[0][2] : 0.f) + (myseg[1] == seg ? c[1][2] : 0.f);
-        float a3 = (myseg[0] == seg ? c[0][3] : 0.f) + (myseg[1] == seg ? c[1][3] : 0.f);
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { a0 += __shfl_xor(a0, m); a1 += __shfl_xor(a1, m); a2 += __shfl_xor(a2, m); a3 += __shfl_xor(a3, m); }
-        if (lane < 4) {
-          const int mode = L.seg_mode[seg];
-          float* dstp = mode == 2 ? aggx + (size_t)L.seg_node[seg] * 4 : partx + ((size_t)tile * 2 + mode) * 4;
-          dstp[lane] = lane == 0 ? a0 : (lane == 1 ? a1 : (lane == 2 ? a2 : a3));
+        if (L.seg_of_row[row] == seg) {
+          const float sv = L.val[row];
+          const float dx = L.diff[row], dy = L.diff[kR + row], dz = L.diff[2 * kR + row];
+          a0 += dx * sv; a1 += dy * sv; a2 += dz * sv;
+          a3 += dx * dx + dy * dy + dz * dz;
         }
+      }
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) { a0 += __shfl_xor(a0, m); a1 += __shfl_xor(a1, m); a2 += __shfl_xor(a2, m); a3 += __shfl_xor(a3, m); }
+      if (lane < 4) {
+        const int mode = L.seg_mode[seg];
+        float* dstp = mode == 2 ? aggx + (size_t)L.seg_node[seg] * 4 : partx + ((size_t)tile * 2 + mode) * 4;
+        dstp[lane] = lane == 0 ? a0 : (lane == 1 ? a1 : (lane == 2 ? a2 : a3));
       }
     }
   } else {

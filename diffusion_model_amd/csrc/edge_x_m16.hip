@@ -20,6 +20,27 @@ namespace egnn {
 
 namespace {
 
+#ifdef EGNN_EXP_WGSTAMP   // diagnostic build only (tools/fwd_stamps.py): 100 MHz wall stamps of EVERY workgroup's phases + where it ran
+__device__ unsigned long long g_xwg_stamps[20000][12];
+#define WG_STAMP(k)                                                                                   \
+  do {                                                                                                \
+    unsigned long long t_;                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    if (threadIdx.x == 0 && blockIdx.x < 20000) g_xwg_stamps[blockIdx.x][k] = t_;                                \
+  } while (0)
+#define WG_STAMP_HW()                                                                                 \
+  do {                                                                                                \
+    if (threadIdx.x == 0 && blockIdx.x < 20000)                                                       \
+      g_xwg_stamps[blockIdx.x][5] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |             \
+                          ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);      \
+  } while (0)
+#else
+#define WG_STAMP(k)
+#define WG_STAMP_HW()
+#endif
+
 using namespace tile128;
 constexpr int kT = 512;
 constexpr int kKC = 64;                       // activation chunk depth
@@ -67,8 +88,10 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
 #define RSTAMP(c, k)
 #endif
   STAMP(30, 0);   // kernel entry
-  const int S = prologue(p, L, e0, nvalid, p.wdx, KP, s_wd, tid, lane, wave);
-  STAMP(30, 1);   // tile structure ready
+  WG_STAMP(0);
+  prologue_rows(p, L, e0, nvalid, p.wdx, KP, s_wd, tid);
+  STAMP(30, 1);   // edge rows and geometry ready
+  WG_STAMP(1);
 
   // ---- K loop ----
   const int NC = KP / kKC, KS = KP / 32;
@@ -110,19 +133,23 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
     if (brow < nvalid) *reinterpret_cast<bf16x8*>(base + (size_t)brow * KP) = o0;
     if (brow + 64 < nvalid) *reinterpret_cast<bf16x8*>(base + (size_t)(brow + 64) * KP) = o1;
   };
-  {  // chunk 0
-    UnitH u;
-    unith_load(u, rs_tab, vdst0, vsrc0, offP, offQ);
-    const bf16x8 o0 = unith_finish(u, s_wd + kg * 8, d2r0, slot0);
-    unith_load(u, rs_tab, vdst1, vsrc1, offP, offQ);
-    const bf16x8 o1 = unith_finish(u, s_wd + kg * 8, d2r1, slot1);
-    if constexpr (SAVE) s1_store(o0, o1, 0);
-  }
+  // chunk 0: both rows' table pieces and the first weight fragments are requested, THEN the segment structure of the tile is
+  // worked out (two barriers, waves 0 and 1 only) while they are in flight, then the activations are finished
+  // (one row after the other and the segment structure in front of them: 2.3 us per 27 us workgroup, tools/fwd_stamps.py)
+  UnitH uc0, uc1;
+  unith_load(uc0, rs_tab, vdst0, vsrc0, offP, offQ);
+  unith_load(uc1, rs_tab, vdst1, vsrc1, offP, offQ);
   bf16x8 bq[2][4];   // weight fragments of the 2 k-steps of the current chunk
 #pragma unroll
   for (int s = 0; s < 2; ++s)
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) bq[s][cb] = ldbuf_bf16x8(rs_w, lane16, w0 + ((unsigned)cb * KS + s) * 1024u);
+  const int S = prologue_segments<false>(p, L, e0, nvalid, tid, lane, wave);   // seg_mode: under the first matrix phase, below
+  {
+    const bf16x8 o0 = unith_finish(uc0, s_wd + kg * 8, d2r0, slot0);
+    const bf16x8 o1 = unith_finish(uc1, s_wd + kg * 8, d2r1, slot1);
+    if constexpr (SAVE) s1_store(o0, o1, 0);
+  }
   __syncthreads();
 
   // matrix phase of chunk c: 2 k-steps x (8 row blocks x 4 column blocks).  Operand pipeline as in edge_bf16_v3.hip: the
@@ -183,11 +210,15 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
   };
   // SIMD partners (waves w and w + 4) in opposite phase, one barrier per chunk (edge_bf16_v3.hip)
   STAMP(30, 2);   // chunk 0 built, first weights requested
+  WG_STAMP(2);
   RSTAMP(31, 1);
   vload(1);
   if (wave < 4) {
+    // row_ptr loads of the segment modes (needed by the epilogue only) ride under the first matrix phase of wave 0
+    const int my_mode = tid < S ? segment_mode(p, L, e0, tid) : 0;
     for (int i = 0; i < NC - 1; ++i) {
       mphase(i, false);
+      if (i == 0 && tid < S) L.seg_mode[tid] = my_mode;
       vfinish(i + 1);
       vload(i + 2);
       __syncthreads();
@@ -204,6 +235,7 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
   mphase(NC - 1, true);
   __syncthreads();
   STAMP(30, 3);   // K loop done
+  WG_STAMP(3);
   RSTAMP(31, 2);
 
   // ---- epilogue: s[row] = [b3] + sum_n w3[n] * SiLU(a2[row][n] + b2[n]) over this workgroup's 512 columns ----
@@ -268,6 +300,7 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
         part[rb * 4 + i + 1] = pp.y;
       }
   }
+  WG_STAMP(6);   // second-layer SiLU + w3 products done
   {
     float t0, t1;
     butterfly16(part, lane, t0, t1);   // value indices 2 m, 2 m + 1 (m = lane & 15): row block m >> 1, register 2 (m & 1) + {0, 1}
@@ -276,6 +309,7 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
     L.part[wave * kR + row + 1] = t1;
   }
   __syncthreads();
+  WG_STAMP(7);   // row partials of the 8 waves in LDS
   if (tid < kR) {
     float v = half == 0 ? p.scal[0] : 0.f;
 #pragma unroll
@@ -283,8 +317,11 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
     L.val[tid] = v;
   }
   __syncthreads();
+  WG_STAMP(8);   // s_e per row ready
   coordinate_segment_sums(p, L, S, tile, half, tid, lane, wave);
   STAMP(31, 0);   // epilogue done
+  WG_STAMP(4);
+  WG_STAMP_HW();
 #undef STAMP
 #undef RSTAMP
 }
@@ -325,3 +362,9 @@ int launch_edge_x_m16_save(const EdgeParams& p, hipStream_t st) {
 }
 
 }  // namespace egnn
+
+#ifdef EGNN_EXP_WGSTAMP
+extern "C" int egnn_debug_xwg_stamps(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(egnn::g_xwg_stamps), sizeof(unsigned long long) * 20000 * 12) == hipSuccess ? 0 : -1;
+}
+#endif
