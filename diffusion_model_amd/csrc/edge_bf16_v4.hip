@@ -128,8 +128,7 @@ __global__ __launch_bounds__(kT3, ((CB == 1 && !BWD) ? EGNN_V4_M_WAVES : 2)) voi
 #endif
   STAMP(30, 0);   // kernel entry
   WG_STAMP(0);
-  const int S = prologue(p, L, e0, nvalid, IS_M ? p.wdm : p.wdx, KP, s_wd, tid, lane, wave);
-  (void)S;
+  prologue_rows(p, L, e0, nvalid, IS_M ? p.wdm : p.wdx, KP, s_wd, tid);
 
   STAMP(30, 1);   // tile structure ready
   WG_STAMP(1);
@@ -174,19 +173,12 @@ __global__ __launch_bounds__(kT3, ((CB == 1 && !BWD) ? EGNN_V4_M_WAVES : 2)) voi
     if (row < nvalid)
       *reinterpret_cast<bf16x8*>(static_cast<__bf16*>(p.s1_out) + (size_t)(e0 + row) * KP + c * kKC3 + kg * 8) = ov;
   };
+  // chunks 0 and 1: all four table pieces and the first weight fragments are requested, THEN the segment structure of the tile
+  // is worked out (two barriers, waves 0 and 1 only) while they are in flight, then the activations are finished (as in
+  // edge_x_m16.hip; the segment modes' row_ptr loads ride under the first chunk of the K loop)
+  UnitH u2, u3;
   uload(u0, vdst0, vsrc0, 0); uload(u1, vdst1, vsrc1, 0);
-  {
-    const bf16x8 o0 = unith_finish(u0, s_wd + kg * 8, d2r0, slot0);
-    const bf16x8 o1 = unith_finish(u1, s_wd + kg * 8, d2r1, slot1);
-    if constexpr (BWD || SAVE) { s1_store(o0, brow, 0); s1_store(o1, brow + 64, 0); }
-  }
-  uload(u0, vdst0, vsrc0, 1); uload(u1, vdst1, vsrc1, 1);
-  {
-    const bf16x8 o0 = unith_finish(u0, s_wd + kKC3 + kg * 8, d2r0, slot0 + kA1_3);
-    const bf16x8 o1 = unith_finish(u1, s_wd + kKC3 + kg * 8, d2r1, slot1 + kA1_3);
-    if constexpr (BWD || SAVE) { s1_store(o0, brow, 1); s1_store(o1, brow + 64, 1); }
-  }
-  uload(u0, vdst0, vsrc0, 2); uload(u1, vdst1, vsrc1, 2);
+  uload(u2, vdst0, vsrc0, 1); uload(u3, vdst1, vsrc1, 1);
   // weight fragments, requested BQD k-steps ahead of their use (a whole chunk for the coordinate kernel; the message
   // kernel, compiled for <= 128 VGPRs so that two workgroups share a CU, keeps 2 -- its other workgroup covers the rest)
   constexpr int BQD = (CB == 1 && !BWD && EGNN_V4_M_WAVES >= 4) ? 2 : 4;
@@ -195,6 +187,19 @@ __global__ __launch_bounds__(kT3, ((CB == 1 && !BWD) ? EGNN_V4_M_WAVES : 2)) voi
   for (int s = 0; s < BQD; ++s)
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) bq[s][cb] = ldbuf_bf16x8(rs_w, lane16, w0off + ((unsigned)cb * KS + s) * 1024u);
+  const int S = prologue_segments<false>(p, L, e0, nvalid, tid, lane, wave);
+  {
+    const bf16x8 o0 = unith_finish(u0, s_wd + kg * 8, d2r0, slot0);
+    const bf16x8 o1 = unith_finish(u1, s_wd + kg * 8, d2r1, slot1);
+    if constexpr (BWD || SAVE) { s1_store(o0, brow, 0); s1_store(o1, brow + 64, 0); }
+  }
+  {
+    const bf16x8 o0 = unith_finish(u2, s_wd + kKC3 + kg * 8, d2r0, slot0 + kA1_3);
+    const bf16x8 o1 = unith_finish(u3, s_wd + kKC3 + kg * 8, d2r1, slot1 + kA1_3);
+    if constexpr (BWD || SAVE) { s1_store(o0, brow, 1); s1_store(o1, brow + 64, 1); }
+  }
+  uload(u0, vdst0, vsrc0, 2); uload(u1, vdst1, vsrc1, 2);
+  const int my_mode = tid < S ? segment_mode(p, L, e0, tid) : 0;   // stored after the first chunk
   __syncthreads();
 
   // ring offsets (bytes): chunk c is read at off_cur, chunk c+1 at off_nxt, chunk c+2 is written at off_wr
@@ -292,7 +297,11 @@ __global__ __launch_bounds__(kT3, ((CB == 1 && !BWD) ? EGNN_V4_M_WAVES : 2)) voi
   STAMP(30, 2);   // chunks 0 and 1 built, first weights requested
   WG_STAMP(2);
   RSTAMP(31, 1);
-  for (int c = 0; c < NC - 2; ++c) { chunk(c, true, false); __syncthreads(); STAMP(c, 3); }
+  for (int c = 0; c < NC - 2; ++c) {
+    chunk(c, true, false);
+    if (c == 0 && tid < S) L.seg_mode[tid] = my_mode;
+    __syncthreads(); STAMP(c, 3);
+  }
   chunk(NC - 2, false, false);
   __syncthreads();
   STAMP(NC - 2, 3);
