@@ -254,9 +254,19 @@ def train_leg(args, rk, steps, warmup, batch):
     # edge and layer + the node MLP) over the step time, against the dense bf16 MFMA peak
     E = batch * n * (n - 1)
     fwd_flop = L * (2.0 * edge_macs(H, M, W, W) * E + 2.0 * node_macs(H, M, W) * batch * n)
+    # HBM bytes per step from separate rocprofv3 --pmc passes of this leg (profiles/traffic_train.json), as for the sampler
+    train_traffic, train_traffic_src = None, None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_train.json")))
+        if args.precision == "bf16" and batch == 256 and n == 64 and L == 4:
+            train_traffic = tj["bytes_per_step"]
+            train_traffic_src = (f"profiles/traffic_train.json (rocprofv3 --pmc, separate passes of `bench.py --mode train` at git head "
+                                 f"{tj.get('git_head', '?')}: sum over the step's dispatches of FETCH_SIZE x 2 + WRITE_SIZE)")
+    except Exception:
+        pass
     out["roofline"] = {"bound": "mfma", "achieved": 3 * fwd_flop / (el / steps) / 1e12, "peak": PEAK_TFLOPS["bf16"],
                        "unit": "TFLOP/s", "frac": 3 * fwd_flop / (el / steps) / 1e12 / PEAK_TFLOPS["bf16"],
-                       "algorithmic_flop_per_step": 3 * fwd_flop, "traffic": None,
+                       "algorithmic_flop_per_step": 3 * fwd_flop, "traffic": train_traffic, "traffic_source": train_traffic_src,
                        "backward_path": getattr(getattr(net, "_ctx", None), "last_backward_path", None)}
     if world > 1:
         el1 = rk.timed(lambda: run(steps, False))

@@ -40,4 +40,5 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
             print(f"    {c:30s} mean={sum(v)/len(v):.4g} n={len(v)}")
 PY
 cat "$out/summary.txt"
+python3 "$root/tools/make_train_traffic_json.py" "$out" "${GIT_HEAD:-unknown}" 3 "$out/traffic_train.json" > /dev/null 2>&1
 find "$out" -name "*.csv" -size +4M -delete
