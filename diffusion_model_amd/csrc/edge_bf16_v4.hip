@@ -440,7 +440,7 @@ int init_edge_bf16_v4_attributes() {
 int edge_v4_rows() { return kR3; }
 
 bool edge_bf16_v4_supported(const EdgeParams& p) {
-  return (p.WxP == 256 || p.WxP == 512 || p.WxP == 1024) && p.MP == 256 && p.WmP % 64 == 0 &&
+  return (p.WxP == 256 || p.WxP == 512 || p.WxP == 1024) && p.MP == 256 && p.WmP % 64 == 0 && p.WmP >= 192 &&   // >= 3 chunks: the K loop has a steady-state iteration (segment modes are stored there)
          v4_smem_bytes(p.WmP, p.MP, true) <= 160 * 1024 && v4_smem_bytes(p.WxP, p.MP, false) <= 160 * 1024 &&
          (size_t)p.N * p.TC * 4 < ((size_t)1 << 32);
 }
