@@ -415,7 +415,7 @@ def test_saved_activation_backward_matches_recompute(monkeypatch):
 
 
 # ---------------- data-parallel training step on RCCL (needs >= 2 GPUs: skipped on a one-GPU box) ----------------
-def _nccl_worker(rank, world, port, out):
+def _nccl_worker(rank, world, port, out, force_active=False):
     """one rank per GPU, backend nccl (= RCCL on ROCm): each rank runs the real forward + backward on its shard of the
     graphs with the overlapped per-layer all-reduce (GradAllReducer.armed), the loss divided by the GLOBAL graph count"""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -437,6 +437,9 @@ def _nccl_worker(rank, world, port, out):
     lei = fully_connected_edge_index(lsizes).to(dev)
     proc = dma.E3DiffusionProcess(1e-5, 2.0, T)
     red = dma.GradAllReducer(list(net.egcl_list))
+    if force_active:   # one-rank rehearsal: issue the collectives although a single rank has nothing to exchange
+        red._active = lambda: True
+    assert red.stream is not None          # backend nccl: the buckets go out on the process's communication stream
     noised = dma.diffuse_as_batch(pos0[sel].to(dev), x0[sel].to(dev), lbatch, proc, times=[times[g] for g in mine],
                                   noise_pos=npos[sel].to(dev), noise_h=nh[sel].to(dev), num_graphs=len(mine))
     with red.armed():
@@ -451,6 +454,38 @@ def _nccl_worker(rank, world, port, out):
                     "world": dist.get_world_size(), "backend": dist.get_backend()}, out)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _single_process_reference():
+    dev = "cuda:0"
+    H, A, T = 36, 2, 50
+    d = dims_for(H, 128, 256, 256, 256)
+    torch.manual_seed(3)
+    net = dma.EquivariantGNN(2, **d).to(dev)
+    net.norm_scope = "graph"
+    sizes = (6, 4, 7, 5)
+    pos0, x0, cond, batch, ei, npos, nh, _ = _problem(seed=5, sizes=sizes)
+    proc = dma.E3DiffusionProcess(1e-5, 2.0, T)
+    noised = dma.diffuse_as_batch(pos0.to(dev), x0.to(dev), batch.to(dev), proc, times=[17, 3, 40, 22], noise_pos=npos.to(dev),
+                                  noise_h=nh.to(dev), num_graphs=4)
+    loss, _, _ = dma.training_loss(net, ei.to(dev), batch.to(dev), noised, cond.to(dev), A, num_graphs=4)
+    loss.backward()
+    return float(loss.detach()), {k: p.grad.cpu() for k, p in net.named_parameters()}
+
+
+@pytest.mark.gpu
+def test_reducer_collectives_on_rccl_one_rank_rehearsal(tmp_path):
+    """What a one-GPU box can rehearse of the RCCL path: ONE rank under backend nccl with the reducer forced to issue its
+    per-layer all-reduces (communication stream, record_stream, wait_stream, dist.all_reduce on the RCCL communicator) from
+    inside the real backward; a sum over one rank must leave the gradients exactly those of the plain step."""
+    out = str(tmp_path / "nccl1.pt")
+    mp.spawn(_nccl_worker, args=(1, _free_port(), out, True), nprocs=1, join=True)
+    res = torch.load(out, weights_only=True)
+    assert res["world"] == 1 and res["backend"] == "nccl"
+    loss, grads = _single_process_reference()
+    assert abs(loss - res["loss"]) <= 1e-6 * abs(loss)
+    for k, g in grads.items():
+        assert rel_err(res["grads"][k], g) <= 1e-5, k   # same kernels, same order; the fp32 atomics of the scatter reorder
 
 
 @pytest.mark.gpu
