@@ -51,6 +51,18 @@ __global__ __launch_bounds__(kThreadsN, (OBT > 2 ? 1 : 2)) void node_post_bf16_k
 #pragma unroll
     for (int s = 0; s < kMaxKS1; ++s) wf[s] = w1b[(size_t)(s < KS1 ? s : 0) * 64];
   }
+  // the same for the first hidden block's biases and its W2h fragments (two more round trips of the B = 1 chain)
+  float b1v[16];
+  bf16x8 w2f[OBT][2];
+  {
+    const int hbf = hb0 + wave * hb_per_wave;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) b1v[i] = p.b1h[32 * hbf + acc_row(i, lane)];
+#pragma unroll
+    for (int ob = 0; ob < OBT; ++ob)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) w2f[ob][s] = w2[((size_t)(ob < OB ? ob : 0) * KS2 + 2 * hbf + s) * 64 + lane];
+  }
 
   // gather [h | sum_m] (tile partials added in tile order), pack to bf16 in the fragment image.  The CSR lookups of the
   // 32 nodes go through LDS first and the item loop is unrolled: independent loads in flight instead of a chain of
@@ -184,19 +196,23 @@ __global__ __launch_bounds__(kThreadsN, (OBT > 2 ? 1 : 2)) void node_post_bf16_k
       }
     // bias + SiLU on the accumulator; registers 8s..8s+7 are the B fragment of k-step s of the second product
     bf16x8 hf[2];
+    if (q > 0) {   // (block 0: requested at the top)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float bias = p.b1h[32 * hb + acc_row(i, lane)];
-      hf[i >> 3][i & 7] = (__bf16)silu_f(acc[i] + bias);
+      for (int i = 0; i < 16; ++i) b1v[i] = p.b1h[32 * hb + acc_row(i, lane)];
+#pragma unroll
+      for (int ob = 0; ob < OBT; ++ob)
+        if (ob < OB) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) w2f[ob][s] = w2[((size_t)ob * KS2 + 2 * hb + s) * 64 + lane];
+        }
     }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) hf[i >> 3][i & 7] = (__bf16)silu_f(acc[i] + b1v[i]);
 #pragma unroll
     for (int ob = 0; ob < OBT; ++ob)
       if (ob < OB) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const bf16x8 a = w2[((size_t)ob * KS2 + 2 * hb + s) * 64 + lane];
-          oacc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hf[s], oacc[ob], 0, 0, 0);
-        }
+        for (int s = 0; s < 2; ++s) oacc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[ob][s], hf[s], oacc[ob], 0, 0, 0);
       }
     if constexpr (PF) {
 #pragma unroll
