@@ -57,6 +57,7 @@ class _Workspace:
         rows = _round_up(rows, 64)
         e = lambda *shape, dt=dtype: torch.empty(*shape, dtype=dt, device=device)
         # [h_i | h_j | d2 | 1 | 0...]: 128 columns when the hand-written GEMMs run (their operand width), else padded to 8
+        self.hip_gemms = bool(hip_gemms)   # the decision itself: K1P == 128 also happens for H in 60..63 without it
         self.K1P = 128 if hip_gemms else _round_up(2 * H + 2, 8)
         self.rows, self.dtype = rows, dtype
         if not saved_activations:   # (the saved-activation backward reads s1 / a2 from what the forward kept)
@@ -102,7 +103,7 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_
     Wx, Wm, M = lin_x0.out_features, lin_m0.out_features, lin_m2.out_features
     f32 = dict(dtype=torch.float32, device=h.device)
 
-    hip = fused is not None and dt == torch.bfloat16 and K1P == 128 and _hip_gemm_shapes(H, Wx, Wm, M)
+    hip = fused is not None and dt == torch.bfloat16 and ws.hip_gemms and _hip_gemm_shapes(H, Wx, Wm, M)
     if hip:
         from .gemm import gemm_rows, gemm_tn, pack_rows_weights
 
@@ -306,6 +307,8 @@ class _EGNNFunction(torch.autograd.Function):
         layers, plan, prec = ctx.layers, ctx.plan, ctx.prec
         if prec == _lib.PREC_BF16X3:   # forward on the split-operand kernels; the backward chain is the fp32 one
             prec = _lib.PREC_F32
+        if prec == _lib.PREC_F16:      # forward on fp16 operands; the backward recomputes on the bf16 kernels
+            prec = _lib.PREC_BF16
         scope_graph = ctx.scope == _lib.NORM_GRAPH
         saved = ctx.saved_tensors
         dst32, src32 = plan.edge_dst, plan.edge_src
@@ -340,7 +343,8 @@ class _EGNNFunction(torch.autograd.Function):
             h_l, x_l, sum_m, sum_x, S = saved[5 * l:5 * l + 5]
             # node part
             zero = lambda o, like: o.clone() if o is not None else torch.zeros_like(like)
-            node_hip = (ws is not None and ws.K1P == 128 and h_l.shape[1] <= 64 and layer.mlp_h[0].weight.shape[0] % 256 == 0)
+            node_hip = (ws is not None and ws.hip_gemms and prec == _lib.PREC_BF16 and h_l.shape[1] <= 64 and
+                        layer.mlp_h[0].weight.shape[0] % 256 == 0)
             if node_hip:
                 # x' = x + sum_x / (G + 1) (:64, :70): element-wise, differentiated by torch; the node MLP on the own GEMMs
                 with torch.enable_grad():

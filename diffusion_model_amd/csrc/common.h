@@ -61,6 +61,14 @@ struct LayerPack {
   void* w1hl_bf16 = nullptr;  // scaled first layers as bf16 hi/lo B fragments [TC/32][3][hi|lo][64][8] (node_pre_hilo_kernel)
   void* w1h_bf16 = nullptr;   // mlp_h.0 bf16 fragments (N = WhP, K = K1Q)
   void* w2h_bf16p = nullptr;  // mlp_h.2 bf16 fragments, k in accumulator-row order
+  // precision fp16: the streams of the bf16 path as fp16 fragments, every one multiplied by kF16WScale = 2^8 (kernels.h)
+  void* w2x_f16s16 = nullptr;  // mlp_x.2 scaled, v_mfma_f32_16x16x32_f16 B fragments
+  void* w2m_f16s = nullptr;    // mlp_m.2 scaled, v_mfma_f32_32x32x16_f16 B fragments
+  void* w1h_f16 = nullptr;     // mlp_h.0
+  void* w2h_f16p = nullptr;    // mlp_h.2, k in accumulator-row order
+  // split-operand node MLP (node_post_bf16_kernel<., f16x8, true>): mlp_h.0 head / remainder with K padded to its ring's two
+  // turns, mlp_h.2 remainder (its head is w2h_f16p); null when the shape is outside that kernel
+  void *w1h_f16k = nullptr, *w1h_f16k_lo = nullptr, *w2h_f16p_lo = nullptr;
 };
 
 constexpr int kGraphSteps = 8;   // reverse steps captured per hipGraph
@@ -105,7 +113,7 @@ struct egnn_ctx {
   float* part_x = nullptr;   // [tiles][2][4]
   float* node_d2 = nullptr;  // [N]
   float* gscale = nullptr;   // [B] sum of d^2 per graph (G^2); node_post applies 1/(G+1)
-  int last_R = 64, last_nsplit_x = 1;   // edge path chosen by the last launch_layer_begin
+  int last_R = 64, last_nsplit_x = 1, last_path = 1;   // edge path chosen by the last launch_layer_begin
   bool sq_from_agg = false;             // node_post takes the d^2 sums from the coordinate sums' component 3
   float* h_partial = nullptr;  // [8][N][H] partial node-MLP outputs (hidden-split node_post at small N)
   float* bwd_s = nullptr;    // [nsplit][chunk edges] column-split shares of s_e (backward recompute)

@@ -76,8 +76,12 @@ __host__ __device__ inline size_t v4_smem_bytes(int KP, int MP, bool is_m) {
 // also written to HBM (s1_out) and the epilogue produces dL/d(a2m) through the gate instead of the segment sums.
 // SAVE = true (message kernel): the training forward: also leaves the activation chunks (s1_out) and the scaled
 // second-layer pre-activations (g_a2_out) in HBM (see edge_bf16_v3.hip).
-template <int CB, bool IS_M, bool BWD = false, bool SAVE = false>
+// V8 = the MFMA operand type: bf16x8 (precision bf16) or f16x8 (precision fp16, plain forward only; kernels.h).
+template <int CB, bool IS_M, bool BWD = false, bool SAVE = false, typename V8 = bf16x8>
 __global__ __launch_bounds__(kT3, ((CB == 1 && !BWD) ? EGNN_V4_M_WAVES : 2)) void edge_kernel_bf16_v4(const EdgeParams p) {
+  static_assert(!((BWD || SAVE) && OpTraits<V8>::f16), "the training kernels keep bf16 activations");
+  typedef typename OpTraits<V8>::elem elem;
+  if constexpr (OpTraits<V8>::f16) f16_saturate_mode();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const Lds L(smem);
   int* const s_dst = L.dst; int* const s_src = L.src;
@@ -168,10 +172,10 @@ __global__ __launch_bounds__(kT3, ((CB == 1 && !BWD) ? EGNN_V4_M_WAVES : 2)) voi
   };
   // chunks 0 and 1 are built up front (ring slots 0 and 1)
   // backward: the activation chunk also goes to HBM, 16 bytes per thread, 128 contiguous bytes per row and chunk
-  auto s1_store = [&](const bf16x8 ov, const int row, const int c) {
+  auto s1_store = [&](const V8 ov, const int row, const int c) {
     if (half != 0) return;
     if (row < nvalid)
-      *reinterpret_cast<bf16x8*>(static_cast<__bf16*>(p.s1_out) + (size_t)(e0 + row) * KP + c * kKC3 + kg * 8) = ov;
+      *reinterpret_cast<V8*>(static_cast<__bf16*>(p.s1_out) + (size_t)(e0 + row) * KP + c * kKC3 + kg * 8) = ov;
   };
   // chunks 0 and 1: all four table pieces and the first weight fragments are requested, THEN the segment structure of the tile
   // is worked out (two barriers, waves 0 and 1 only) while they are in flight, then the activations are finished (as in
@@ -182,20 +186,20 @@ __global__ __launch_bounds__(kT3, ((CB == 1 && !BWD) ? EGNN_V4_M_WAVES : 2)) voi
   // weight fragments, requested BQD k-steps ahead of their use (a whole chunk for the coordinate kernel; the message
   // kernel, compiled for <= 128 VGPRs so that two workgroups share a CU, keeps 2 -- its other workgroup covers the rest)
   constexpr int BQD = (CB == 1 && !BWD && EGNN_V4_M_WAVES >= 4) ? 2 : 4;
-  bf16x8 bq[BQD][CB];
+  V8 bq[BQD][CB];
 #pragma unroll
   for (int s = 0; s < BQD; ++s)
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb) bq[s][cb] = ldbuf_bf16x8(rs_w, lane16, w0off + ((unsigned)cb * KS + s) * 1024u);
+    for (int cb = 0; cb < CB; ++cb) bq[s][cb] = ldbuf_v8<V8>(rs_w, lane16, w0off + ((unsigned)cb * KS + s) * 1024u);
   const int S = prologue_segments<false>(p, L, e0, nvalid, tid, lane, wave);
   {
-    const bf16x8 o0 = unith_finish(u0, s_wd + kg * 8, d2r0, slot0);
-    const bf16x8 o1 = unith_finish(u1, s_wd + kg * 8, d2r1, slot1);
+    const V8 o0 = unith_finish<V8>(u0, s_wd + kg * 8, d2r0, slot0);
+    const V8 o1 = unith_finish<V8>(u1, s_wd + kg * 8, d2r1, slot1);
     if constexpr (BWD || SAVE) { s1_store(o0, brow, 0); s1_store(o1, brow + 64, 0); }
   }
   {
-    const bf16x8 o0 = unith_finish(u2, s_wd + kKC3 + kg * 8, d2r0, slot0 + kA1_3);
-    const bf16x8 o1 = unith_finish(u3, s_wd + kKC3 + kg * 8, d2r1, slot1 + kA1_3);
+    const V8 o0 = unith_finish<V8>(u2, s_wd + kKC3 + kg * 8, d2r0, slot0 + kA1_3);
+    const V8 o1 = unith_finish<V8>(u3, s_wd + kKC3 + kg * 8, d2r1, slot1 + kA1_3);
     if constexpr (BWD || SAVE) { s1_store(o0, brow, 1); s1_store(o1, brow + 64, 1); }
   }
   uload(u0, vdst0, vsrc0, 2); uload(u1, vdst1, vsrc1, 2);
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(kT3, ((CB == 1 && !BWD) ? EGNN_V4_M_WAVES : 2)) voi
 
   // ring offsets (bytes): chunk c is read at off_cur, chunk c+1 at off_nxt, chunk c+2 is written at off_wr
   unsigned off_cur = 0u, off_nxt = (unsigned)kA1_3, off_wr = 2u * (unsigned)kA1_3;
-  bf16x8 a[kRB3];
+  V8 a[kRB3];
 #define LDS_RD(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(off))
 #define LDS_WAIT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
   LDS_RD(a[0], lds_a1_base, 0); LDS_RD(a[1], lds_a1_base, 512); LDS_RD(a[2], lds_a1_base, 1024); LDS_RD(a[3], lds_a1_base, 1536);
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(kT3, ((CB == 1 && !BWD) ? EGNN_V4_M_WAVES : 2)) voi
     STAMP(c, 0);
     const unsigned abase = lds_a1_base + off_cur, nbase = lds_a1_base + off_nxt;
     f16x8 t;
-    bf16x8 o;
+    V8 o;
     const float* wdc = s_wd + (c + 2) * kKC3 + kg * 8;   // d^2 column of the first layer for this thread's 8 hidden units
     // The 16 activations a thread owes to chunk c+2 are finished 4 per k-step, as a software pipeline over the 8 MFMA
     // gaps of the k-step: every gap issues ~16 cycles of INDEPENDENT vector instructions whose operands were produced at
@@ -244,10 +248,10 @@ __global__ __launch_bounds__(kT3, ((CB == 1 && !BWD) ? EGNN_V4_M_WAVES : 2)) voi
       if ((Q) == 5) { pe[2] = __builtin_amdgcn_rcpf(pe[2]); pe[3] = __builtin_amdgcn_rcpf(pe[3]); }           \
       if ((Q) == 6) { _Pragma("unroll") for (int k = 0; k < 4; ++k) pu[k] = pu[k] * pe[k]; }                  \
       if ((Q) == 7) {                                                                                         \
-        _Pragma("unroll") for (int k = 0; k < 4; ++k) o[e0_ + k] = (__bf16)pu[k];                             \
-        if ((S) == 1) { *reinterpret_cast<bf16x8*>(slot0 + off_wr) = o; uload(u0, vdst0, vsrc0, c + 3);       \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) o[e0_ + k] = (elem)pu[k];                             \
+        if ((S) == 1) { *reinterpret_cast<V8*>(slot0 + off_wr) = o; uload(u0, vdst0, vsrc0, c + 3);       \
                         if constexpr (BWD || SAVE) s1_store(o, brow, c + 2); }                                        \
-        if ((S) == 3) { *reinterpret_cast<bf16x8*>(slot1 + off_wr) = o; uload(u1, vdst1, vsrc1, c + 3);       \
+        if ((S) == 3) { *reinterpret_cast<V8*>(slot1 + off_wr) = o; uload(u1, vdst1, vsrc1, c + 3);       \
                         if constexpr (BWD || SAVE) s1_store(o, brow + 64, c + 2); }                                   \
       }                                                                                                       \
     }
@@ -258,12 +262,12 @@ __global__ __launch_bounds__(kT3, ((CB == 1 && !BWD) ? EGNN_V4_M_WAVES : 2)) voi
       else if ((RB) == 2) LDS_WAIT(1);                                                                        \
       else LDS_WAIT(0);                                                                                       \
       asm volatile("" : "+v"(a[RB]));                                                                         \
-      acc[RB][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[RB], bq[(S) % BQD][0], acc[RB][0], 0, 0, 0);     \
+      acc[RB][0] = mfma32(a[RB], bq[(S) % BQD][0], acc[RB][0]);                                               \
       __builtin_amdgcn_sched_barrier(0);                                                                      \
       STAGE(S, 2 * (RB))                                                                                      \
       __builtin_amdgcn_sched_barrier(0);                                                                      \
       _Pragma("unroll") for (int cb = 1; cb < CB; ++cb)                                                       \
-        acc[RB][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[RB], bq[(S) % BQD][cb], acc[RB][cb], 0, 0, 0); \
+        acc[RB][cb] = mfma32(a[RB], bq[(S) % BQD][cb], acc[RB][cb]);                                          \
       if ((S) < 3) LDS_RD(a[RB], abase, ((S) + 1) * 4128 + (RB) * 512);                                       \
       else if (!last) LDS_RD(a[RB], nbase, (RB) * 512);                                                       \
       __builtin_amdgcn_sched_barrier(0);                                                                      \
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(kT3, ((CB == 1 && !BWD) ? EGNN_V4_M_WAVES : 2)) voi
     if (!last || (S) + BQD < 4) {   /* k-step c*4 + S + BQD: this chunk's or the next one's */                \
       const unsigned ksn = (unsigned)(c * 4 + (S) + BQD) * 1024u;                                             \
       _Pragma("unroll") for (int cb = 0; cb < CB; ++cb)                                                       \
-        bq[(S) % BQD][cb] = ldbuf_bf16x8(rs_w, lane16, w0off + (unsigned)cb * KS * 1024u + ksn);              \
+        bq[(S) % BQD][cb] = ldbuf_v8<V8>(rs_w, lane16, w0off + (unsigned)cb * KS * 1024u + ksn);              \
     }
     KSTEP(0) KSTEP(1)
     STAMP(c, 1);
@@ -411,16 +415,16 @@ __global__ __launch_bounds__(kT3, ((CB == 1 && !BWD) ? EGNN_V4_M_WAVES : 2)) voi
         store_block_bf16(blk, 1, stg, tout + (size_t)(32 * rb) * p.MP, (size_t)p.MP, nvalid - 32 * rb, lane);
       }
     }
-    message_epilogue<SAVE>(p, L, acc, S, tile, tid, lane, wave);
+    message_epilogue<SAVE>(p, L, acc, S, tile, tid, lane, wave, kNegLog2e / OpTraits<V8>::wscale);
   }
   STAMP(31, 0);   // epilogue done
   WG_STAMP(4);
   WG_STAMP_HW();
 }
 
-template <int CB, bool IS_M, bool BWD = false, bool SAVE = false>
+template <int CB, bool IS_M, bool BWD = false, bool SAVE = false, typename V8 = bf16x8>
 int launch_v4(const EdgeParams& p, int blocks, size_t smem, hipStream_t st) {
-  hipLaunchKernelGGL((edge_kernel_bf16_v4<CB, IS_M, BWD, SAVE>), dim3(blocks), dim3(kT3), smem, st, p);
+  hipLaunchKernelGGL((edge_kernel_bf16_v4<CB, IS_M, BWD, SAVE, V8>), dim3(blocks), dim3(kT3), smem, st, p);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }
@@ -433,6 +437,8 @@ int init_edge_bf16_v4_attributes() {
   EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v4<1, true, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v4<1, true, false, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_kernel_bf16_v4<1, true, false, false, f16x8>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   return EGNN_OK;
 }
@@ -456,6 +462,12 @@ int launch_edge_bf16_v4_m_bwd(const EdgeParams& p, hipStream_t st) {
 int launch_edge_bf16_v4_m_save(const EdgeParams& p, hipStream_t st) {
   const int tiles = (p.E + kR3 - 1) / kR3;
   return launch_v4<1, true, false, true>(p, tiles, v4_smem_bytes(p.WmP, p.MP, true), st);
+}
+
+// message kernel, precision fp16: p.w2m = the fp16 fragment stream (scaled by -2^8 / log2(e))
+int launch_edge_f16_v4_m(const EdgeParams& p, hipStream_t st) {
+  const int tiles = (p.E + kR3 - 1) / kR3;
+  return launch_v4<1, true, false, false, f16x8>(p, tiles, v4_smem_bytes(p.WmP, p.MP, true), st);
 }
 
 // message kernel only

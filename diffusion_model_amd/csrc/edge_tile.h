@@ -209,9 +209,10 @@ __device__ __forceinline__ void x_head(const EdgeParams& p, const Lds& L, const 
 // One 32-column block per wave (256 message columns per workgroup).  Segments are summed kSegFast per pass: the gate of
 // each row is laid out per segment in LDS (L.gseg) and every lane dots its 64 message values with it -- no staging tile.
 // PRE_SCALED: acc already holds t2 = -log2(e) * (a2 + b2) (the training forward stores it before this call).
+// acc_scale: t2 = acc_scale * acc + b2 (-log2(e); precision fp16 divides the weight fragments' 2^8 out here).
 template <bool PRE_SCALED = false>
 __device__ __forceinline__ void message_epilogue(const EdgeParams& p, const Lds& L, const f32x16 (&acc)[4][1], int S, int tile,
-                                                 int tid, int lane, int wave) {
+                                                 int tid, int lane, int wave, const float acc_scale = kNegLog2e) {
   const int r = lane & 31, hh = lane >> 5;
   const int ncol = 32 * wave + r;
   float mval[64];
@@ -222,7 +223,7 @@ __device__ __forceinline__ void message_epilogue(const EdgeParams& p, const Lds&
     for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float m = silu_s(PRE_SCALED ? acc[rb][0][i] : fmaf(acc[rb][0][i], kNegLog2e, bb));   // = -log2(e) * m
+        const float m = silu_s(PRE_SCALED ? acc[rb][0][i] : fmaf(acc[rb][0][i], acc_scale, bb));   // = -log2(e) * m
         mval[rb * 16 + i] = m;
         if (rb < 2) lo[rb * 16 + i] = wa * m; else hi[(rb - 2) * 16 + i] = wa * m;
       }

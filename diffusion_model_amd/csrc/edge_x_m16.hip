@@ -53,8 +53,12 @@ typedef __attribute__((ext_vector_type(4))) float f32x4v;
 // (s1_out, as the MFMA consumed them), the scaled second-layer pre-activations -log2(e) * (a2 + b2) (g_a2_out, row-major bf16
 // through a per-wave LDS transpose) and this column share of s_e (s_half_out) -- what edge_kernel_bf16_v3<2, false, false, true>
 // leaves, so that egcl_backward_heads_saved / the wgrad GEMMs find the same buffers.
-template <bool SAVE>
+// V8 = the MFMA operand type: bf16x8 (precision bf16) or f16x8 (precision fp16: v_mfma_f32_16x16x32_f16, same rate, 11
+// significant bits; weights packed x 2^8, kernels.h "MFMA operand type").
+template <bool SAVE, typename V8 = bf16x8>
 __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
+  static_assert(!(SAVE && OpTraits<V8>::f16), "the training forward keeps bf16 activations");
+  if constexpr (OpTraits<V8>::f16) f16_saturate_mode();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const Lds L(smem);
   char* s_a1 = smem + kOffLoop;
@@ -124,14 +128,14 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
 
   // training forward: the activation chunk also goes to HBM, 16 bytes per thread, 128 contiguous bytes per row and chunk
   // (both column shares build the same activations: only share 0 stores them)
-  auto s1_store = [&](const bf16x8 o0, const bf16x8 o1, const int c) {
+  auto s1_store = [&](const V8 o0, const V8 o1, const int c) {
     if (half != 0) return;
 #ifdef EGNN_EXP_NO_S1   // timing experiment
     return;
 #endif
     __bf16* base = static_cast<__bf16*>(p.s1_out) + (size_t)e0 * KP + c * kKC + kg * 8;
-    if (brow < nvalid) *reinterpret_cast<bf16x8*>(base + (size_t)brow * KP) = o0;
-    if (brow + 64 < nvalid) *reinterpret_cast<bf16x8*>(base + (size_t)(brow + 64) * KP) = o1;
+    if (brow < nvalid) *reinterpret_cast<V8*>(base + (size_t)brow * KP) = o0;
+    if (brow + 64 < nvalid) *reinterpret_cast<V8*>(base + (size_t)(brow + 64) * KP) = o1;
   };
   // chunk 0: both rows' table pieces and the first weight fragments are requested, THEN the segment structure of the tile is
   // worked out (two barriers, waves 0 and 1 only) while they are in flight, then the activations are finished
@@ -139,15 +143,15 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
   UnitH uc0, uc1;
   unith_load(uc0, rs_tab, vdst0, vsrc0, offP, offQ);
   unith_load(uc1, rs_tab, vdst1, vsrc1, offP, offQ);
-  bf16x8 bq[2][4];   // weight fragments of the 2 k-steps of the current chunk
+  V8 bq[2][4];   // weight fragments of the 2 k-steps of the current chunk
 #pragma unroll
   for (int s = 0; s < 2; ++s)
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) bq[s][cb] = ldbuf_bf16x8(rs_w, lane16, w0 + ((unsigned)cb * KS + s) * 1024u);
+    for (int cb = 0; cb < 4; ++cb) bq[s][cb] = ldbuf_v8<V8>(rs_w, lane16, w0 + ((unsigned)cb * KS + s) * 1024u);
   const int S = prologue_segments<false>(p, L, e0, nvalid, tid, lane, wave);   // seg_mode: under the first matrix phase, below
   {
-    const bf16x8 o0 = unith_finish(uc0, s_wd + kg * 8, d2r0, slot0);
-    const bf16x8 o1 = unith_finish(uc1, s_wd + kg * 8, d2r1, slot1);
+    const V8 o0 = unith_finish<V8>(uc0, s_wd + kg * 8, d2r0, slot0);
+    const V8 o1 = unith_finish<V8>(uc1, s_wd + kg * 8, d2r1, slot1);
     if constexpr (SAVE) s1_store(o0, o1, 0);
   }
   __syncthreads();
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
   auto mphase = [&](const int c, const bool last) {
     const unsigned boff = (unsigned)(c & 1) * (unsigned)kA1;
     const unsigned ab0 = abase0 + boff, ab1 = abase1 + boff;
-    bf16x8 a[3];   // ring of 3 operand pieces: use u = 8 s + rb takes a[u % 3], which is refilled for use u + 3 right after
+    V8 a[3];   // ring of 3 operand pieces: use u = 8 s + rb takes a[u % 3], which is refilled for use u + 3 right after
                    // (a fourth set costs the 4 registers that made hipcc spill around the K loop: 63 MB of scratch traffic per launch)
 #define LDS_RD(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(off))
 #define LDS_WAIT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
         asm volatile("" : "+v"(a[u % 3]));   // uses of the piece stay below the wait
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
-          acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u % 3], bq[s][cb], acc[rb][cb], 0, 0, 0);
+          acc[rb][cb] = mfma16(a[u % 3], bq[s][cb], acc[rb][cb]);
         // refill in place for use u + 3 (the MFMAs above have read the registers at issue): row block (u + 3) & 7 of k-step (u + 3) >> 3
         if (u == 0) LDS_RD(a[0], ab0, 768); if (u == 1) LDS_RD(a[1], ab0, 1024); if (u == 2) LDS_RD(a[2], ab0, 1280);
         if (u == 3) LDS_RD(a[0], ab0, 1536); if (u == 4) LDS_RD(a[1], ab0, 1792); if (u == 5) LDS_RD(a[2], ab1, 0);
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
       if (!last) {
         const unsigned ksn = (unsigned)((c + 1) * 2 + s) * 1024u;
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) bq[s][cb] = ldbuf_bf16x8(rs_w, lane16, w0 + (unsigned)cb * KS * 1024u + ksn);
+        for (int cb = 0; cb < 4; ++cb) bq[s][cb] = ldbuf_v8<V8>(rs_w, lane16, w0 + (unsigned)cb * KS * 1024u + ksn);
       }
     }
 #undef LDS_WAIT
@@ -203,8 +207,8 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
   auto vfinish = [&](const int c) {  // SiLU + bf16 pack of chunk c into its LDS buffer
     const size_t nbuf = (size_t)(c & 1) * kA1;
     __builtin_amdgcn_s_setprio(3);   // vector work wins issue arbitration over the partner wave's MFMAs
-    const bf16x8 o0 = unith_finish(ua0, s_wd + c * kKC + kg * 8, d2r0, slot0 + nbuf);
-    const bf16x8 o1 = unith_finish(ua1, s_wd + c * kKC + kg * 8, d2r1, slot1 + nbuf);
+    const V8 o0 = unith_finish<V8>(ua0, s_wd + c * kKC + kg * 8, d2r0, slot0 + nbuf);
+    const V8 o1 = unith_finish<V8>(ua1, s_wd + c * kKC + kg * 8, d2r1, slot1 + nbuf);
     __builtin_amdgcn_s_setprio(0);
     if constexpr (SAVE) s1_store(o0, o1, c);
   };
@@ -283,7 +287,8 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
   for (int cb = 0; cb < 4; ++cb) {
     const int n = 16 * (cb0 + cb) + r15;
     const float bb = p.b2x[n], w = p.w3x[n];
-    const f32x2 bb2 = {bb, bb}, w2 = {w, w}, k2 = {kNegLog2e, kNegLog2e}, one2 = {1.0f, 1.0f};
+    constexpr float kAcc = kNegLog2e / OpTraits<V8>::wscale;   // fp16: the weight fragments carry 2^8
+    const f32x2 bb2 = {bb, bb}, w2 = {w, w}, k2 = {kAcc, kAcc}, one2 = {1.0f, 1.0f};
 #pragma unroll
     for (int rb = 0; rb < 8; ++rb)
 #pragma unroll
@@ -333,6 +338,8 @@ int init_edge_x_m16_attributes() {
                                160 * 1024));
   EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_x_m16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                160 * 1024));
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_x_m16_kernel<false, f16x8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               160 * 1024));
   return EGNN_OK;
 }
 
@@ -347,6 +354,16 @@ int launch_edge_x_m16(const EdgeParams& p, hipStream_t st) {
   EdgeParams q = p;
   q.w2x = p.w2x16;
   hipLaunchKernelGGL(edge_x_m16_kernel<false>, dim3(tiles * (p.WxP / 512)), dim3(kT), x16_smem_bytes(p.WxP), st, q);
+  EGNN_HIP(hipGetLastError());
+  return EGNN_OK;
+}
+
+// precision fp16: p.w2x16 = the fp16 fragment stream (pack_frags_n16<_Float16>, scaled by -2^8 / log2(e))
+int launch_edge_x_m16_f16(const EdgeParams& p, hipStream_t st) {
+  const int tiles = (p.E + kR - 1) / kR;
+  EdgeParams q = p;
+  q.w2x = p.w2x16;
+  hipLaunchKernelGGL((edge_x_m16_kernel<false, f16x8>), dim3(tiles * (p.WxP / 512)), dim3(kT), x16_smem_bytes(p.WxP), st, q);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }

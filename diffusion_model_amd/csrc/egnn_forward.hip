@@ -57,8 +57,17 @@ __global__ void pack_frags_f32(const float* __restrict__ W, int Nout, int K, int
 }
 // v_mfma_f32_32x32x16_bf16: lane l holds B[k = 16*ks + 8*(l>>5) + j][n = 32*nb + (l&31)], j = 0..7.
 // out[((nb*KS + ks)*64 + lane)*8 + j]
+// OT = __bf16, or _Float16 for precision fp16 (scale then carries kF16WScale; clamped to the finite fp16 range)
+// LO: the remainder v - OT(v) of the same element (split-operand products)
+template <typename OT, bool LO = false>
+__device__ __forceinline__ OT to_operand(float v) {
+  if constexpr (sizeof(OT) == 2 && !__is_same(OT, __bf16)) v = fminf(fmaxf(v, -65504.f), 65504.f);
+  if constexpr (LO) return (OT)(v - (float)(OT)v);
+  return (OT)v;
+}
+template <typename OT, bool LO = false>
 __global__ void pack_frags_bf16(const float* __restrict__ W, int Nout, int K, int ldw, int NP, int KP,
-                                __bf16* __restrict__ out, float scale) {
+                                OT* __restrict__ out, float scale) {
   const int KS = KP / 16;
   const size_t total = (size_t)(NP / 32) * KS * 64 * 8;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -66,13 +75,14 @@ __global__ void pack_frags_bf16(const float* __restrict__ W, int Nout, int K, in
     const size_t f = i >> 9;
     const int ks = f % KS, nb = f / KS;
     const int n = 32 * nb + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + j;
-    out[i] = (__bf16)((n < Nout && k < K) ? W[(size_t)n * ldw + k] * scale : 0.f);
+    out[i] = to_operand<OT, LO>((n < Nout && k < K) ? W[(size_t)n * ldw + k] * scale : 0.f);
   }
 }
 // v_mfma_f32_16x16x32_bf16: lane l holds B[k = 32*ks + 8*(l>>4) + j][n = 16*nb + (l&15)], j = 0..7.
 // out[((nb*KS + ks)*64 + lane)*8 + j]
+template <typename OT>
 __global__ void pack_frags_bf16_n16(const float* __restrict__ W, int Nout, int K, int ldw, int NP, int KP,
-                                    __bf16* __restrict__ out, float scale) {
+                                    OT* __restrict__ out, float scale) {
   const int KS = KP / 32;
   const size_t total = (size_t)(NP / 16) * KS * 64 * 8;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -80,7 +90,7 @@ __global__ void pack_frags_bf16_n16(const float* __restrict__ W, int Nout, int K
     const size_t f = i >> 9;
     const int ks = f % KS, nb = f / KS;
     const int n = 16 * nb + (lane & 15), k = 32 * ks + 8 * (lane >> 4) + j;
-    out[i] = (__bf16)((n < Nout && k < K) ? W[(size_t)n * ldw + k] * scale : 0.f);
+    out[i] = to_operand<OT>((n < Nout && k < K) ? W[(size_t)n * ldw + k] * scale : 0.f);
   }
 }
 // bf16 remainder of the same fragments: out = bf16(v - bf16(v)), v = W * scale (precision bf16x3)
@@ -99,8 +109,9 @@ __global__ void pack_frags_bf16_lo(const float* __restrict__ W, int Nout, int K,
 }
 // mlp_h.2 as the A operand of out^T = W2h . hidden^T where hidden^T comes straight from an accumulator tile:
 // element j of lane half hh in k-step ks is hidden unit 32*(ks/2) + 16*(ks%2) + 8*(j>>2) + 4*hh + (j&3).
+template <typename OT, bool LO = false>
 __global__ void pack_frags_bf16_accperm(const float* __restrict__ W, int Nout, int K, int ldw, int NP, int KP,
-                                        __bf16* __restrict__ out) {
+                                        OT* __restrict__ out, float scale) {
   const int KS = KP / 16;
   const size_t total = (size_t)(NP / 32) * KS * 64 * 8;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -109,7 +120,7 @@ __global__ void pack_frags_bf16_accperm(const float* __restrict__ W, int Nout, i
     const int ks = f % KS, nb = f / KS;
     const int n = 32 * nb + (lane & 31);
     const int k = 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
-    out[i] = (__bf16)((n < Nout && k < K) ? W[(size_t)n * ldw + k] : 0.f);
+    out[i] = to_operand<OT, LO>((n < Nout && k < K) ? W[(size_t)n * ldw + k] * scale : 0.f);
   }
 }
 // the same fragment layout for B[k][n] = W[k][n] (the transposed use of an nn.Linear weight: dgrad g . W)
@@ -1157,6 +1168,13 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
     else prec = EGNN_PREC_F32;
     fill_edge_params(c, layer, prec, x, p);
   }
+  if (prec == EGNN_PREC_F16) {   // fp16 operands on the bf16 path's kernels (hidden width 512 / 1024), else the exact fp32 path
+    EdgeParams q = p;
+    const float *w1c, *b1c;
+    use_scaled_pack(c, layer, q, w1c, b1c);
+    if (edge_sel >= 4 && edge_bf16_v4_supported(q) && edge_x_m16_supported(q) && !c->save_s1x) path = 6;
+    else { prec = EGNN_PREC_F32; fill_edge_params(c, layer, prec, x, p); }
+  }
   if (prec == EGNN_PREC_BF16 && edge_sel >= 4 && edge_bf16_v4_supported(p) && edge_bf16_v3_supported(p)) path = 4;
   if (c->save_s1x && path != 4) { set_error("egcl_forward_save needs the 128-edge-tile bf16 kernels"); return EGNN_EINVAL; }
   const float* w1catT = lp.w1catT;
@@ -1173,7 +1191,7 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
       else
         hipLaunchKernelGGL(node_pre_kernel<float>, dim3((N + kPreNodes - 1) / kPreNodes, (c->TC + kThreads - 1) / kThreads),
                            dim3(kThreads), (size_t)kPreNodes * c->H * sizeof(float), st, h, N, c->H, w1catT, b1cat, c->TC, c->table);
-    } else if (path == 4) {   // half-precision table
+    } else if (path == 4 || path == 6) {   // half-precision table
       int rc = launch_node_pre_f16(c, st, layer, h, w1catT, b1cat);
       if (rc) return rc;
     } else if (c->H <= 64) {
@@ -1206,6 +1224,22 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
       R = 128;
       nsplit_x = p.WxP / 256;
       rc = launch_edge_bf16x3(p, st);
+    } else if (path == 6) {   // precision fp16: the path-4 kernels on fp16 operands (same tiles, same launch structure)
+      R = edge_v4_rows();
+      nsplit_x = p.WxP / 512;
+      p.w2x16 = lp.w2x_f16s16; p.w2m = lp.w2m_f16s;
+      const bool fork = !c->prof && st != nullptr && c->side != nullptr && c->ev_fork != nullptr && fork_candidate(E, p.WxP);
+      if (fork) {
+        EGNN_HIP(hipEventRecord(c->ev_fork, st));
+        EGNN_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+        rc = launch_edge_x_m16_f16(p, st);
+        if (!rc) rc = launch_edge_f16_v4_m(p, c->side);
+        EGNN_HIP(hipEventRecord(c->ev_join, c->side));
+        EGNN_HIP(hipStreamWaitEvent(st, c->ev_join, 0));
+      } else {
+        rc = launch_edge_x_m16_f16(p, st);
+        if (!rc) rc = launch_edge_f16_v4_m(p, st);
+      }
     } else if (path == 4) {
       R = edge_v4_rows();
       const bool xm16 = edge_x_m16_supported(p);   // hidden width 512 / 1024: v_mfma_f32_16x16x32_bf16 (512 columns per workgroup)
@@ -1236,7 +1270,7 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
     if (rc) return rc;
   }
 
-  c->last_R = R; c->last_nsplit_x = nsplit_x;
+  c->last_R = R; c->last_nsplit_x = nsplit_x; c->last_path = path;
   c->sq_from_agg = false;
   if (path >= 4) {
     if (E == 0) {
@@ -1273,7 +1307,21 @@ int launch_layer_end(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_
     q.w1h_bf16 = lp.w1h_bf16; q.w2h_bf16p = lp.w2h_bf16p; q.K1Q = c->K1Q;
     q.h_partial = c->h_partial;
     prof_begin(c, st, 1);
-    if (prec == EGNN_PREC_BF16 && node_post_bf16_supported(q)) {
+    // node MLP of precision fp16 (and of bf16x3 on the 128-edge-tile path): split-operand fp16 products (22 significant bits,
+    // node_bf16.hip) where the shape allows, else the exact fp32 kernel.  EGNN_F16_NODE (error-budget experiments only):
+    // 0 = exact fp32 node MLP, 1 = plain fp16 operands.
+    static const int f16_node = getenv("EGNN_F16_NODE") ? atoi(getenv("EGNN_F16_NODE")) : 2;
+    PostParams qs = q;
+    qs.w1h_bf16 = lp.w1h_f16k; qs.w2h_bf16p = lp.w2h_f16p; qs.w1h_lo = lp.w1h_f16k_lo; qs.w2h_lo = lp.w2h_f16p_lo;
+    const bool half_path = (prec == EGNN_PREC_F16 && c->last_path == 6) || (prec == EGNN_PREC_BF16X3 && c->last_path == 5);
+    if (half_path && f16_node == 2 && node_post_split_supported(qs)) {
+      int rc = launch_node_post_bf16(qs, st, true, true);
+      if (rc) return rc;
+    } else if (prec == EGNN_PREC_F16 && c->last_path == 6 && f16_node == 1 && node_post_bf16_supported(q)) {
+      q.w1h_bf16 = lp.w1h_f16; q.w2h_bf16p = lp.w2h_f16p;
+      int rc = launch_node_post_bf16(q, st, true);
+      if (rc) return rc;
+    } else if (prec == EGNN_PREC_BF16 && node_post_bf16_supported(q)) {
       int rc = launch_node_post_bf16(q, st);
       if (rc) return rc;
     } else {
@@ -1331,7 +1379,8 @@ int egnn_create(egnn_ctx** out, int device) {
 static void free_layer(LayerPack& lp) {
   void* ptrs[] = {lp.w1catT, lp.b1cat, lp.wdx, lp.wdm, lp.w2x_f32, lp.w2x_bf16, lp.b2x, lp.w3x, lp.w2m_f32,
                   lp.w2m_bf16, lp.b2m, lp.wa, lp.scal, lp.w1h_f32, lp.b1h, lp.w2h_f32, lp.b2h, lp.sc, lp.w2x_bf16s, lp.w2m_bf16s, lp.w1h_bf16, lp.w2h_bf16p,
-                  lp.w2xT_bf16, lp.w2mT_bf16, lp.w1hl_bf16, lp.w2x_bf16s16, lp.w2x_bf16s_lo, lp.w2m_bf16s_lo};
+                  lp.w2xT_bf16, lp.w2mT_bf16, lp.w1hl_bf16, lp.w2x_bf16s16, lp.w2x_bf16s_lo, lp.w2m_bf16s_lo,
+                  lp.w2x_f16s16, lp.w2m_f16s, lp.w1h_f16, lp.w2h_f16p, lp.w1h_f16k, lp.w1h_f16k_lo, lp.w2h_f16p_lo};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   lp = LayerPack();
@@ -1445,18 +1494,34 @@ int egnn_pack_layer(egnn_ctx* c, void* stream, int l, const float* m0_w, const f
     if ((rc = dev_alloc(&tmp, (size_t)MP * WmP))) return rc;
     lp.w2mT_bf16 = tmp; tmp = nullptr;
     if ((rc = dev_alloc(&tmp, (size_t)(TC / 32) * 3 * 2 * 512))) return rc;
-    lp.w1hl_bf16 = tmp;
+    lp.w1hl_bf16 = tmp; tmp = nullptr;
+    if ((rc = dev_alloc(&tmp, (size_t)WxP * WxP))) return rc;      // fp16 streams: same sizes as their bf16 twins
+    lp.w2x_f16s16 = tmp; tmp = nullptr;
+    if ((rc = dev_alloc(&tmp, (size_t)MP * WmP))) return rc;
+    lp.w2m_f16s = tmp; tmp = nullptr;
+    if ((rc = dev_alloc(&tmp, (size_t)WhP * c->K1Q))) return rc;
+    lp.w1h_f16 = tmp; tmp = nullptr;
+    if ((rc = dev_alloc(&tmp, (size_t)HP * WhP))) return rc;
+    lp.w2h_f16p = tmp; tmp = nullptr;
+    if (HP <= 64 && H + MP > node_post_split_k() / 2 && H + MP <= node_post_split_k()) {   // shapes of the split-operand node MLP
+      if ((rc = dev_alloc(&tmp, (size_t)WhP * node_post_split_k()))) return rc;
+      lp.w1h_f16k = tmp; tmp = nullptr;
+      if ((rc = dev_alloc(&tmp, (size_t)WhP * node_post_split_k()))) return rc;
+      lp.w1h_f16k_lo = tmp; tmp = nullptr;
+      if ((rc = dev_alloc(&tmp, (size_t)HP * WhP))) return rc;
+      lp.w2h_f16p_lo = tmp;
+    }
   }
   const dim3 g(256), b(256);
   hipLaunchKernelGGL(pack_first, g, b, 0, st, x0_w, x0_b, m0_w, m0_b, H, Wx, Wm, WxP, WmP, lp.w1catT, lp.b1cat);
   hipLaunchKernelGGL(pad_copy, dim3(8), b, 0, st, x0_w + 2 * H, Wx, 2 * H + 1, lp.wdx, WxP);
   hipLaunchKernelGGL(pad_copy, dim3(8), b, 0, st, m0_w + 2 * H, Wm, 2 * H + 1, lp.wdm, WmP);
   hipLaunchKernelGGL(pack_frags_f32, g, b, 0, st, x2_w, Wx, Wx, Wx, WxP, WxP, lp.w2x_f32);
-  hipLaunchKernelGGL(pack_frags_bf16, g, b, 0, st, x2_w, Wx, Wx, Wx, WxP, WxP, reinterpret_cast<__bf16*>(lp.w2x_bf16), 1.0f);
+  hipLaunchKernelGGL(pack_frags_bf16<__bf16>, g, b, 0, st, x2_w, Wx, Wx, Wx, WxP, WxP, reinterpret_cast<__bf16*>(lp.w2x_bf16), 1.0f);
   hipLaunchKernelGGL(pad_copy, dim3(8), b, 0, st, x2_b, Wx, 1, lp.b2x, WxP);
   hipLaunchKernelGGL(pad_copy, dim3(8), b, 0, st, x4_w, Wx, 1, lp.w3x, WxP);
   hipLaunchKernelGGL(pack_frags_f32, g, b, 0, st, m2_w, M, Wm, Wm, MP, WmP, lp.w2m_f32);
-  hipLaunchKernelGGL(pack_frags_bf16, g, b, 0, st, m2_w, M, Wm, Wm, MP, WmP, reinterpret_cast<__bf16*>(lp.w2m_bf16), 1.0f);
+  hipLaunchKernelGGL(pack_frags_bf16<__bf16>, g, b, 0, st, m2_w, M, Wm, Wm, MP, WmP, reinterpret_cast<__bf16*>(lp.w2m_bf16), 1.0f);
   hipLaunchKernelGGL(pad_copy, dim3(8), b, 0, st, m2_b, M, 1, lp.b2m, MP);
   hipLaunchKernelGGL(pad_copy, dim3(8), b, 0, st, a_w, M, 1, lp.wa, MP);
   hipLaunchKernelGGL(pad_copy, dim3(1), dim3(64), 0, st, x4_b, 1, 1, lp.scal, 1);
@@ -1477,13 +1542,24 @@ int egnn_pack_layer(egnn_ctx* c, void* stream, int l, const float* m0_w, const f
     hipLaunchKernelGGL(scale_copy, dim3(8), b, 0, st, lp.w3x, (size_t)WxP, s2, o); o += WxP;
     hipLaunchKernelGGL(scale_copy, dim3(8), b, 0, st, lp.b2m, (size_t)MP, s1, o); o += MP;
     hipLaunchKernelGGL(scale_copy, dim3(8), b, 0, st, lp.wa, (size_t)MP, s2, o);
-    hipLaunchKernelGGL(pack_frags_bf16, g, b, 0, st, x2_w, Wx, Wx, Wx, WxP, WxP, reinterpret_cast<__bf16*>(lp.w2x_bf16s), s2);
-    hipLaunchKernelGGL(pack_frags_bf16, g, b, 0, st, m2_w, M, Wm, Wm, MP, WmP, reinterpret_cast<__bf16*>(lp.w2m_bf16s), s2);
-    hipLaunchKernelGGL(pack_frags_bf16_n16, g, b, 0, st, x2_w, Wx, Wx, Wx, WxP, WxP, reinterpret_cast<__bf16*>(lp.w2x_bf16s16), s2);
+    hipLaunchKernelGGL(pack_frags_bf16<__bf16>, g, b, 0, st, x2_w, Wx, Wx, Wx, WxP, WxP, reinterpret_cast<__bf16*>(lp.w2x_bf16s), s2);
+    hipLaunchKernelGGL(pack_frags_bf16<__bf16>, g, b, 0, st, m2_w, M, Wm, Wm, MP, WmP, reinterpret_cast<__bf16*>(lp.w2m_bf16s), s2);
+    hipLaunchKernelGGL(pack_frags_bf16_n16<__bf16>, g, b, 0, st, x2_w, Wx, Wx, Wx, WxP, WxP, reinterpret_cast<__bf16*>(lp.w2x_bf16s16), s2);
+    // precision fp16: the same streams as fp16 fragments, times 2^8 (kernels.h "MFMA operand type")
+    hipLaunchKernelGGL(pack_frags_bf16_n16<_Float16>, g, b, 0, st, x2_w, Wx, Wx, Wx, WxP, WxP, reinterpret_cast<_Float16*>(lp.w2x_f16s16), s2 * kF16WScale);
+    hipLaunchKernelGGL(pack_frags_bf16<_Float16>, g, b, 0, st, m2_w, M, Wm, Wm, MP, WmP, reinterpret_cast<_Float16*>(lp.w2m_f16s), s2 * kF16WScale);
+    hipLaunchKernelGGL(pack_frags_bf16<_Float16>, g, b, 0, st, h0_w, Wh, H + M, H + M, WhP, c->K1Q, reinterpret_cast<_Float16*>(lp.w1h_f16), kF16WScale);
+    hipLaunchKernelGGL(pack_frags_bf16_accperm<_Float16>, g, b, 0, st, h2_w, H, Wh, Wh, HP, WhP, reinterpret_cast<_Float16*>(lp.w2h_f16p), kF16WScale);
+    if (lp.w1h_f16k) {   // split-operand node MLP: heads + remainders, mlp_h.0 with K padded to the ring's two turns
+      const int KS = node_post_split_k();
+      hipLaunchKernelGGL(pack_frags_bf16<_Float16>, g, b, 0, st, h0_w, Wh, H + M, H + M, WhP, KS, reinterpret_cast<_Float16*>(lp.w1h_f16k), kF16WScale);
+      hipLaunchKernelGGL((pack_frags_bf16<_Float16, true>), g, b, 0, st, h0_w, Wh, H + M, H + M, WhP, KS, reinterpret_cast<_Float16*>(lp.w1h_f16k_lo), kF16WScale);
+      hipLaunchKernelGGL((pack_frags_bf16_accperm<_Float16, true>), g, b, 0, st, h2_w, H, Wh, Wh, HP, WhP, reinterpret_cast<_Float16*>(lp.w2h_f16p_lo), kF16WScale);
+    }
     hipLaunchKernelGGL(pack_frags_bf16_lo, g, b, 0, st, x2_w, Wx, Wx, Wx, WxP, WxP, reinterpret_cast<__bf16*>(lp.w2x_bf16s_lo), s2);
     hipLaunchKernelGGL(pack_frags_bf16_lo, g, b, 0, st, m2_w, M, Wm, Wm, MP, WmP, reinterpret_cast<__bf16*>(lp.w2m_bf16s_lo), s2);
-    hipLaunchKernelGGL(pack_frags_bf16, g, b, 0, st, h0_w, Wh, H + M, H + M, WhP, c->K1Q, reinterpret_cast<__bf16*>(lp.w1h_bf16), 1.0f);
-    hipLaunchKernelGGL(pack_frags_bf16_accperm, g, b, 0, st, h2_w, H, Wh, Wh, HP, WhP, reinterpret_cast<__bf16*>(lp.w2h_bf16p));
+    hipLaunchKernelGGL(pack_frags_bf16<__bf16>, g, b, 0, st, h0_w, Wh, H + M, H + M, WhP, c->K1Q, reinterpret_cast<__bf16*>(lp.w1h_bf16), 1.0f);
+    hipLaunchKernelGGL(pack_frags_bf16_accperm<__bf16>, g, b, 0, st, h2_w, H, Wh, Wh, HP, WhP, reinterpret_cast<__bf16*>(lp.w2h_bf16p), 1.0f);
     if (H <= 48)   // hi/lo bf16 fragments of the scaled first-layer weights (node_pre_hilo_kernel)
       hipLaunchKernelGGL(pack_w1_hilo, g, b, 0, st, lp.sc, H, TC, reinterpret_cast<__bf16*>(lp.w1hl_bf16));
     // transposed packs for the backward dgrad: B[k = second-layer output][column = hidden unit]
@@ -1525,7 +1601,10 @@ int egnn_set_graph(egnn_ctx* c, int N, int E, int B, const int32_t* edge_dst, co
 
 static int check_ready(egnn_ctx* c, int prec, int norm_scope) {
   if (!c || c->L == 0 || c->N == 0) { set_error("model/graph not set"); return EGNN_ESTATE; }
-  if (prec != EGNN_PREC_F32 && prec != EGNN_PREC_BF16 && prec != EGNN_PREC_BF16X3) { set_error("bad precision %d", prec); return EGNN_EINVAL; }
+  if (prec != EGNN_PREC_F32 && prec != EGNN_PREC_BF16 && prec != EGNN_PREC_BF16X3 && prec != EGNN_PREC_F16) {
+    set_error("bad precision %d", prec);
+    return EGNN_EINVAL;
+  }
   if (norm_scope != EGNN_NORM_CALL && norm_scope != EGNN_NORM_GRAPH) { set_error("bad norm scope"); return EGNN_EINVAL; }
   return EGNN_OK;
 }

@@ -203,6 +203,37 @@ __device__ __forceinline__ void unit_finish(const Unit& u, const float* wd, floa
 // is rounded to afterwards): half the bytes through the vector-memory path, P + Q as packed-half adds and the
 // fp16 -> fp32 conversion folded into the fma (v_fma_mix_f32).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// ---- MFMA operand type of the half-precision paths: bf16x8 (precision bf16) or f16x8 (precision fp16) ------------------
+// fp16 operands have 11 significant bits against bf16's 8 at the same matrix-core rate.  What the narrower exponent needs:
+//  * the fp16 weight fragments are packed multiplied by kF16WScale = 2^8 (default-init and trained weights of a 1024-wide
+//    layer are ~1e-2: a fraction of them would otherwise be fp16 subnormals) and the accumulators divided by it in the
+//    epilogue's existing fma (the constant changes, no instruction is added);
+//  * overflow saturates instead of producing inf (an infinite activation times a zero weight would be NaN where the bf16
+//    path stays finite): the kernels set MODE.FP16_OVFL (f16_saturate_mode), which clamps an overflowing fp16 RESULT to
+//    +-65504 in hardware; the packs clamp explicitly.
+constexpr float kF16WScale = 256.0f;
+template <typename V8> struct OpTraits;
+template <> struct OpTraits<bf16x8> { typedef __bf16 elem; static constexpr bool f16 = false; static constexpr float wscale = 1.0f; };
+template <> struct OpTraits<f16x8> { typedef _Float16 elem; static constexpr bool f16 = true; static constexpr float wscale = kF16WScale; };
+__device__ __forceinline__ void f16_saturate_mode() {   // hwreg(HW_REG_MODE = 1, offset 23, size 1) = FP16_OVFL
+  __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);
+}
+template <typename V8>
+__device__ __forceinline__ V8 pack8(const float (&v)[8]) {
+  typedef float f32x8 __attribute__((ext_vector_type(8)));
+  const f32x8 f = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+  return __builtin_convertvector(f, V8);
+}
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+template <typename V8>
+__device__ __forceinline__ V8 ldbuf_v8(rsrc_t rs, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(V8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, __builtin_amdgcn_readfirstlane(soff), 0));
+}
+
 struct UnitH {  // one build unit in flight: 8 columns of one row of one MLP
   f16x8 p, q;
 };
@@ -210,16 +241,19 @@ __device__ __forceinline__ void unith_load(UnitH& u, rsrc_t tab, unsigned vdst, 
   u.p = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(tab, vdst, __builtin_amdgcn_readfirstlane(sP), 0));
   u.q = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(tab, vsrc, __builtin_amdgcn_readfirstlane(sQ), 0));
 }
-__device__ __forceinline__ bf16x8 unith_finish(const UnitH& u, const float* wd, float d2, char* slot) {
+// V8 = bf16x8 (precision bf16) or f16x8 (precision fp16): the MFMA operand type the activation is rounded to
+template <typename V8 = bf16x8>
+__device__ __forceinline__ V8 unith_finish(const UnitH& u, const float* wd, float d2, char* slot) {
   const f32x4 w0 = *reinterpret_cast<const f32x4*>(wd), w1 = *reinterpret_cast<const f32x4*>(wd + 4);
   const f16x8 t = u.p + u.q;
-  bf16x8 o;
+  typedef typename OpTraits<V8>::elem elem;
+  V8 o;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    o[j] = (__bf16)silu_s(fmaf(w0[j], d2, (float)t[j]));   // table, wd pre-scaled by -log2(e)
-    o[j + 4] = (__bf16)silu_s(fmaf(w1[j], d2, (float)t[j + 4]));
+    o[j] = (elem)silu_s(fmaf(w0[j], d2, (float)t[j]));   // table, wd pre-scaled by -log2(e)
+    o[j + 4] = (elem)silu_s(fmaf(w1[j], d2, (float)t[j + 4]));
   }
-  *reinterpret_cast<bf16x8*>(slot) = o;
+  *reinterpret_cast<V8*>(slot) = o;
   return o;
 }
 
@@ -267,12 +301,15 @@ struct PostParams {
   int per_graph;
   const f32x4 *w1h, *w2h;
   const void *w1h_bf16, *w2h_bf16p;   // bf16 node MLP (node_post_bf16_kernel)
+  const void *w1h_lo = nullptr, *w2h_lo = nullptr;   // split-operand form: remainder streams (heads in w1h_bf16 / w2h_bf16p)
   int K1Q;                            // H + MP rounded up to 16
   const float *b1h, *b2h;
   float *h_out, *x_out;
   float* h_partial;   // [8][N][H] scratch of the hidden-split form (small N), or null
 };
-int launch_node_post_bf16(const PostParams& q, hipStream_t st);
+int launch_node_post_bf16(const PostParams& q, hipStream_t st, bool f16 = false, bool split = false);
+bool node_post_split_supported(const PostParams& q);   // head + remainder fp16 operands, three MFMAs per product (node_bf16.hip)
+int node_post_split_k();
 bool node_post_bf16_supported(const PostParams& q);
 int init_node_bf16_attributes();
 
@@ -290,6 +327,8 @@ int init_edge_bf16_v4_attributes();
 int init_edge_bf16_v3_attributes();
 int launch_edge_x_m16(const EdgeParams& p, hipStream_t st);   // coordinate kernel on v_mfma_f32_16x16x32_bf16
 int launch_edge_x_m16_save(const EdgeParams& p, hipStream_t st);
+int launch_edge_x_m16_f16(const EdgeParams& p, hipStream_t st);   // precision fp16: v_mfma_f32_16x16x32_f16 (p.w2x16 = fp16 fragments)
+int launch_edge_f16_v4_m(const EdgeParams& p, hipStream_t st);    // precision fp16 message kernel (p.w2m = fp16 fragments)
 bool edge_x_m16_supported(const EdgeParams& p);
 int init_edge_x_m16_attributes();
 int launch_edge_bf16x3(const EdgeParams& p, hipStream_t st);    // precision 'bf16x3': head / remainder split operands

@@ -17,8 +17,10 @@ namespace {
 
 constexpr int kNodes = 32, kThreadsN = 256;
 constexpr int kMaxKS1 = 20;   // k-steps of the first product held in registers (H + MP <= 320)
-__host__ __device__ inline size_t nb_smem_bytes(int K1Q, int OB) {
-  const size_t xs = (size_t)(K1Q / 8) * 33 * 16;          // X^T image [k-group][33][8 bf16]
+constexpr int kSplitK = 320;  // K of the split-operand form: 20 k-steps = 2 turns of the 10-deep weight ring (H + MP in (160, 320])
+constexpr int kRingD = 10;
+__host__ __device__ inline size_t nb_smem_bytes(int K1Q, int OB, bool split = false) {
+  const size_t xs = (size_t)(K1Q / 8) * 33 * 16 * (split ? 2 : 1);   // X^T image [k-group][33][8 bf16] (split: head + remainder)
   const size_t red = (size_t)4 * OB * 16 * 64 * 4;         // cross-wave partial out^T
   return xs + red;
 }
@@ -27,33 +29,55 @@ __host__ __device__ inline size_t nb_smem_bytes(int K1Q, int OB) {
 // with a single H <= 256 instantiation the kernel took 464 registers per lane = ONE workgroup per CU, and a layer's 512
 // workgroups ran as two serial rounds of a latency-bound chain (88-98 us); at OBT = 2 (H <= 64, 224 VGPRs) two workgroups
 // share a CU: 49 us.
-template <int OBT>
+// V8 = the MFMA operand type: bf16x8, or f16x8 for precision fp16 (p.w1h_bf16 / p.w2h_bf16p then point at the fp16 fragment
+// streams, packed x 2^8: both accumulators are divided by it where the biases are added).
+// SPLIT = true (fp32-grade node MLP on the half-precision matrix cores; used by precision fp16 and bf16x3): every operand of
+// both products is a head + remainder pair (X = X_hi + X_lo, W = W_hi + W_lo, hidden = h_hi + h_lo; with fp16 pairs 22
+// significant bits) and each product is three MFMAs, small terms first: lo x hi + hi x lo + hi x hi.  The node MLP is the
+// largest single rounding-error source of the fp16 path (tools/rounding_budget.py: 4.5e-4 of 5.3e-4 on h', 6.2e-4 of 8.3e-4
+// on eps_x) and costs 0.4 % of a layer's FLOP.  W1h head / remainder fragments stream through a ring of kRingD k-steps
+// (requested kRingD k-steps ahead, across hidden-block boundaries) instead of living in registers for a whole block;
+// K is padded to kSplitK = 2 ring turns so that the ring slot of a k-step is a compile-time constant.
+template <int OBT, typename V8 = bf16x8, bool SPLIT = false>
 __global__ __launch_bounds__(kThreadsN, (OBT > 2 ? 1 : 2)) void node_post_bf16_kernel(const PostParams p) {
+  typedef typename OpTraits<V8>::elem elem;
+  constexpr float kInvW = 1.0f / OpTraits<V8>::wscale;
+  if constexpr (OpTraits<V8>::f16) f16_saturate_mode();
   constexpr bool PF = true;   // the W1h fragments of the next hidden block are requested while this one is multiplied
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Xb = smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
   const int n0 = blockIdx.x * kNodes;
-  const int KS1 = p.K1Q / 16, OB = p.HP / 32;
-  float* red = reinterpret_cast<float*>(smem + (size_t)(p.K1Q / 8) * 33 * 16);
+  const int K1Q = SPLIT ? kSplitK : p.K1Q;
+  const int KS1 = K1Q / 16, OB = p.HP / 32;
+  char* Xl = Xb + (size_t)(K1Q / 8) * 33 * 16;   // SPLIT: remainder image
+  float* red = reinterpret_cast<float*>(smem + (size_t)(K1Q / 8) * 33 * 16 * (SPLIT ? 2 : 1));
 
-  const bf16x8* w1 = reinterpret_cast<const bf16x8*>(p.w1h_bf16);    // [WhP/32][KS1][64]
-  const bf16x8* w2 = reinterpret_cast<const bf16x8*>(p.w2h_bf16p);   // [OB][WhP/16][64], k permuted
+  const V8* w1 = reinterpret_cast<const V8*>(p.w1h_bf16);    // [WhP/32][KS1][64]
+  const V8* w2 = reinterpret_cast<const V8*>(p.w2h_bf16p);   // [OB][WhP/16][64], k permuted
   const int KS2 = p.WhP / 16;
   // hidden units: split over the gridDim.y workgroups of a node tile (1 = all here), then over the 4 waves
   const int hsplit = gridDim.y, hsi = blockIdx.y;
   const int nhb = p.WhP / 32, hb_per_wave = nhb / (4 * hsplit), hb0 = hsi * (nhb / hsplit);
   // the first hidden block's W1h fragments depend on nothing: requested before the gather so that their L2 / HBM round
   // trip runs under it (at B = 1 a layer's node_post is a chain of such round trips and little else)
-  bf16x8 wf[kMaxKS1];
-  {
-    const bf16x8* w1b = w1 + ((size_t)(hb0 + wave * hb_per_wave) * KS1) * 64 + lane;
+  const V8* w1l = reinterpret_cast<const V8*>(p.w1h_lo);    // SPLIT: remainders, same layouts
+  const V8* w2l = reinterpret_cast<const V8*>(p.w2h_lo);
+  V8 wf[SPLIT ? 1 : kMaxKS1];
+  V8 rh[SPLIT ? kRingD : 1], rl[SPLIT ? kRingD : 1];   // SPLIT: ring of W1h head / remainder fragments
+  if constexpr (SPLIT) {
+    const size_t o = ((size_t)(hb0 + wave * hb_per_wave) * (kSplitK / 16)) * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < kRingD; ++s) { rh[s] = w1[o + (size_t)s * 64]; rl[s] = w1l[o + (size_t)s * 64]; }
+  } else {
+    const V8* w1b = w1 + ((size_t)(hb0 + wave * hb_per_wave) * KS1) * 64 + lane;
 #pragma unroll
     for (int s = 0; s < kMaxKS1; ++s) wf[s] = w1b[(size_t)(s < KS1 ? s : 0) * 64];
   }
   // the same for the first hidden block's biases and its W2h fragments (two more round trips of the B = 1 chain)
   float b1v[16];
-  bf16x8 w2f[OBT][2];
+  V8 w2f[OBT][2];
+  V8 w2g[SPLIT ? OBT : 1][2];   // SPLIT: remainders of the W2h fragments
   {
     const int hbf = hb0 + wave * hb_per_wave;
 #pragma unroll
@@ -61,7 +85,10 @@ __global__ __launch_bounds__(kThreadsN, (OBT > 2 ? 1 : 2)) void node_post_bf16_k
 #pragma unroll
     for (int ob = 0; ob < OBT; ++ob)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) w2f[ob][s] = w2[((size_t)(ob < OB ? ob : 0) * KS2 + 2 * hbf + s) * 64 + lane];
+      for (int s = 0; s < 2; ++s) {
+        w2f[ob][s] = w2[((size_t)(ob < OB ? ob : 0) * KS2 + 2 * hbf + s) * 64 + lane];
+        if constexpr (SPLIT) w2g[ob][s] = w2l[((size_t)(ob < OB ? ob : 0) * KS2 + 2 * hbf + s) * 64 + lane];
+      }
   }
 
   // gather [h | sum_m] (tile partials added in tile order), pack to bf16 in the fragment image.  The CSR lookups of the
@@ -80,8 +107,8 @@ __global__ __launch_bounds__(kThreadsN, (OBT > 2 ? 1 : 2)) void node_post_bf16_k
   }
   __syncthreads();
 #pragma unroll 4
-  for (int i = tid; i < kNodes * (p.K1Q / 2); i += kThreadsN) {
-    const int node = i / (p.K1Q / 2), kp = i % (p.K1Q / 2), n = n0 + node;
+  for (int i = tid; i < kNodes * (K1Q / 2); i += kThreadsN) {
+    const int node = i / (K1Q / 2), kp = i % (K1Q / 2), n = n0 + node;
     float v[2] = {0.f, 0.f};
     if (n < p.N) {
       const int t0 = s_t0[node], t1 = s_t1[node];
@@ -101,15 +128,21 @@ __global__ __launch_bounds__(kThreadsN, (OBT > 2 ? 1 : 2)) void node_post_bf16_k
       }
     }
     const int k = 2 * kp;
-    __bf16* dst = reinterpret_cast<__bf16*>(Xb + ((size_t)(k >> 3) * 33 + node) * 16) + (k & 7);
-    dst[0] = (__bf16)v[0];
-    dst[1] = (__bf16)v[1];
+    elem* dst = reinterpret_cast<elem*>(Xb + ((size_t)(k >> 3) * 33 + node) * 16) + (k & 7);
+    const elem e0 = (elem)v[0], e1 = (elem)v[1];
+    dst[0] = e0;
+    dst[1] = e1;
+    if constexpr (SPLIT) {
+      elem* dl = reinterpret_cast<elem*>(Xl + ((size_t)(k >> 3) * 33 + node) * 16) + (k & 7);
+      dl[0] = (elem)(v[0] - (float)e0);
+      dl[1] = (elem)(v[1] - (float)e1);
+    }
   }
   // normaliser G^2 = sum of d^2 over the edges of the node's graph (:64), from component 3 of the coordinate sums.
   // Small graphs (<= 64 nodes): 8 lanes per node.  Larger graphs: the whole workgroup sums each distinct graph of its
   // 32 nodes (a latency-bound loop of dependent loads otherwise).  Either way every workgroup that needs a graph's
   // sum adds the same values in the same order: the result is bitwise the same everywhere.
-  float* gsq = reinterpret_cast<float*>(smem + nb_smem_bytes(p.K1Q, p.HP / 32));   // [kNodes] then [kThreadsN] scratch
+  float* gsq = reinterpret_cast<float*>(smem + nb_smem_bytes(K1Q, p.HP / 32, SPLIT));   // [kNodes] then [kThreadsN] scratch
   if (p.sq_from_agg && blockIdx.y == 0) {
     float* red = gsq + kNodes;
     const int node = tid >> 3, n = n0 + node;
@@ -172,30 +205,56 @@ __global__ __launch_bounds__(kThreadsN, (OBT > 2 ? 1 : 2)) void node_post_bf16_k
   // The W1h fragments of a hidden block (KS1 <= kMaxKS1 k-steps, 1 KiB each) are all requested before the
   // block's MFMA chain, and the next block's while this one is multiplied: one exposed L2 round trip per
   // wave instead of one per k-step.
-  bf16x8 wn[kMaxKS1];
+  V8 wn[SPLIT ? 1 : kMaxKS1];
+  const char* xfrag_lo = Xl + ((size_t)hh * 33 + r) * 16;
   for (int q = 0; q < hb_per_wave; ++q) {
     const int hb = hb0 + wave * hb_per_wave + q;
-    if constexpr (PF) {
+    if constexpr (SPLIT) {
+    } else if constexpr (PF) {
       const int hbn = q + 1 < hb_per_wave ? hb + 1 : hb;
-      const bf16x8* w1b = w1 + ((size_t)hbn * KS1) * 64 + lane;
+      const V8* w1b = w1 + ((size_t)hbn * KS1) * 64 + lane;
 #pragma unroll
       for (int s = 0; s < kMaxKS1; ++s) wn[s] = w1b[(size_t)(s < KS1 ? s : 0) * 64];
     } else if (q > 0) {
-      const bf16x8* w1b = w1 + ((size_t)hb * KS1) * 64 + lane;
+      const V8* w1b = w1 + ((size_t)hb * KS1) * 64 + lane;
 #pragma unroll
       for (int s = 0; s < kMaxKS1; ++s) wf[s] = w1b[(size_t)(s < KS1 ? s : 0) * 64];
     }
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    if constexpr (SPLIT) {
+      const int hbn = q + 1 < hb_per_wave ? hb + 1 : hb;   // (past the last block: a harmless repeat)
+      const size_t oc = ((size_t)hb * (kSplitK / 16)) * 64 + lane, on = ((size_t)hbn * (kSplitK / 16)) * 64 + lane;
+      static_assert((kSplitK / 16) % kRingD == 0, "the ring slot of a k-step must be a compile-time constant");
+#pragma unroll 1
+      for (int turn = 0; turn < kSplitK / 16 / kRingD; ++turn) {   // (not unrolled: bounds the LDS operands hipcc hoists)
+        const bool last_turn = turn == kSplitK / 16 / kRingD - 1;
+        // the k-step a freed slot is refilled with: kRingD ahead in this block, or the next block's first turn
+        const size_t ofill = last_turn ? on : oc + (size_t)(turn + 1) * kRingD * 64;
+#pragma unroll
+        for (int u = 0; u < kRingD; ++u) {
+          const int s = turn * kRingD + u;
+          const V8 bh = *reinterpret_cast<const V8*>(xfrag + (size_t)s * 2 * 33 * 16);
+          const V8 bl = *reinterpret_cast<const V8*>(xfrag_lo + (size_t)s * 2 * 33 * 16);
+          acc = mfma32(rl[u], bh, acc);
+          acc = mfma32(rh[u], bl, acc);
+          acc = mfma32(rh[u], bh, acc);
+          rh[u] = w1[ofill + (size_t)u * 64];
+          rl[u] = w1l[ofill + (size_t)u * 64];
+        }
+      }
+    } else {
 #pragma unroll
     for (int s = 0; s < kMaxKS1; ++s)
       if (s < KS1) {
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(xfrag + (size_t)s * 2 * 33 * 16);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s], b, acc, 0, 0, 0);
+        const V8 b = *reinterpret_cast<const V8*>(xfrag + (size_t)s * 2 * 33 * 16);
+        acc = mfma32(wf[s], b, acc);
       }
+    }
     // bias + SiLU on the accumulator; registers 8s..8s+7 are the B fragment of k-step s of the second product
-    bf16x8 hf[2];
+    V8 hf[2];
+    V8 hg[SPLIT ? 2 : 1];   // SPLIT: remainders of the hidden activation
     if (q > 0) {   // (block 0: requested at the top)
 #pragma unroll
       for (int i = 0; i < 16; ++i) b1v[i] = p.b1h[32 * hb + acc_row(i, lane)];
@@ -203,18 +262,32 @@ __global__ __launch_bounds__(kThreadsN, (OBT > 2 ? 1 : 2)) void node_post_bf16_k
       for (int ob = 0; ob < OBT; ++ob)
         if (ob < OB) {
 #pragma unroll
-          for (int s = 0; s < 2; ++s) w2f[ob][s] = w2[((size_t)ob * KS2 + 2 * hb + s) * 64 + lane];
+          for (int s = 0; s < 2; ++s) {
+            w2f[ob][s] = w2[((size_t)ob * KS2 + 2 * hb + s) * 64 + lane];
+            if constexpr (SPLIT) w2g[ob][s] = w2l[((size_t)ob * KS2 + 2 * hb + s) * 64 + lane];
+          }
         }
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) hf[i >> 3][i & 7] = (__bf16)silu_f(acc[i] + b1v[i]);
+    for (int i = 0; i < 16; ++i) {
+      const float hv = silu_f(OpTraits<V8>::f16 ? fmaf(acc[i], kInvW, b1v[i]) : acc[i] + b1v[i]);
+      const elem he = (elem)hv;
+      hf[i >> 3][i & 7] = he;
+      if constexpr (SPLIT) hg[i >> 3][i & 7] = (elem)(hv - (float)he);
+    }
 #pragma unroll
     for (int ob = 0; ob < OBT; ++ob)
       if (ob < OB) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) oacc[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[ob][s], hf[s], oacc[ob], 0, 0, 0);
+        for (int s = 0; s < 2; ++s) {
+          if constexpr (SPLIT) {
+            oacc[ob] = mfma32(w2g[ob][s], hf[s], oacc[ob]);
+            oacc[ob] = mfma32(w2f[ob][s], hg[s], oacc[ob]);
+          }
+          oacc[ob] = mfma32(w2f[ob][s], hf[s], oacc[ob]);
+        }
       }
-    if constexpr (PF) {
+    if constexpr (PF && !SPLIT) {
 #pragma unroll
       for (int s = 0; s < kMaxKS1; ++s) wf[s] = wn[s];
     }
@@ -232,6 +305,7 @@ __global__ __launch_bounds__(kThreadsN, (OBT > 2 ? 1 : 2)) void node_post_bf16_k
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) v += red[((size_t)(w * OB + ob) * 16 + i) * 64 + l];
+    if constexpr (OpTraits<V8>::f16) v *= kInvW;
     const int o = 32 * ob + acc_row(i, l), n = n0 + (l & 31);
     if (n < p.N && o < p.H) {
       if (hsplit == 1) p.h_out[(size_t)n * p.H + o] = v + p.b2h[o];
@@ -254,7 +328,10 @@ __global__ void node_post_finish_kernel(int N, int H, int hsplit, const float* _
 
 int init_node_bf16_attributes() {
   const void* fns[] = {reinterpret_cast<const void*>(&node_post_bf16_kernel<2>),
-                       reinterpret_cast<const void*>(&node_post_bf16_kernel<kPostMaxOB>)};
+                       reinterpret_cast<const void*>(&node_post_bf16_kernel<kPostMaxOB>),
+                       reinterpret_cast<const void*>(&node_post_bf16_kernel<2, f16x8>),
+                       reinterpret_cast<const void*>(&node_post_bf16_kernel<kPostMaxOB, f16x8>),
+                       reinterpret_cast<const void*>(&node_post_bf16_kernel<2, f16x8, true>)};
   for (const void* f : fns) EGNN_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   return EGNN_OK;
 }
@@ -264,7 +341,15 @@ bool node_post_bf16_supported(const PostParams& q) {
          nb_smem_bytes(q.K1Q, q.HP / 32) + (kNodes + kThreadsN) * 4 <= 160 * 1024;
 }
 
-int launch_node_post_bf16(const PostParams& q, hipStream_t st) {
+// split-operand form: H <= 64 (two output blocks), 160 < H + MP <= 320, head + remainder fp16 streams packed for K = kSplitK
+bool node_post_split_supported(const PostParams& q) {
+  return q.w1h_lo && q.w2h_lo && q.w1h_bf16 && q.w2h_bf16p && q.HP <= 64 && q.H + q.MP > kSplitK / 2 && q.H + q.MP <= kSplitK &&
+         q.WhP % 128 == 0 && nb_smem_bytes(kSplitK, q.HP / 32, true) + (kNodes + kThreadsN) * 4 <= 80 * 1024;
+}
+int node_post_split_k() { return kSplitK; }
+
+// f16: q.w1h_bf16 / q.w2h_bf16p are the fp16 fragment streams (precision fp16); split: + q.w1h_lo / q.w2h_lo (K = kSplitK)
+int launch_node_post_bf16(const PostParams& q, hipStream_t st, bool f16, bool split) {
   const int tiles = (q.N + kNodes - 1) / kNodes;
   // Few node tiles (small graphs): a layer would wait for ONE workgroup's serial chain over all hidden blocks (40 us).
   // Split the hidden units over `hs` workgroups per tile (partial h' to scratch) and add them up in a second tiny launch:
@@ -272,8 +357,13 @@ int launch_node_post_bf16(const PostParams& q, hipStream_t st) {
   int hs = 1;
   if (q.h_partial && tiles * 8 <= 256 && (q.WhP / 32) % 32 == 0) hs = 8;
   const dim3 grid(tiles, hs);
-  const size_t sm = nb_smem_bytes(q.K1Q, q.HP / 32) + (kNodes + kThreadsN) * 4;
-  if (q.HP <= 64) hipLaunchKernelGGL(node_post_bf16_kernel<2>, grid, dim3(kThreadsN), sm, st, q);
+  const size_t sm = nb_smem_bytes(split ? kSplitK : q.K1Q, q.HP / 32, split) + (kNodes + kThreadsN) * 4;
+  if (split) {
+    hipLaunchKernelGGL((node_post_bf16_kernel<2, f16x8, true>), grid, dim3(kThreadsN), sm, st, q);
+  } else if (f16) {
+    if (q.HP <= 64) hipLaunchKernelGGL((node_post_bf16_kernel<2, f16x8>), grid, dim3(kThreadsN), sm, st, q);
+    else hipLaunchKernelGGL((node_post_bf16_kernel<kPostMaxOB, f16x8>), grid, dim3(kThreadsN), sm, st, q);
+  } else if (q.HP <= 64) hipLaunchKernelGGL(node_post_bf16_kernel<2>, grid, dim3(kThreadsN), sm, st, q);
   else hipLaunchKernelGGL(node_post_bf16_kernel<kPostMaxOB>, grid, dim3(kThreadsN), sm, st, q);
   if (hs > 1)
     hipLaunchKernelGGL(node_post_finish_kernel, dim3((q.N * q.H + 255) / 256), dim3(256), 0, st, q.N, q.H, hs, q.h_partial,

@@ -1,0 +1,116 @@
+"""Rounding-error budget of the half-precision paths, EMULATED on the CPU (no GPU needed): the oracle's layer arithmetic
+(oracle/egnn_ref.py, EquivariantGraphNeuralNetwork.py:55-71) with a rounding to the operand format injected at each place
+the HIP kernels round -- first-layer table entries P, Q (fp16), their fp16 sum, the hidden activation (MFMA A operand),
+the second-layer weights (B operand), the node MLP's input / weights / hidden activation -- one at a time and in the
+combinations that correspond to a kernel design.  Error = relative L2 of (eps_x, h') against the unrounded fp32 chain on the
+full-width golden graphs.  Validates itself against the GPU measurements of profiles/r04a_prec_errors.log (bf16 / fp16 rows).
+
+What it answers: which roundings set the floor of precision 'fp16', whether the two-product form
+(fp16 activation x (W_hi + W_lo): weights exact) reaches north_star's 1e-4, and what a split-operand node MLP buys.
+
+usage: python tools/rounding_budget.py [--case full_g64] > profiles/r04_rounding_budget.txt
+test infrastructure (imports tests/ helpers); never imported by the product."""
+import argparse
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tests._util import golden_case, load_golden, rel_err  # noqa: E402
+
+
+def rnd(t, fmt):
+    if fmt is None:
+        return t
+    if fmt == "bf16":
+        return t.to(torch.bfloat16).float()
+    if fmt == "fp16":
+        return t.to(torch.float16).float()
+    if fmt == "bf16x2":      # head + remainder, both bf16: 16 bits
+        hi = t.to(torch.bfloat16).float()
+        return hi + (t - hi).to(torch.bfloat16).float()
+    if fmt == "fp16x2":      # head + remainder, both fp16: 22 bits
+        hi = t.to(torch.float16).float()
+        return hi + (t - hi).to(torch.float16).float()
+    raise ValueError(fmt)
+
+
+def layer(sd, l, ei, h, x, r):
+    """one EGCL layer; r = dict of formats: tab (P, Q entries), tabsum (P + Q), act (hidden activation of both edge MLPs),
+    w2 (mlp_x.2 / mlp_m.2 weights), nin (node MLP input [h | sum_m]), nw (mlp_h weights), nact (node hidden activation)"""
+    p = f"egcl_list.{l}."
+    W = lambda n: sd[p + n + ".weight"]
+    B = lambda n: sd[p + n + ".bias"]
+    H = h.shape[1]
+    row, col = ei[0], ei[1]
+    diff = x[row] - x[col]
+    d2 = (diff * diff).sum(1, keepdim=True)
+
+    def edge_mlp(name, nlin):
+        w1, b1 = W(f"{name}.0"), B(f"{name}.0")
+        P = rnd(F.linear(h, w1[:, :H], b1), r.get("tab"))          # per-node table halves (node_pre)
+        Q = rnd(F.linear(h, w1[:, H:2 * H]), r.get("tab"))
+        t = rnd(P[row] + Q[col], r.get("tabsum")) + d2 * w1[:, 2 * H]
+        a1 = rnd(F.silu(t), r.get("act"))
+        return F.silu(F.linear(a1, rnd(W(f"{name}.2"), r.get("w2")), B(f"{name}.2")))
+
+    m = edge_mlp("mlp_m", 2)
+    m = m * torch.sigmoid(F.linear(m, W("attention.0"), B("attention.0")))
+    agg_m = torch.zeros(h.shape[0], m.shape[1]).index_add_(0, row, m)
+    hcat = rnd(torch.cat((h, agg_m), 1), r.get("nin"))
+    hid = rnd(F.silu(F.linear(hcat, rnd(W("mlp_h.0"), r.get("nw")), B("mlp_h.0"))), r.get("nact"))
+    h_new = F.linear(hid, rnd(W("mlp_h.2"), r.get("nw")), B("mlp_h.2"))
+    s = F.linear(edge_mlp("mlp_x", 2), W("mlp_x.4"), B("mlp_x.4"))
+    G = torch.sqrt((diff * diff).sum())
+    return h_new, x + torch.zeros_like(x).index_add_(0, row, diff * s / (G + 1))
+
+
+def run(sd, L, ei, h, x, r):
+    for l in range(L):
+        h, x = layer(sd, l, ei, h, x, r)
+    return h, x
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--case", default="full_g64")
+    a = ap.parse_args()
+    torch.set_num_threads(8)
+    G = load_golden("egnn_golden.npz")
+    sd, h, x, sizes, layers, d = golden_case(G, a.case)
+    assert len(sizes) == 1, "single-graph cases only (call scope == graph scope)"
+    n = sizes[0]
+    ei = torch.tensor([[i, j] for i in range(n) for j in range(n) if i != j]).t().contiguous()
+    L = len(layers)
+    h0, x0 = run(sd, L, ei, h, x, {})
+    print(f"# tools/rounding_budget.py  case {a.case}: emulation vs the reference golden (sanity): "
+          f"h {rel_err(h0, layers[-1][0]):.1e} eps_x {rel_err(x0 - x, layers[-1][1] - x):.1e}")
+    T = {"tab": "fp16", "tabsum": "fp16"}   # the half-precision table both paths share
+    rows = [
+        ("precision bf16 as built (fp16 table, bf16 act / w2 / node MLP)", dict(T, act="bf16", w2="bf16", nin="bf16", nw="bf16", nact="bf16")),
+        ("bf16 edges + split-operand node MLP (bf16x2 input / weights / hidden)", dict(T, act="bf16", w2="bf16", nin="bf16x2", nw="bf16x2", nact="bf16x2")),
+        ("  only the bf16 node MLP", dict(nin="bf16", nw="bf16", nact="bf16")),
+        ("precision fp16 as built (fp16 everywhere)", dict(T, act="fp16", w2="fp16", nin="fp16", nw="fp16", nact="fp16")),
+        ("fp16 edges, exact node MLP (EGNN_F16_NODE=0)", dict(T, act="fp16", w2="fp16")),
+        ("  only the fp16 table entries P, Q", dict(tab="fp16")),
+        ("  only the fp16 sum P + Q", dict(tabsum="fp16")),
+        ("  only the fp16 hidden activation", dict(act="fp16")),
+        ("  only the fp16 second-layer weights", dict(w2="fp16")),
+        ("  only the fp16 node MLP (input, weights, hidden)", dict(nin="fp16", nw="fp16", nact="fp16")),
+        ("two-product form: fp16 activation x (W_hi + W_lo), fp16 table, exact node MLP", dict(T, act="fp16", w2="fp16x2")),
+        ("two-product form with an exact (fp32) table", dict(act="fp16", w2="fp16x2")),
+        ("fp16 edges as built + split-operand node MLP (fp16x2 input / weights / hidden)", dict(T, act="fp16", w2="fp16", nin="fp16x2", nw="fp16x2", nact="fp16x2")),
+        ("fp16x2 everywhere except the fp16 table (three-product edges + split node MLP)", dict(T, act="fp16x2", w2="fp16x2", nin="fp16x2", nw="fp16x2", nact="fp16x2")),
+        ("fp16x2 everywhere, fp32 table (= the bf16x3 design point on fp16 operands)", dict(act="fp16x2", w2="fp16x2", nin="fp16x2", nw="fp16x2", nact="fp16x2")),
+    ]
+    print(f"{'rounding set':92s} {'h_out':>9s} {'eps_x':>9s}")
+    for name, r in rows:
+        hh, xx = run(sd, L, ei, h, x, r)
+        print(f"{name:92s} {rel_err(hh, h0):9.2e} {rel_err(xx - x, x0 - x):9.2e}")
+
+
+if __name__ == "__main__":
+    main()
