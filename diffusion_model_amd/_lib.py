@@ -12,6 +12,24 @@ PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "float32": PREC_F32, "bf16": PR
               "bf16x3": PREC_BF16X3, "fp16": PREC_F16, "f16": PREC_F16, "float16": PREC_F16}
 NORM_SCOPES = {"call": NORM_CALL, "graph": NORM_GRAPH}
 
+
+
+def edge_kernel_sources_sha256() -> str:
+    """Fingerprint of the sources the dominant (edge) kernels are compiled from, plus the compiler flags: what a PMC
+    measurement of those kernels (profiles/traffic.json) is valid for.  A hash of the .so itself would not survive a rebuild
+    in another directory (hipcc derives its per-TU symbol ids from the path)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(_HERE, "csrc")
+    for name in ("edge_x_m16.hip", "edge_bf16_v4.hip", "edge_tile.h", "kernels.h", "common.h"):
+        with open(os.path.join(csrc, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    with open(os.path.join(os.path.dirname(_HERE), "Makefile"), "rb") as f:
+        flags = [l for l in f.read().splitlines() if l.startswith(b"FLAGS")]
+    h.update(b"\n".join(flags))
+    return h.hexdigest()
+
+
 _vp, _i, _f, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_uint64
 _fp = C.POINTER(C.c_float)
 

@@ -271,7 +271,8 @@ class _EGNNFunction(torch.autograd.Function):
             if cache is None or cache[0] != key:
                 free = torch.cuda.mem_get_info(hc.device)[0] + (torch.cuda.memory_reserved(hc.device) -
                                                                 torch.cuda.memory_allocated(hc.device))
-                cache = (key, need < 0.5 * free)
+                # (the keeping forward stores its activation chunks through a 32-bit buffer descriptor: E x Wx x 2 B < 4 GiB)
+                cache = (key, need < 0.5 * free and E * Wx * 2 < 2 ** 32)
                 c._keep_decision = cache
             if cache[1]:
                 kept = []

@@ -58,6 +58,12 @@ __global__ __launch_bounds__(256) void dense_rows_kernel(int N, int K, int J, co
 }  // namespace
 
 int launch_dense_rows(int N, int K, int J, const float* in, const float* W, const float* b, int relu, float* out, hipStream_t st) {
+  // kMlpRows x K fp32 of dynamic LDS: 128 KiB at the documented limit K = 2048, above the 64 KiB a kernel gets by default
+  static bool attr_done = false;
+  if (!attr_done) {
+    EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
   hipLaunchKernelGGL(dense_rows_kernel, dim3((N + kMlpRows - 1) / kMlpRows), dim3(256), (size_t)kMlpRows * K * sizeof(float), st, N, K,
                      J, in, W, b, relu, out);
   EGNN_HIP(hipGetLastError());
@@ -82,7 +88,10 @@ int egnn_gamma_tilde(void* stream, int n, int hidden, const float* d_t, const fl
 }
 
 int egnn_dense_rows(void* stream, int N, int K, int J, const float* d_in, const float* d_W, const float* d_b, int relu, float* d_out) {
-  if (N < 1 || K < 1 || J < 1 || K > 2048 || !d_in || !d_W || !d_b || !d_out) { set_error("bad egnn_dense_rows arguments (K <= 2048)"); return EGNN_EINVAL; }
+  {
+    const int rc = dense_rows_args_check(N, K, J, d_in, d_W, d_b, d_out);   // host_logic.cpp
+    if (rc) return rc;
+  }
   return launch_dense_rows(N, K, J, d_in, d_W, d_b, relu, d_out, reinterpret_cast<hipStream_t>(stream));
 }
 

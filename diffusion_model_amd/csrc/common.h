@@ -7,14 +7,12 @@
 #include <vector>
 
 #include "../../include/egnn_amd.h"
+#include "host_logic.h"   // set_error, padded model dimensions, argument checks, GEMM plan: the HIP-free part of the host side
 
 namespace egnn {
 
 constexpr int kThreads = 256;   // 4 wave64 per workgroup, one per SIMD
 constexpr int kWaves = 4;
-constexpr int kMaxCB = 8;       // 32-column blocks per wave in the fused edge GEMMs (N <= 1024)
-
-void set_error(const char* fmt, ...);
 
 #define EGNN_HIP(call)                                                                      \
   do {                                                                                      \
@@ -24,8 +22,6 @@ void set_error(const char* fmt, ...);
       return EGNN_EHIP;                                                                     \
     }                                                                                       \
   } while (0)
-
-inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // Packed parameters of one EGCL layer (all device memory, owned by the context).
 struct LayerPack {

@@ -18,6 +18,7 @@
 // the double-buffered LDS activation chunk, CB B fragments straight from the packed weights, 4*CB MFMAs.
 #include <type_traits>
 
+#include "diag.h"
 #include "edge_tile.h"
 
 namespace egnn {
@@ -61,38 +62,8 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
   const int e0 = tile * kR3;
   const int nvalid = min(kR3, p.E - e0);
 
-#ifdef EGNN_EXP_STAMP
-  const bool stamp_wg = blockIdx.x == gridDim.x / 2;
-  unsigned long long* st_base = p.stamps + ((size_t)(IS_M ? 1 : 0) * 8 + wave) * 32 * 4;
-#define STAMP(c, k)                                                                               \
-  do {                                                                                            \
-    unsigned long long t_;                                                                        \
-    __builtin_amdgcn_sched_barrier(0);                                                            \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
-    __builtin_amdgcn_sched_barrier(0);                                                            \
-    if (stamp_wg && lane == 0 && (c) < 32) st_base[(c) * 4 + (k)] = t_;                           \
-  } while (0)
-// 100 MHz wall counter next to a cycle stamp: in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz
-#define RSTAMP(c, k)                                                                              \
-  do {                                                                                            \
-    unsigned long long t_;                                                                        \
-    __builtin_amdgcn_sched_barrier(0);                                                            \
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
-    __builtin_amdgcn_sched_barrier(0);                                                            \
-    if (stamp_wg && lane == 0 && (c) < 32) st_base[(c) * 4 + (k)] = t_;                           \
-  } while (0)
-#else
-#define STAMP(c, k)
-#define RSTAMP(c, k)
-#endif
-#ifdef EGNN_EXP_STAMP2   // finer stamps inside the first half of a chunk (replaces the meaning of slots 1..3)
-#define STAMP2(c, k, cond) do { if (cond) STAMP(c, k); } while (0)
-#define STAMP1(c, k)
-#else
-#define STAMP2(c, k, cond)
-#define STAMP1(c, k) STAMP(c, k)
-#endif
-  STAMP(30, 0);   // kernel entry
+  DIAG_STAMP_SETUP(p.stamps + ((size_t)(IS_M ? 1 : 0) * 8 + wave) * 32 * 4);
+  DIAG_STAMP(30, 0);   // kernel entry
   const int S = prologue(p, L, e0, nvalid, IS_M ? p.wdm : p.wdx, KP, s_wd, tid, lane, wave);
   if constexpr (BWD && !IS_M) {   // dL/ds_e = dL/d(sum_x[i]) . (x_i - x_j)   (:64, xm = (x_i - x_j) * s); read behind the K loop's barriers
     if (tid < kR3) {
@@ -102,13 +73,13 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
     }
   }
 
-  STAMP(30, 1);   // tile structure ready
+  DIAG_STAMP(30, 1);   // tile structure ready
 
   // ---- K-loop ----
   const int NC = KP / kKC3, KS = KP / 16;
   const int brow = tid >> 3, kg = tid & 7;   // this thread builds rows brow and brow + 64
-  const rsrc_t rs_tab = make_rsrc(p.table, (p.dbg & 2) ? 0u : (unsigned)((size_t)p.N * p.TC * 2));
-  const rsrc_t rs_w = make_rsrc(IS_M ? p.w2m : p.w2x, (p.dbg & 1) ? 0u : (unsigned)((size_t)(IS_M ? p.MP : p.WxP) * KP * 2));
+  const rsrc_t rs_tab = make_rsrc(p.table, diag::drop_table_loads(p.dbg) ? 0u : (unsigned)((size_t)p.N * p.TC * 2));
+  const rsrc_t rs_w = make_rsrc(IS_M ? p.w2m : p.w2x, diag::drop_weight_loads(p.dbg) ? 0u : (unsigned)((size_t)(IS_M ? p.MP : p.WxP) * KP * 2));
   const unsigned vdst0 = (unsigned)s_dst[brow] * (unsigned)p.TC * 2u + (unsigned)kg * 16u;
   const unsigned vsrc0 = (unsigned)s_src[brow] * (unsigned)p.TC * 2u + (unsigned)kg * 16u;
   const unsigned vdst1 = (unsigned)s_dst[brow + 64] * (unsigned)p.TC * 2u + (unsigned)kg * 16u;
@@ -159,7 +130,6 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
   // after the MFMAs of k-step s of chunk c were issued (a whole chunk = 4 k-steps of distance, enough to cover
   // an L2 round trip under load), the LDS A fragments one k-step ahead.
   auto mphase = [&](const int c, const bool last) {
-#ifndef EGNN_EXP_NO_MFMA
     // A fragments by inline-asm ds_read_b128 so that hipcc cannot sink them to their use: a[rb] is refilled in
     // place for k-step s+1 right after the MFMAs of (s, rb) were issued and flies under the next 3 row blocks'
     // MFMAs.  LDS operations of a wave return in order, so lgkmcnt(3) before a use means "all but the 3
@@ -187,45 +157,15 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
         if (s == 1) { if (rb == 0) LDS_RD(a[0], 8256); if (rb == 1) LDS_RD(a[1], 8256 + 512); if (rb == 2) LDS_RD(a[2], 8256 + 1024); if (rb == 3) LDS_RD(a[3], 8256 + 1536); }
         if (s == 2) { if (rb == 0) LDS_RD(a[0], 12384); if (rb == 1) LDS_RD(a[1], 12384 + 512); if (rb == 2) LDS_RD(a[2], 12384 + 1024); if (rb == 3) LDS_RD(a[3], 12384 + 1536); }
       }
-#ifndef EGNN_EXP_W_ONCE   // timing experiment: keep the first chunk's weight fragments (real data, no weight stream)
       if (!last) {
         const unsigned ksn = (unsigned)((c + 1) * 4 + s) * 1024u;
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) bq[s][cb] = ldbuf_bf16x8(rs_w, lane16, w0 + (unsigned)cb * KS * 1024u + ksn);
       }
-#endif
-      if (s == 0) STAMP2(c, 2, wave < 4);
+      if (s == 0) DIAG_STAMP2(c, 2, wave < 4);
     }
 #undef LDS_WAIT
 #undef LDS_RD
-#else   // timing experiment without MFMAs: compiler-visible LDS reads
-    const char* cur = s_a1 + (size_t)(c & 1) * kA1_3 + ((size_t)hh * kRPAD3 + r) * 16;
-    bf16x8 a[kRB3], an[kRB3];
-#pragma unroll
-    for (int rb = 0; rb < kRB3; ++rb) a[rb] = *reinterpret_cast<const bf16x8*>(cur + (size_t)(32 * rb) * 16);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      if (s < 3) {
-#pragma unroll
-        for (int rb = 0; rb < kRB3; ++rb)
-          an[rb] = *reinterpret_cast<const bf16x8*>(cur + ((size_t)((s + 1) * 2) * kRPAD3 + 32 * rb) * 16);
-      }
-#pragma unroll
-      for (int rb = 0; rb < kRB3; ++rb)
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb)
-          acc[rb][cb][0] += (float)a[rb][0] * (float)bq[s][cb][0];
-      if (!last) {
-        const unsigned ksn = (unsigned)((c + 1) * 4 + s) * 1024u;
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb) bq[s][cb] = ldbuf_bf16x8(rs_w, lane16, w0 + (unsigned)cb * KS * 1024u + ksn);
-      }
-      if (s < 3) {
-#pragma unroll
-        for (int rb = 0; rb < kRB3; ++rb) a[rb] = an[rb];
-      }
-    }
-#endif
   };
   // Table-row units: set A serves every chunk (depth 1) or the odd chunks (depth 2), set B the even chunks of
   // the depth-2 pipeline.  Depth 2 = rows requested two chunks ahead; the message kernel has the registers for
@@ -243,14 +183,14 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
     // vector work wins issue arbitration over the partner wave's MFMAs (which only need 1 slot in 4)
     __builtin_amdgcn_s_setprio(3);
     const bf16x8 o0 = unith_finish(x0, s_wd + c * kKC3 + kg * 8, d2r0, slot0 + nbuf);
-    STAMP2(c - 1, 1, wave >= 4);
+    DIAG_STAMP2(c - 1, 1, wave >= 4);
     const bf16x8 o1 = unith_finish(x1, s_wd + c * kKC3 + kg * 8, d2r1, slot1 + nbuf);
-    STAMP2(c - 1, 2, wave >= 4);
+    DIAG_STAMP2(c - 1, 2, wave >= 4);
     __builtin_amdgcn_s_setprio(0);
     if constexpr (BWD || SAVE) s1_store(o0, o1, c);
   };
-  STAMP(30, 2);   // chunk 0 built, first weights requested
-  RSTAMP(31, 1);
+  DIAG_STAMP(30, 2);   // chunk 0 built, first weights requested
+  DIAG_RSTAMP(31, 1);
   // The two waves that share a SIMD (w and w+4) run the chunk in opposite phase: waves 0-3 multiply chunk c
   // and then build chunk c+1, waves 4-7 build chunk c+1 first and then multiply chunk c -- one wave's vector
   // work runs under its partner's matrix work instead of both alternating in lockstep.  One barrier per chunk
@@ -259,21 +199,18 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
   // the group's barrier wait instead of delaying its matrix phase).
   // (the steady-state loop bodies are branch-free so that hipcc's waitcnt insertion can keep counted
   // vmcnt waits across the back edge instead of draining the queue at every control-flow join)
-#ifdef EGNN_EXP_NO_BUILD
-  for (int c = 0; c < NC; ++c) { mphase(c, c == NC - 1); __syncthreads(); }
-#else
   if (wave < 4) {
     auto step = [&](UnitH& x0, UnitH& x1, const int i) {   // chunk i: multiply, build i+1, request the set's next chunk
-      STAMP(i, 0);
-      STAMP2(i, 1, true);
+      DIAG_STAMP(i, 0);
+      DIAG_STAMP2(i, 1, true);
       mphase(i, false);
-      STAMP1(i, 1);
-      STAMP2(i, 3, true);
+      DIAG_STAMP1(i, 1);
+      DIAG_STAMP2(i, 3, true);
       vfinish(x0, x1, i + 1);
       vload(x0, x1, i + (DEPTH2 ? 3 : 2));
-      STAMP1(i, 2);
+      DIAG_STAMP1(i, 2);
       __syncthreads();
-      STAMP1(i, 3);
+      DIAG_STAMP1(i, 3);
     };
     vload(ua0, ua1, 1);
     if constexpr (DEPTH2) {
@@ -288,16 +225,16 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
     __syncthreads();
   } else {
     auto step = [&](UnitH& x0, UnitH& x1, const int i) {   // build i+1, request the set's next chunk, multiply chunk i
-      STAMP(i, 0);
+      DIAG_STAMP(i, 0);
       vfinish(x0, x1, i + 1);
       vload(x0, x1, i + (DEPTH2 ? 3 : 2));
       __builtin_amdgcn_sched_barrier(0);
-      STAMP1(i, 1);
-      STAMP2(i, 3, true);
+      DIAG_STAMP1(i, 1);
+      DIAG_STAMP2(i, 3, true);
       mphase(i, false);
-      STAMP1(i, 2);
+      DIAG_STAMP1(i, 2);
       __syncthreads();
-      STAMP1(i, 3);
+      DIAG_STAMP1(i, 3);
     };
     vload(ua0, ua1, 1);
     if constexpr (DEPTH2) {
@@ -311,22 +248,8 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
     mphase(NC - 1, true);
     __syncthreads();
   }
-#endif
-  STAMP(30, 3);   // K loop done
-  RSTAMP(31, 2);
-#ifdef EGNN_EXP_NO_EPI
-  {
-    float keep = 0.f;
-#pragma unroll
-    for (int rb = 0; rb < kRB3; ++rb)
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) keep += acc[rb][cb][i];
-    if (keep == 1.2345e-30f) p.agg_x[tid] = keep;
-    return;
-  }
-#endif
+  DIAG_STAMP(30, 3);   // K loop done
+  DIAG_RSTAMP(31, 2);
 
   // row of value index q (q = rb*16 + reg) for this lane
   auto row_of = [&](int q) { return 32 * (q >> 4) + acc_row(q & 15, lane); };
@@ -446,7 +369,7 @@ __global__ __launch_bounds__(kT3, 2) void edge_kernel_bf16_v3(const EdgeParams p
   } else {
     static_assert(!IS_M, "edge_bf16_v3.hip keeps the coordinate kernels only (message kernels: edge_bf16_v4.hip)");
   }
-  STAMP(31, 0);   // epilogue done
+  DIAG_STAMP(31, 0);   // epilogue done
 }
 
 template <int CB, bool IS_M, bool BWD = false, bool SAVE = false>

@@ -30,28 +30,17 @@
 // the double-buffered LDS activation chunk, CB B fragments straight from the packed weights, 4*CB MFMAs.
 #include <type_traits>
 
+#include "diag.h"
 #include "edge_tile.h"
 
 namespace egnn {
 
 namespace {
 
-#ifdef EGNN_EXP_WGSTAMP   // diagnostic build only (tools/fwd_stamps.py): 100 MHz wall stamps of EVERY workgroup's phases + where it ran
+#ifdef EGNN_EXP_WGSTAMP   // diagnostic build (diag.h, tools/fwd_stamps.py)
 __device__ unsigned long long g_mwg_stamps[20000][6];
-#define WG_STAMP(k)                                                                                   \
-  do {                                                                                                \
-    unsigned long long t_;                                                                            \
-    __builtin_amdgcn_sched_barrier(0);                                                                \
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
-    __builtin_amdgcn_sched_barrier(0);                                                                \
-    if (threadIdx.x == 0 && blockIdx.x < 20000) g_mwg_stamps[blockIdx.x][k] = t_;                                \
-  } while (0)
-#define WG_STAMP_HW()                                                                                 \
-  do {                                                                                                \
-    if (threadIdx.x == 0 && blockIdx.x < 20000)                                                       \
-      g_mwg_stamps[blockIdx.x][5] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |             \
-                          ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);      \
-  } while (0)
+#define WG_STAMP(k) DIAG_WG_STAMP(g_mwg_stamps, 20000, k)
+#define WG_STAMP_HW() DIAG_WG_STAMP_HW(g_mwg_stamps, 20000, 5)
 #else
 #define WG_STAMP(k)
 #define WG_STAMP_HW()
@@ -99,49 +88,19 @@ __global__ __launch_bounds__(kT3, ((CB == 1 && !BWD) ? EGNN_V4_M_WAVES : 2)) voi
   const int e0 = tile * kR3;
   const int nvalid = min(kR3, p.E - e0);
 
-#ifdef EGNN_EXP_STAMP
-  const bool stamp_wg = blockIdx.x == gridDim.x / 2;
-  unsigned long long* st_base = p.stamps + ((size_t)(IS_M ? 1 : 0) * 8 + wave) * 32 * 4;
-#define STAMP(c, k)                                                                               \
-  do {                                                                                            \
-    unsigned long long t_;                                                                        \
-    __builtin_amdgcn_sched_barrier(0);                                                            \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
-    __builtin_amdgcn_sched_barrier(0);                                                            \
-    if (stamp_wg && lane == 0 && (c) < 32) st_base[(c) * 4 + (k)] = t_;                           \
-  } while (0)
-// 100 MHz wall counter next to a cycle stamp: in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz
-#define RSTAMP(c, k)                                                                              \
-  do {                                                                                            \
-    unsigned long long t_;                                                                        \
-    __builtin_amdgcn_sched_barrier(0);                                                            \
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
-    __builtin_amdgcn_sched_barrier(0);                                                            \
-    if (stamp_wg && lane == 0 && (c) < 32) st_base[(c) * 4 + (k)] = t_;                           \
-  } while (0)
-#else
-#define STAMP(c, k)
-#define RSTAMP(c, k)
-#endif
-#ifdef EGNN_EXP_STAMP2   // finer stamps inside the first half of a chunk (replaces the meaning of slots 1..3)
-#define STAMP2(c, k, cond) do { if (cond) STAMP(c, k); } while (0)
-#define STAMP1(c, k)
-#else
-#define STAMP2(c, k, cond)
-#define STAMP1(c, k) STAMP(c, k)
-#endif
-  STAMP(30, 0);   // kernel entry
+  DIAG_STAMP_SETUP(p.stamps + ((size_t)(IS_M ? 1 : 0) * 8 + wave) * 32 * 4);
+  DIAG_STAMP(30, 0);   // kernel entry
   WG_STAMP(0);
   prologue_rows(p, L, e0, nvalid, IS_M ? p.wdm : p.wdx, KP, s_wd, tid);
 
-  STAMP(30, 1);   // tile structure ready
+  DIAG_STAMP(30, 1);   // tile structure ready
   WG_STAMP(1);
 
   // ---- K-loop ----
   const int NC = KP / kKC3, KS = KP / 16;
   const int brow = tid >> 3, kg = tid & 7;   // this thread builds rows brow and brow + 64, columns [8 kg, 8 kg + 8) of a chunk
-  const rsrc_t rs_tab = make_rsrc(p.table, (p.dbg & 2) ? 0u : (unsigned)((size_t)p.N * p.TC * 2));
-  const rsrc_t rs_w = make_rsrc(IS_M ? p.w2m : p.w2x, (p.dbg & 1) ? 0u : (unsigned)((size_t)(IS_M ? p.MP : p.WxP) * KP * 2));
+  const rsrc_t rs_tab = make_rsrc(p.table, diag::drop_table_loads(p.dbg) ? 0u : (unsigned)((size_t)p.N * p.TC * 2));
+  const rsrc_t rs_w = make_rsrc(IS_M ? p.w2m : p.w2x, diag::drop_weight_loads(p.dbg) ? 0u : (unsigned)((size_t)(IS_M ? p.MP : p.WxP) * KP * 2));
   const unsigned vdst0 = (unsigned)s_dst[brow] * (unsigned)p.TC * 2u + (unsigned)kg * 16u;
   const unsigned vsrc0 = (unsigned)s_src[brow] * (unsigned)p.TC * 2u + (unsigned)kg * 16u;
   const unsigned vdst1 = (unsigned)s_dst[brow + 64] * (unsigned)p.TC * 2u + (unsigned)kg * 16u;
@@ -219,7 +178,7 @@ __global__ __launch_bounds__(kT3, ((CB == 1 && !BWD) ? EGNN_V4_M_WAVES : 2)) voi
   // only use the 24 free issue cycles of an MFMA's 32 if the fillers sit BETWEEN two MFMAs in program order.
   // sched_barrier(0) pins this order; inside a half the compiler schedules freely.
   auto chunk = [&](const int c, const bool build, const bool last) {
-    STAMP(c, 0);
+    DIAG_STAMP(c, 0);
     const unsigned abase = lds_a1_base + off_cur, nbase = lds_a1_base + off_nxt;
     f16x8 t;
     V8 o;
@@ -288,9 +247,9 @@ __global__ __launch_bounds__(kT3, ((CB == 1 && !BWD) ? EGNN_V4_M_WAVES : 2)) voi
         bq[(S) % BQD][cb] = ldbuf_v8<V8>(rs_w, lane16, w0off + (unsigned)cb * KS * 1024u + ksn);              \
     }
     KSTEP(0) KSTEP(1)
-    STAMP(c, 1);
+    DIAG_STAMP(c, 1);
     KSTEP(2) KSTEP(3)
-    STAMP(c, 2);
+    DIAG_STAMP(c, 2);
 #undef KSTEP
 #undef GROUP
 #undef STAGE
@@ -298,24 +257,24 @@ __global__ __launch_bounds__(kT3, ((CB == 1 && !BWD) ? EGNN_V4_M_WAVES : 2)) voi
   };
   // (the steady-state loop body is branch-free so that hipcc's waitcnt insertion keeps counted vmcnt waits across
   // the back edge instead of draining the queue at every control-flow join)
-  STAMP(30, 2);   // chunks 0 and 1 built, first weights requested
+  DIAG_STAMP(30, 2);   // chunks 0 and 1 built, first weights requested
   WG_STAMP(2);
-  RSTAMP(31, 1);
+  DIAG_RSTAMP(31, 1);
   for (int c = 0; c < NC - 2; ++c) {
     chunk(c, true, false);
     if (c == 0 && tid < S) L.seg_mode[tid] = my_mode;
-    __syncthreads(); STAMP(c, 3);
+    __syncthreads(); DIAG_STAMP(c, 3);
   }
   chunk(NC - 2, false, false);
   __syncthreads();
-  STAMP(NC - 2, 3);
+  DIAG_STAMP(NC - 2, 3);
   chunk(NC - 1, false, true);
   __syncthreads();
-  STAMP(NC - 1, 3);
-  RSTAMP(31, 2);
+  DIAG_STAMP(NC - 1, 3);
+  DIAG_RSTAMP(31, 2);
 #undef LDS_WAIT
 #undef LDS_RD
-  STAMP(30, 3);   // K loop done
+  DIAG_STAMP(30, 3);   // K loop done
   WG_STAMP(3);
 
 
@@ -417,7 +376,7 @@ __global__ __launch_bounds__(kT3, ((CB == 1 && !BWD) ? EGNN_V4_M_WAVES : 2)) voi
     }
     message_epilogue<SAVE>(p, L, acc, S, tile, tid, lane, wave, kNegLog2e / OpTraits<V8>::wscale);
   }
-  STAMP(31, 0);   // epilogue done
+  DIAG_STAMP(31, 0);   // epilogue done
   WG_STAMP(4);
   WG_STAMP_HW();
 }

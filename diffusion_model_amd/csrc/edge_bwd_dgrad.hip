@@ -15,6 +15,7 @@
 // half-wave), product, row-major bf16 store through the per-wave LDS transpose.
 #include <stdlib.h>
 
+#include "diag.h"
 #include "kernels.h"
 
 namespace egnn {
@@ -46,16 +47,9 @@ struct DgradParams {
 // CB = 32-column blocks per wave: 2 = 512 output columns per workgroup (252 VGPRs, one workgroup per CU); 1 = 256 columns
 // (<= 128 VGPRs, TWO workgroups per CU: one's SiLU' epilogue runs under the other's K loop; the dL/da2 tile is then
 // copied by four workgroups instead of two, which costs L2 reads only -- there is no vector arithmetic to duplicate).
-#ifdef EGNN_EXP_DGSTAMP   // diagnostic build only (tools/dgrad_stamps.py): 100 MHz wall stamps of EVERY workgroup's phases + where it ran
+#ifdef EGNN_EXP_DGSTAMP   // diagnostic build (diag.h, tools/dgrad_stamps.py)
 __device__ unsigned long long g_dg_stamps[2][40000][12];
-#define DG_STAMP(k)                                                                                   \
-  do {                                                                                                \
-    unsigned long long t_;                                                                            \
-    __builtin_amdgcn_sched_barrier(0);                                                                \
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
-    __builtin_amdgcn_sched_barrier(0);                                                                \
-    if (tid == 0 && blockIdx.x < 40000) g_dg_stamps[CB == 2 ? 0 : 1][blockIdx.x][k] = t_;             \
-  } while (0)
+#define DG_STAMP(k) DIAG_WG_STAMP(g_dg_stamps[CB == 2 ? 0 : 1], 40000, k)
 #else
 #define DG_STAMP(k)
 #endif
@@ -178,27 +172,12 @@ __global__ __launch_bounds__(64 * NW, (CB == 1 ? 4 : 2)) void edge_dgrad_kernel(
     s_src[tid] = (int)(((unsigned)s * (unsigned)p.TC + (unsigned)p.offQ) * 2u);
     s_d2[tid] = dd;
   }
-#ifdef EGNN_EXP_DG_NOK   // timing experiment: two chunks of K loop only (prologue + epilogue time)
-  const int NC = 2, KS = p.Kd / 16;
-#else
-  const int NC = p.Kd / kKCD, KS = p.Kd / 16;
-#endif
+  const int NC = diag::kDgNoK ? 2 : p.Kd / kKCD, KS = p.Kd / 16;   // (diag: two chunks only = prologue + epilogue time)
   const int brow = tid >> 3, kg = tid & 7;   // this thread copies rows brow + 8 NW i (i < PP), k-group kg of every chunk
-#ifdef EGNN_EXP_DG_NOG   // timing experiments only (tools/exp_build.sh): zero-size descriptors = loads that never leave the CU
-  const rsrc_t rs_g = make_rsrc(p.g_a2, 0u);
-#else
-  const rsrc_t rs_g = make_rsrc(p.g_a2, (unsigned)((size_t)p.E * p.Kd * 2));   // rows past the chunk read as zero
-#endif
-#ifdef EGNN_EXP_DG_NOW
-  const rsrc_t rs_w = make_rsrc(p.w2t, 0u);
-#else
-  const rsrc_t rs_w = make_rsrc(p.w2t, (unsigned)((size_t)p.KP * p.Kd * 2));
-#endif
-#ifdef EGNN_EXP_DG_L2G   // timing experiment: every tile streams tile 0's rows (real data, served from L2)
-  const unsigned vrow0 = (unsigned)(brow) * (unsigned)p.Kd * 2u + (unsigned)kg * 16u;
-#else
-  const unsigned vrow0 = (unsigned)(e0 + brow) * (unsigned)p.Kd * 2u + (unsigned)kg * 16u;
-#endif
+  // (diag timing builds: zero-size descriptors = loads that never leave the CU; kDgL2G: every tile streams tile 0's rows)
+  const rsrc_t rs_g = make_rsrc(p.g_a2, diag::kDgNoG ? 0u : (unsigned)((size_t)p.E * p.Kd * 2));   // rows past the chunk read as zero
+  const rsrc_t rs_w = make_rsrc(p.w2t, diag::kDgNoW ? 0u : (unsigned)((size_t)p.KP * p.Kd * 2));
+  const unsigned vrow0 = (unsigned)((diag::kDgL2G ? 0 : e0) + brow) * (unsigned)p.Kd * 2u + (unsigned)kg * 16u;
   const unsigned vstep = (unsigned)(8 * NW) * (unsigned)p.Kd * 2u;
   char* slot0 = s_a1 + ((size_t)kg * kRPADD + brow) * 16;
   constexpr unsigned kSlotStep = 8 * NW * 16;
@@ -306,10 +285,7 @@ __global__ __launch_bounds__(64 * NW, (CB == 1 ? 4 : 2)) void edge_dgrad_kernel(
   // gathers per accumulator element (round 2: 256 scalar-width vector-memory instructions per wave and row block, the
   // epilogue as long as the K loop).  SiLU' is applied on the row-major values; the table entries are added in fp16 as the
   // forward adds them (same a1 bit for bit).
-#ifdef EGNN_EXP_DG_NOTAB
-  const rsrc_t rs_tab = make_rsrc(p.table, 0u);
-#elif defined(EGNN_EXP_DG_NOEPI)   // timing experiment: K loop only, one value per lane stored so that nothing is dropped
-  {
+  if constexpr (diag::kDgNoEpi) {   // timing build: K loop only, one value per lane stored so that nothing is dropped
     float sum = 0.f;
 #pragma unroll
     for (int rb = 0; rb < kRBD; ++rb)
@@ -320,10 +296,7 @@ __global__ __launch_bounds__(64 * NW, (CB == 1 ? 4 : 2)) void edge_dgrad_kernel(
     if (sum == 123.456f) static_cast<__bf16*>(p.g_a1_out)[tid] = (__bf16)sum;
     return;
   }
-  const rsrc_t rs_tab = make_rsrc(p.table, 0u);
-#else
-  const rsrc_t rs_tab = make_rsrc(tab_ptr, tab_bytes);
-#endif
+  const rsrc_t rs_tab = make_rsrc(tab_ptr, diag::kDgNoTab ? 0u : tab_bytes);
   __bf16* stg = reinterpret_cast<__bf16*>(s_a1) + (size_t)wave * 32 * 72;
   __bf16* gout = static_cast<__bf16*>(out_ptr) + (size_t)e0 * p.KP + 32 * colblk0;
   dgrad_epilogue<CB>(acc, rs_tab, s_dst, s_src, s_d2, wd_ptr, stg, gout, p.KP, colblk0, nvalid, lane);
@@ -331,9 +304,7 @@ __global__ __launch_bounds__(64 * NW, (CB == 1 ? 4 : 2)) void edge_dgrad_kernel(
 #ifdef EGNN_EXP_DGSTAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   DG_STAMP(4);
-  if (tid == 0 && blockIdx.x < 40000)
-    g_dg_stamps[CB == 2 ? 0 : 1][blockIdx.x][5] =
-        (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
+  DIAG_WG_STAMP_HW(g_dg_stamps[CB == 2 ? 0 : 1], 40000, 5);
 #endif
 }
 

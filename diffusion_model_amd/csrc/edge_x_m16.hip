@@ -14,28 +14,17 @@
 //   * weight fragments packed [16-column block][32-deep k-step][lane][8 bf16] (pack_frags_bf16_n16);
 //   * the row sums of the head s = w3 . SiLU(a2) + b3 run over the 16 lanes of a DPP row (tile128::butterfly16).
 // Prologue and segment sums are the shared ones of edge_tile.h.
+#include "diag.h"
 #include "edge_tile.h"
 
 namespace egnn {
 
 namespace {
 
-#ifdef EGNN_EXP_WGSTAMP   // diagnostic build only (tools/fwd_stamps.py): 100 MHz wall stamps of EVERY workgroup's phases + where it ran
+#ifdef EGNN_EXP_WGSTAMP   // diagnostic build (diag.h, tools/fwd_stamps.py)
 __device__ unsigned long long g_xwg_stamps[20000][12];
-#define WG_STAMP(k)                                                                                   \
-  do {                                                                                                \
-    unsigned long long t_;                                                                            \
-    __builtin_amdgcn_sched_barrier(0);                                                                \
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
-    __builtin_amdgcn_sched_barrier(0);                                                                \
-    if (threadIdx.x == 0 && blockIdx.x < 20000) g_xwg_stamps[blockIdx.x][k] = t_;                                \
-  } while (0)
-#define WG_STAMP_HW()                                                                                 \
-  do {                                                                                                \
-    if (threadIdx.x == 0 && blockIdx.x < 20000)                                                       \
-      g_xwg_stamps[blockIdx.x][5] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |             \
-                          ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);      \
-  } while (0)
+#define WG_STAMP(k) DIAG_WG_STAMP(g_xwg_stamps, 20000, k)
+#define WG_STAMP_HW() DIAG_WG_STAMP_HW(g_xwg_stamps, 20000, 5)
 #else
 #define WG_STAMP(k)
 #define WG_STAMP_HW()
@@ -74,34 +63,18 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
   const int e0 = tile * kR;
   const int nvalid = min(kR, p.E - e0);
 
-#ifdef EGNN_EXP_STAMP   // diagnostic build only: cycle / 100 MHz wall stamps of one workgroup (tools/stamps.py layout)
-  const bool stamp_wg = blockIdx.x == gridDim.x / 2;
-  unsigned long long* st_base = p.stamps + (size_t)wave * 32 * 4;
-#define STAMP_(insn, c, k)                                                                        \
-  do {                                                                                            \
-    unsigned long long t_;                                                                        \
-    __builtin_amdgcn_sched_barrier(0);                                                            \
-    asm volatile(insn " %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                        \
-    __builtin_amdgcn_sched_barrier(0);                                                            \
-    if (stamp_wg && lane == 0) st_base[(c) * 4 + (k)] = t_;                                       \
-  } while (0)
-#define STAMP(c, k) STAMP_("s_memtime", c, k)
-#define RSTAMP(c, k) STAMP_("s_memrealtime", c, k)
-#else
-#define STAMP(c, k)
-#define RSTAMP(c, k)
-#endif
-  STAMP(30, 0);   // kernel entry
+  DIAG_STAMP_SETUP(p.stamps + (size_t)wave * 32 * 4);
+  DIAG_STAMP(30, 0);   // kernel entry
   WG_STAMP(0);
   prologue_rows(p, L, e0, nvalid, p.wdx, KP, s_wd, tid);
-  STAMP(30, 1);   // edge rows and geometry ready
+  DIAG_STAMP(30, 1);   // edge rows and geometry ready
   WG_STAMP(1);
 
   // ---- K loop ----
   const int NC = KP / kKC, KS = KP / 32;
   const int brow = tid >> 3, kg = tid & 7;   // this thread builds rows brow and brow + 64, columns 8 kg .. 8 kg + 7 of a chunk
-  const rsrc_t rs_tab = make_rsrc(p.table, (p.dbg & 2) ? 0u : (unsigned)((size_t)p.N * p.TC * 2));
-  const rsrc_t rs_w = make_rsrc(p.w2x, (p.dbg & 1) ? 0u : (unsigned)((size_t)p.WxP * KP * 2));
+  const rsrc_t rs_tab = make_rsrc(p.table, diag::drop_table_loads(p.dbg) ? 0u : (unsigned)((size_t)p.N * p.TC * 2));
+  const rsrc_t rs_w = make_rsrc(p.w2x, diag::drop_weight_loads(p.dbg) ? 0u : (unsigned)((size_t)p.WxP * KP * 2));
   const unsigned vdst0 = (unsigned)L.dst[brow] * (unsigned)p.TC * 2u + (unsigned)kg * 16u;
   const unsigned vsrc0 = (unsigned)L.src[brow] * (unsigned)p.TC * 2u + (unsigned)kg * 16u;
   const unsigned vdst1 = (unsigned)L.dst[brow + 64] * (unsigned)p.TC * 2u + (unsigned)kg * 16u;
@@ -128,14 +101,17 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
 
   // training forward: the activation chunk also goes to HBM, 16 bytes per thread, 128 contiguous bytes per row and chunk
   // (both column shares build the same activations: only share 0 stores them)
+  // (buffer stores: descriptor in scalar registers, one 32-bit offset per row, the chunk's column offset as the scalar offset;
+  // rows past the edge list fall outside the descriptor and are dropped by the hardware.  Flat 64-bit addresses cost the
+  // four registers that made hipcc spill 20 bytes per lane around the K loop.)
+  const rsrc_t rs_s1 = make_rsrc(SAVE ? p.s1_out : nullptr, SAVE ? (unsigned)((size_t)p.E * KP * 2) : 0u);   // < 4 GiB: checked by the host
+  const unsigned vs1_0 = (unsigned)(e0 + brow) * (unsigned)KP * 2u + (unsigned)kg * 16u, vs1_1 = vs1_0 + 64u * (unsigned)KP * 2u;
   auto s1_store = [&](const V8 o0, const V8 o1, const int c) {
     if (half != 0) return;
-#ifdef EGNN_EXP_NO_S1   // timing experiment
-    return;
-#endif
-    __bf16* base = static_cast<__bf16*>(p.s1_out) + (size_t)e0 * KP + c * kKC + kg * 8;
-    if (brow < nvalid) *reinterpret_cast<V8*>(base + (size_t)brow * KP) = o0;
-    if (brow + 64 < nvalid) *reinterpret_cast<V8*>(base + (size_t)(brow + 64) * KP) = o1;
+    if constexpr (diag::kNoS1) return;
+    const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)c * kKC * 2u);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rs_s1, vs1_0, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rs_s1, vs1_1, soff, 0);
   };
   // chunk 0: both rows' table pieces and the first weight fragments are requested, THEN the segment structure of the tile is
   // worked out (two barriers, waves 0 and 1 only) while they are in flight, then the activations are finished
@@ -213,9 +189,9 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
     if constexpr (SAVE) s1_store(o0, o1, c);
   };
   // SIMD partners (waves w and w + 4) in opposite phase, one barrier per chunk (edge_bf16_v3.hip)
-  STAMP(30, 2);   // chunk 0 built, first weights requested
+  DIAG_STAMP(30, 2);   // chunk 0 built, first weights requested
   WG_STAMP(2);
-  RSTAMP(31, 1);
+  DIAG_RSTAMP(31, 1);
   vload(1);
   if (wave < 4) {
     // row_ptr loads of the segment modes (needed by the epilogue only) ride under the first matrix phase of wave 0
@@ -238,9 +214,9 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
   }
   mphase(NC - 1, true);
   __syncthreads();
-  STAMP(30, 3);   // K loop done
+  DIAG_STAMP(30, 3);   // K loop done
   WG_STAMP(3);
-  RSTAMP(31, 2);
+  DIAG_RSTAMP(31, 2);
 
   // ---- epilogue: s[row] = [b3] + sum_n w3[n] * SiLU(a2[row][n] + b2[n]) over this workgroup's 512 columns ----
   // accumulator layout of the 16x16 tile: column = lane & 15, row = 4 (lane >> 4) + register
@@ -270,11 +246,7 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int piece = lane + 64 * t, row = piece >> 3, seg = piece & 7;   // 16 rows x 8 pieces of 16 bytes
-#ifdef EGNN_EXP_NO_T2   // timing experiment
-        if (16 * rb + row < nvalid - 1000)
-#else
-        if (16 * rb + row < nvalid)
-#endif
+        if (16 * rb + row < nvalid - (diag::kNoT2 ? 1000 : 0))
           *reinterpret_cast<bf16x8*>(tout + (size_t)(16 * rb + row) * p.WxP + 8 * seg) = *reinterpret_cast<const bf16x8*>(stg + row * 72 + 8 * seg);
       }
       __builtin_amdgcn_wave_barrier();
@@ -324,11 +296,9 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
   __syncthreads();
   WG_STAMP(8);   // s_e per row ready
   coordinate_segment_sums(p, L, S, tile, half, tid, lane, wave);
-  STAMP(31, 0);   // epilogue done
+  DIAG_STAMP(31, 0);   // epilogue done
   WG_STAMP(4);
   WG_STAMP_HW();
-#undef STAMP
-#undef RSTAMP
 }
 
 }  // namespace

@@ -28,14 +28,6 @@
 
 namespace egnn {
 
-static thread_local char g_err[512] = "";
-void set_error(const char* fmt, ...) {
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(g_err, sizeof(g_err), fmt, ap);
-  va_end(ap);
-}
-
 // ------------------------------------------------------------------------------------------------
 // parameter packing
 // ------------------------------------------------------------------------------------------------
@@ -976,11 +968,7 @@ static void prof_end(egnn_ctx* c, hipStream_t st) {
 // CU), the message kernel goes to the side stream and runs in that shadow: one 64-atom graph 64 of 256 CUs busy, five graphs
 // (generate()'s default gen_num_per_spectrum) 316 coordinate workgroups = 1.23 rounds -> 0.49 -> 0.42 ms per reverse step.
 // Full rounds (16 graphs and more: measured equal eager, 2-8 % slower in graph replay) keep the single stream.
-static bool fork_candidate(int E, int WxP) {
-  const long tiles = (E + 127) / 128, xw = tiles * (WxP >= 512 ? WxP / 512 : 1);
-  const long idle = (xw + 255) / 256 * 256 - xw;
-  return E > 0 && idle >= (tiles + 1) / 2;
-}
+// (the decision itself: fork_candidate() in host_logic.cpp)
 
 int fork_streams(egnn_ctx* c) {   // fork / join events for a context whose caller provided a side stream
   if (!c->side || c->ev_fork) return EGNN_OK;
@@ -1036,8 +1024,10 @@ static void fill_edge_params(egnn_ctx* c, int layer, int prec, const float* x, E
   p.agg_m = c->agg_m; p.agg_x = c->agg_x; p.part_m = c->part_m; p.part_x = c->part_x;
   p.agg_x_stride = (size_t)c->cap_nodes * 4; p.part_x_stride = (c->cap_tiles + 1) * 2 * 4;
   p.stamps = c->stamps;
+#ifdef EGNN_DIAG   // diagnostic builds only (diag.h): EGNN_DEBUG switches the weight / table streams off
   static const int dbg = getenv("EGNN_DEBUG") ? atoi(getenv("EGNN_DEBUG")) : 0;
   p.dbg = dbg;
+#endif
 }
 // the bf16 fast kernels (v2..v4) use the copies pre-scaled by -log2(e) / -1/log2(e) (LayerPack::sc)
 static void use_scaled_pack(egnn_ctx* c, int layer, EdgeParams& p, const float*& w1catT, const float*& b1cat) {
@@ -1355,9 +1345,6 @@ using namespace egnn;
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-const char* egnn_last_error(void) { return g_err; }
-int egnn_version(void) { return 1; }
-
 int egnn_create(egnn_ctx** out, int device) {
   if (!out) return EGNN_EINVAL;
   int count = 0;
@@ -1406,31 +1393,20 @@ int egnn_destroy(egnn_ctx* c) {
   return EGNN_OK;
 }
 
-static int pow2_ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
-
 int egnn_set_model(egnn_ctx* c, int L, int H, int M, int Wm, int Wx, int Wh) {
-  if (!c || L < 1 || H < 1 || M < 1 || Wm < 1 || Wx < 1 || Wh < 1) { set_error("bad model dims"); return EGNN_EINVAL; }
-  if (Wx > 128 * kMaxCB || Wm > 128 * kMaxCB || M > 128 * kMaxCB || H > 32 * kPostMaxOB) {
-    set_error("unsupported width: hidden/message widths must be <= %d and H <= %d", 128 * kMaxCB, 32 * kPostMaxOB);
-    return EGNN_EINVAL;
+  if (!c) return EGNN_EINVAL;
+  ModelDims md;
+  {
+    const int rc = model_dims(L, H, M, Wm, Wx, Wh, &md);   // validation + padded widths (host_logic.cpp)
+    if (rc) return rc;
   }
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   for (auto& lp : c->layers) free_layer(lp);
   c->layers.assign(L, LayerPack());
   c->L = L; c->H = H; c->M = M; c->Wm = Wm; c->Wx = Wx; c->Wh = Wh;
-  // widths are padded to 256 * 2^k: 8 waves x 32-column blocks in the bf16 kernel, 4 waves x 64 in the
-  // fp32 one; zero-padded weights/biases contribute SiLU(0) * 0 = 0
-  c->WxP = 256 * pow2_ceil((Wx + 255) / 256);   // K and N of mlp_x.2
-  c->WmP = 256 * pow2_ceil((Wm + 255) / 256);   // K of mlp_m.2
-  c->MP = 256 * pow2_ceil((M + 255) / 256);     // N of mlp_m.2
-  c->cbx = c->WxP / 128;
-  c->cbm = c->MP / 128;
-  c->WhP = round_up(Wh, 128);
-  c->HP = round_up(H, 32);
-  c->K1P = round_up(H + c->MP, 8);
-  c->K1Q = round_up(H + c->MP, 16);
-  c->TC = 2 * c->WxP + 2 * c->WmP;
+  c->WxP = md.WxP; c->WmP = md.WmP; c->MP = md.MP; c->cbx = md.cbx; c->cbm = md.cbm;
+  c->WhP = md.WhP; c->HP = md.HP; c->K1P = md.K1P; c->K1Q = md.K1Q; c->TC = md.TC;
   c->cap_nodes = c->cap_tiles = c->cap_graphs = 0;  // MP / TC may have changed
   if (post_smem_bytes(c->K1P, c->WhP) > 160 * 1024 || edge_smem_bytes(64, c->MP) > 160 * 1024) {
     set_error("model does not fit the 160 KiB LDS budget");
@@ -1586,11 +1562,11 @@ int egnn_set_side_stream(egnn_ctx* c, void* stream) {
 
 int egnn_set_graph(egnn_ctx* c, int N, int E, int B, const int32_t* edge_dst, const int32_t* edge_src,
                    const int32_t* row_ptr, const int32_t* graph_ptr, const int32_t* node_graph) {
-  if (!c || N < 1 || E < 0 || B < 1 || !row_ptr || !graph_ptr || !node_graph || (E > 0 && (!edge_dst || !edge_src))) {
-    set_error("bad graph arguments");
-    return EGNN_EINVAL;
+  if (!c) return EGNN_EINVAL;
+  {
+    const int rc = graph_args_check(c->L != 0, N, E, B, edge_dst, edge_src, row_ptr, graph_ptr, node_graph);
+    if (rc) return rc;
   }
-  if (c->L == 0) { set_error("egnn_set_model first"); return EGNN_ESTATE; }
   EGNN_HIP(hipSetDevice(c->device));
   c->N = N; c->E = E; c->B = B;
   c->edge_dst = edge_dst; c->edge_src = edge_src; c->row_ptr = row_ptr; c->graph_ptr = graph_ptr;
@@ -1600,13 +1576,7 @@ int egnn_set_graph(egnn_ctx* c, int N, int E, int B, const int32_t* edge_dst, co
 }
 
 static int check_ready(egnn_ctx* c, int prec, int norm_scope) {
-  if (!c || c->L == 0 || c->N == 0) { set_error("model/graph not set"); return EGNN_ESTATE; }
-  if (prec != EGNN_PREC_F32 && prec != EGNN_PREC_BF16 && prec != EGNN_PREC_BF16X3 && prec != EGNN_PREC_F16) {
-    set_error("bad precision %d", prec);
-    return EGNN_EINVAL;
-  }
-  if (norm_scope != EGNN_NORM_CALL && norm_scope != EGNN_NORM_GRAPH) { set_error("bad norm scope"); return EGNN_EINVAL; }
-  return EGNN_OK;
+  return precision_scope_check(c && c->L != 0 && c->N != 0, prec, norm_scope);
 }
 
 int egcl_forward(egnn_ctx* c, void* stream, int layer, int prec, int norm_scope, const float* h, const float* x,
@@ -1631,6 +1601,10 @@ int egcl_forward_save(egnn_ctx* c, void* stream, int layer, int norm_scope, cons
     return EGNN_EINVAL;
   }
   if (c->E == 0 || !backward_recompute_supported(c)) { set_error("egcl_forward_save is not available for these widths"); return EGNN_EINVAL; }
+  if ((size_t)c->E * c->WxP * 2 >= ((size_t)1 << 32)) {   // the activation chunks are stored through a 32-bit buffer descriptor
+    set_error("egcl_forward_save: E x Wx x 2 bytes must stay below 4 GiB (%d edges); train on smaller batches or use the recompute path", c->E);
+    return EGNN_EINVAL;
+  }
   c->save_s1x = s1x; c->save_s1m = s1m; c->save_t2x = t2x; c->save_t2m = t2m; c->save_s = s_shares;
   rc = launch_layer(c, reinterpret_cast<hipStream_t>(stream), layer, EGNN_PREC_BF16, norm_scope, h, x, h_out, x_out, true);
   c->save_s1x = c->save_s1m = c->save_t2x = c->save_t2m = nullptr; c->save_s = nullptr;

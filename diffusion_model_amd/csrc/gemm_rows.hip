@@ -171,14 +171,9 @@ int egnn_gemm_rows_pack(void* stream, int K, int ncols, const float* d_W, int ld
 
 int egnn_gemm_rows_bf16(void* stream, int E, const void* d_A0, int lda0, int K0, const void* d_W0, const void* d_A1, int lda1, int K1,
                         const void* d_W1, void* d_out, int ldo, int out_f32) {
-  if (E < 1 || !d_A0 || !d_W0 || !d_out || K0 < 64 || K0 % 64 != 0 || lda0 < K0 || lda0 % 8 != 0 || ldo < 128 || ldo % 4 != 0 ||
-      (d_A1 && (!d_W1 || K1 < 64 || K1 % 64 != 0 || lda1 < K1 || lda1 % 8 != 0))) {
-    set_error("egnn_gemm_rows_bf16: unsupported shape E=%d K0=%d K1=%d", E, K0, K1);
-    return EGNN_EINVAL;
-  }
-  if ((size_t)E * lda0 * 2 >= ((size_t)1 << 32) || (d_A1 && (size_t)E * lda1 * 2 >= ((size_t)1 << 32))) {
-    set_error("egnn_gemm_rows_bf16: operand larger than 4 GiB (cut the rows into chunks)");
-    return EGNN_EINVAL;
+  {
+    const int rc = gemm_rows_args_check(E, d_A0, lda0, K0, d_W0, d_A1, lda1, K1, d_W1, d_out, ldo);   // host_logic.cpp
+    if (rc) return rc;
   }
   GemmRowsParams p;
   p.A[0] = d_A0; p.lda[0] = lda0; p.K[0] = K0; p.W[0] = d_W0;

@@ -37,6 +37,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4v;
 
 constexpr int kTG = 512, kBM = 256, kBK = 32;
+static_assert(kBM == kGemmBM && kBK == kGemmBK, "host_logic.cpp plans the slices for this tile");
 
 // buffer_load_dwordx4 ... lds: 64 lanes x 16 bytes from per-lane offsets `voff` of the buffer to LDS at `dst` + 16 * lane
 // (dst wave-uniform).  A plain (non-template) device function: inside the kernel TEMPLATE the builtin makes the host pass
@@ -208,18 +209,6 @@ __global__ void gemm_tn_reduce_kernel(const float* __restrict__ slabs, int S, in
   *o = (accumulate ? *o : 0.f) + scale * v;
 }
 
-void plan(int E, int M, int N, int& BN, int& tiles_n, int& S, int& steps_per_slice) {
-  BN = (N % 256 == 0) ? 256 : 128;
-  tiles_n = N / BN;
-  const int ntiles = (M / kBM) * tiles_n;
-  const int total_steps = (E + kBK - 1) / kBK;
-  int want = (768 + ntiles - 1) / ntiles;                    // ~3 workgroups per CU in all
-  const int max_s = total_steps / 16 > 0 ? total_steps / 16 : 1;   // at least 16 steps per slice
-  S = want < 1 ? 1 : (want > max_s ? max_s : want);
-  steps_per_slice = (total_steps + S - 1) / S;
-  S = (total_steps + steps_per_slice - 1) / steps_per_slice;
-}
-
 }  // namespace
 
 int init_gemm_tn_attributes() {
@@ -238,7 +227,6 @@ int launch_gemm_tn(const GemmTnParams& p, int BN, int rows, int cols, float scal
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }
-void plan_gemm_tn(int E, int M, int N, int& BN, int& tiles_n, int& S, int& sps) { plan(E, M, N, BN, tiles_n, S, sps); }
 
 }  // namespace egnn
 
@@ -246,34 +234,17 @@ using namespace egnn;
 
 extern "C" {
 
-// bytes of fp32 slab workspace egnn_gemm_tn_bf16 needs for this shape (0 = unsupported shape)
-size_t egnn_gemm_tn_workspace_bytes(int E, int M, int N) {
-  if (E < 1 || M < 256 || M % 256 != 0 || N < 128 || N % 128 != 0) return 0;
-  int BN, tiles_n, S, sps;
-  plan_gemm_tn(E, M, N, BN, tiles_n, S, sps);
-  return (size_t)S * M * N * sizeof(float);
-}
-
 int egnn_gemm_tn_bf16(void* stream, int E, int M, int N, const void* d_A, int lda, const void* d_B, int ldb, float scale,
                       float* d_C, int ldc, int rows, int cols, int accumulate, void* d_workspace, size_t workspace_bytes) {
-  if (E < 1 || M < 256 || M % 256 != 0 || N < 128 || N % 128 != 0 || lda < M || ldb < N || lda % 8 != 0 || ldb % 8 != 0 ||
-      !d_A || !d_B || !d_C || rows < 1 || rows > M || cols < 1 || cols > N || ldc < cols) {
-    set_error("egnn_gemm_tn_bf16: unsupported shape E=%d M=%d N=%d lda=%d ldb=%d", E, M, N, lda, ldb);
-    return EGNN_EINVAL;
-  }
-  if ((size_t)E * lda * 2 >= ((size_t)1 << 32) || (size_t)E * ldb * 2 >= ((size_t)1 << 32)) {
-    set_error("egnn_gemm_tn_bf16: operand larger than 4 GiB (cut the reduction into chunks)");
-    return EGNN_EINVAL;
+  {   // shape / pointer / 4 GiB-offset / workspace checks and the split-K plan: host_logic.cpp
+    const int rc = gemm_tn_args_check(E, M, N, d_A, lda, d_B, ldb, d_C, ldc, rows, cols, d_workspace, workspace_bytes);
+    if (rc) return rc;
   }
   static bool attr_done = false;
   if (!attr_done) { int rc = init_gemm_tn_attributes(); if (rc) return rc; attr_done = true; }
   GemmTnParams p;
   int BN;
   plan_gemm_tn(E, M, N, BN, p.tiles_n, p.nslices, p.steps_per_slice);
-  if (!d_workspace || workspace_bytes < (size_t)p.nslices * M * N * sizeof(float)) {
-    set_error("egnn_gemm_tn_bf16: workspace too small (%zu bytes, see egnn_gemm_tn_workspace_bytes)", workspace_bytes);
-    return EGNN_EINVAL;
-  }
   p.A = d_A; p.B = d_B; p.lda = lda; p.ldb = ldb; p.E = E; p.M = M; p.N = N;
   p.slabs = static_cast<float*>(d_workspace);
   return launch_gemm_tn(p, BN, rows, cols, scale, d_C, ldc, accumulate, reinterpret_cast<hipStream_t>(stream));

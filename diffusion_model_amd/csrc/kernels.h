@@ -45,7 +45,7 @@ struct EdgeParams {
   float *agg_m, *agg_x, *part_m, *part_x;
   size_t agg_x_stride, part_x_stride;  // elements between the column-split copies of agg_x / part_x
   unsigned long long* stamps;  // diagnostic builds only (EGNN_EXP_STAMP): s_memtime stamps of one workgroup
-  int dbg;  // timing experiments only (EGNN_DEBUG): bit0 drop weight loads, bit1 drop table loads
+  int dbg;  // diagnostic builds only (diag.h, EGNN_DEBUG): bit0 drop weight loads, bit1 drop table loads; 0 and ignored otherwise
   // ---- backward recompute variants only (BWD = true instantiations; edges = a chunk [0, E) of the caller's edge list) ----
   const float* g_sum_x;   // [N][3]  dL/d(sum_x), already multiplied by 1/(G+1)
   const float* g_sum_m;   // [N][MP] dL/d(sum_m)
@@ -286,7 +286,6 @@ __device__ __forceinline__ void store_block_bf16(const f32x16 (&v)[2], int ncb, 
   __builtin_amdgcn_wave_barrier();
 }
 
-constexpr int kPostMaxOB = 8;  // output column blocks of node_post (H <= 256)
 // node_post arguments (fp32 and bf16 variants)
 struct PostParams {
   int N, H, MP, K1P, WhP, HP, R;

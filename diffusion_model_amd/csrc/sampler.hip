@@ -436,59 +436,7 @@ int ddpm_sampler_final(void* stream, int N, int H, int A, int B, int T, const in
   return EGNN_OK;
 }
 
-// ---- schedule (host, fp32, same operation order as torch on CPU) ----------------------------------
-int schedule_table_from_alpha(int T, const float* alpha, const float* sigma, float* table) {
-  if (T < 1 || !alpha || !table) { set_error("bad schedule arguments"); return EGNN_EINVAL; }
-  (void)sigma;
-  for (int t = 1; t <= T; ++t) {
-    // calculate_mu / reverse_diffuse_one_step, diffusion_x_h.py:61-90 (fp32 scalar arithmetic)
-    const float at = alpha[t], as = alpha[t - 1];
-    const float sq_t = 1.0f - at * at, sq_s = 1.0f - as * as;
-    const float ats = at / as;
-    const float sq_ts = sq_t - (ats * ats) * sq_s;
-    const float sig_t = sqrtf(sq_t);
-    table[4 * t + 0] = 1.0f / ats;
-    table[4 * t + 1] = sq_ts / ats / sig_t;
-    table[4 * t + 2] = sqrtf(sq_ts * sq_s / sq_t);
-    table[4 * t + 3] = (float)t / (float)T;
-  }
-  const float a0 = alpha[0], s0 = sigma ? sigma[0] : sqrtf(1.0f - a0 * a0);
-  table[0] = 1.0f / a0; table[1] = s0 / a0; table[2] = s0 / a0; table[3] = 0.f;
-  return EGNN_OK;
-}
-
-int schedule_table_build(int T, double s, double power, float* alpha, float* sigma, float* table) {
-  if (T < 1) { set_error("T must be >= 1"); return EGNN_EINVAL; }
-  std::vector<float> a(T + 1), sg(T + 1);
-  // polynomial_schedule (:99-106): x = linspace(0,T,T+1); a2 = (1 - (x/T)^p)^2
-  // clip_noise_schedule (:92-97): ratios to the previous entry (first vs 1), clamp [0.001, 1], cumprod.
-  // Python scalars enter torch's fp32 tensor arithmetic rounded to fp32: (1 - 2*s) and s are formed in
-  // double first; torch.pow with exponent 2 / 3 is evaluated as x*x / x*x*x.
-  const float prec = (float)(1.0 - 2.0 * s), sf = (float)s, pw = (float)power;
-  // torch.cumprod on CPU accumulates fp32 inputs in double and rounds each output to fp32
-  float prev = 1.0f;
-  double cum = 1.0;
-  for (int i = 0; i <= T; ++i) {
-    const float q = (float)i / (float)T;  // linspace(0, T, T+1) is exact for integer endpoints
-    float qp;
-    if (power == 2.0) qp = q * q;
-    else if (power == 3.0) qp = q * q * q;
-    else if (power == 1.0) qp = q;
-    else qp = powf(q, pw);
-    const float base = 1.0f - qp;
-    const float a2 = base * base;
-    float step = a2 / prev;
-    step = fminf(fmaxf(step, 0.001f), 1.0f);
-    cum = (i == 0) ? (double)step : cum * (double)step;
-    prev = a2;
-    a[i] = prec * (float)cum + sf;
-    sg[i] = sqrtf(1.0f - a[i] * a[i]);
-  }
-  if (alpha) memcpy(alpha, a.data(), sizeof(float) * (T + 1));
-  if (sigma) memcpy(sigma, sg.data(), sizeof(float) * (T + 1));
-  if (table) return schedule_table_from_alpha(T, a.data(), sg.data(), table);
-  return EGNN_OK;
-}
+// (schedule_table_build / schedule_table_from_alpha: host_logic.cpp)
 
 // ---- sampler --------------------------------------------------------------------------------------
 int egnn_sampler_prepare(egnn_ctx* c, int T, int A, float onehot_scale, const float* d_table, const float* d_cond,

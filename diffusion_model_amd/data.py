@@ -238,11 +238,13 @@ class GraphLoader:
         self.epoch = int(epoch)
 
     def _order(self, n: int):
+        """the permutation of the CURRENT epoch: a pure function of (seed, epoch).  The epoch advances only when a pass
+        has been iterated to its end (`__iter__`), or by `set_epoch`: a peek (`next(iter(loader))`), an aborted pass or an
+        extra pass on one rank alone no longer moves that rank to another permutation than its peers'."""
         if not self.shuffle:
             return list(range(n))
         if self.seed is not None:
             g = torch.Generator().manual_seed(int(self.seed) * 1000003 + self.epoch)
-            self.epoch += 1
             return torch.randperm(n, generator=g).tolist()
         return torch.randperm(n, generator=self.generator).tolist()
 
@@ -260,6 +262,7 @@ class GraphLoader:
         nb = self._num_global_batches()
         if nb == 0:
             return
+        epoch_at_start = self.epoch
         steps = (nb + self.world_size - 1) // self.world_size
         dev = torch.device(self.device) if self.device is not None else None
         on_gpu = dev is not None and dev.type == "cuda"
@@ -274,6 +277,8 @@ class GraphLoader:
             recs = [self.dataset[i] for i in idx]
             if not on_gpu:
                 yield collate(recs, device=self.device)
+                if s == steps - 1 and self.shuffle and self.seed is not None and self.epoch == epoch_at_start:
+                    self.epoch += 1   # a COMPLETED pass (see _order)
                 continue
             with torch.cuda.stream(self._copy_stream):
                 batch = collate(recs, device=dev)
@@ -287,6 +292,8 @@ class GraphLoader:
                     v.record_stream(cur)
             plan_record_stream(plan, cur)
             yield batch
+        if on_gpu and self.shuffle and self.seed is not None and self.epoch == epoch_at_start:
+            self.epoch += 1   # a COMPLETED pass: the next one draws the next permutation (see _order)
 
 
 # ---- flat on-disk format ---------------------------------------------------------------------------------------------

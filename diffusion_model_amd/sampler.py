@@ -210,7 +210,12 @@ def generate(nn_dict, test_data, params, diffusion_process, gen_num_per_spectrum
                                     seed=base_seed * 1000003 + first * 1009 + attempt, norm_scope="graph", device=device)
                 attempt += 1
                 pos, hc, onehot, bad = smp.sample(use_graph=use_graph)
-                bad = bad.cpu()
+                # the reference's "> 1000 Angstrom" rejection (:425) for every graph of the batch in ONE device reduction and
+                # one download, next to the non-finite flags (was: one host sync per accepted graph)
+                gid = torch.repeat_interleave(torch.arange(len(sizes), device=pos.device), torch.tensor(sizes, device=pos.device))
+                far = torch.zeros(len(sizes), dtype=torch.int32, device=pos.device)
+                far.index_put_((gid,), (pos > 1000).any(dim=1).to(torch.int32), accumulate=True)
+                bad, far = (t.cpu() for t in (bad, far))
                 lo = 0
                 for g, idx in enumerate(owner):
                     n_atoms = sizes[g]
@@ -221,7 +226,7 @@ def generate(nn_dict, test_data, params, diffusion_process, gen_num_per_spectrum
                         if n_nan[idx] >= 10:
                             raise RuntimeError("too much nan was generated")
                         continue
-                    if bool((pos[sl] > 1000).any()):
+                    if int(far[g]) != 0:
                         continue
                     data = test_data[idx]
                     graph = SimpleNamespace(x=onehot[sl].clone(), pos=pos[sl].clone(), h=hc[sl].clone(),

@@ -55,7 +55,11 @@ class GammaNetwork(nn.Module):
         return out[:n].view(n, 1), out[n], out[n + 1]
 
     def forward(self, t):
-        if t.is_cuda and t.dim() == 2 and t.shape[1] == 1 and self.l2.weight.is_cuda:
+        # the library kernel evaluates gamma_tilde without a graph: only when no gradient with respect to t is asked for
+        # (the reference detaches the softplus weights, SNR.py:21, but gamma(t) stays differentiable in t).  The kernel's
+        # and the torch path's fp32 sums differ by up to ~5e-4 on gamma (as the reference itself does across thread counts,
+        # DESIGN.md section 2): tabulate the training and the sampling schedule on the SAME device.
+        if t.is_cuda and t.dim() == 2 and t.shape[1] == 1 and self.l2.weight.is_cuda and not (t.requires_grad and torch.is_grad_enabled()):
             gt, g0, g1 = self._gamma_tilde_device(t)
         else:
             g0 = self.gamma_tilde(torch.zeros_like(t))

@@ -24,6 +24,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libegnn_amd.so is built with -fvisibility=hidden: exactly the functions declared below are exported */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 typedef struct egnn_ctx egnn_ctx;
 
@@ -339,6 +343,9 @@ int egnn_debug_stamps(egnn_ctx* ctx, unsigned long long* host_out);
 int egnn_profile_enable(egnn_ctx* ctx, int enable);
 int egnn_profile_read(egnn_ctx* ctx, float* edge_ms_avg, int* edge_launches, float* node_ms_avg);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

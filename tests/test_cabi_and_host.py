@@ -36,6 +36,15 @@ def test_library_exports_every_header_symbol():
     assert _lib.lib().egnn_version() >= 1
 
 
+def test_library_exports_nothing_but_the_header():
+    """-fvisibility=hidden + the header's visibility push(default): the dynamic FUNCTION symbols of libegnn_amd.so are exactly
+    the functions include/egnn_amd.h declares (no helper, no C++ runtime template, no debug entry leaks out)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(l.split()[2] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] in ("T", "t", "W", "i"))
+    assert exported == _header_functions(), sorted(set(exported) ^ set(_header_functions()))
+
+
 def test_schedule_host_routine_matches_reference_tables():
     for tag in ("T1000", "T50", "T200"):
         T, p, s = G_DIFF[f"{tag}.params"]

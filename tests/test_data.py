@@ -192,8 +192,18 @@ def test_shuffled_multi_rank_loader_draws_one_permutation():
     a = [list(b.id) for b in dma.GraphLoader(recs, batch_size=2, shuffle=True, seed=7)]
     ld = dma.GraphLoader(recs, batch_size=2, shuffle=True, seed=7)
     first = [list(b.id) for b in ld]
-    second = [list(b.id) for b in ld]                # the epoch advances by itself
+    second = [list(b.id) for b in ld]                # the epoch advances after a COMPLETED pass
     assert first == a and second != first
+    # a peek or an aborted pass on one rank must not move it to another permutation than its peers'
+    peer = dma.GraphLoader(recs, batch_size=2, shuffle=True, seed=7)
+    ld = dma.GraphLoader(recs, batch_size=2, shuffle=True, seed=7)
+    next(iter(ld))                                   # a peek
+    it = iter(ld)
+    next(it); next(it)                               # an aborted pass
+    del it
+    assert ld.epoch == 0 and [list(b.id) for b in ld] == [list(b.id) for b in peer]
+    assert ld.epoch == 1 and peer.epoch == 1
+    assert [list(b.id) for b in ld] == [list(b.id) for b in peer] == second
 
 
 def test_batch_copy_does_not_carry_a_plan_of_another_device():

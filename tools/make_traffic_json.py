@@ -35,7 +35,12 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recurs
             avg_ns[k] = float(r["AverageNs"])
 fetch, write, sq = pmc("pmc_fetch"), pmc("pmc_write"), pmc("pmc_sq")
 kernels = sorted(avg_ns)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from diffusion_model_amd import _lib  # noqa: E402  (no GPU call: only the source fingerprint and the library path)
+import hashlib  # noqa: E402
 doc = {"comment": __doc__.split("usage")[0].strip(), "git_head": head, "source": os.path.basename(out.rstrip("/")),
+       "edge_kernel_sources_sha256": _lib.edge_kernel_sources_sha256(),
+       "library_sha256_on_the_profiled_box": hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest(),
        "workload": "256 graphs x 64 atoms, bf16, default path", "kernels": {}}
 total = 0.0
 for k in kernels:
