@@ -37,7 +37,10 @@ def _net(precision):
 
 # bf16: MFMA operands of the edge and node MLPs rounded to 8 significant bits in each of the 51 chained evaluations; the
 # trained denoiser contracts perturbations, so the final structure stays close: 3e-2 relative on positions and continuous types (measured 9.5e-3, no type flips)
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 3e-2)])
+# bf16x3: head + remainder operands (width 256 runs the split-operand kernels too): 1e-3 as fp32.  fp16: at this width the fp16
+# path falls to the exact fp32 kernels (include/egnn_amd.h EGNN_PREC_F16) -- the full-width fp16 chain is covered by
+# test_full_width_chain_statistics_against_fp32 below.
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16x3", 1e-3), ("fp16", 1e-3), ("bf16", 3e-2)])
 def test_full_chain_same_noise_matches_oracle(precision, tol):
     net, sd, A, T, proc = _net(precision)
     ref = SU.oracle_process()
@@ -67,7 +70,7 @@ def test_full_chain_same_noise_matches_oracle(precision, tol):
         flips += int((onehot[sl].cpu() != oh_ref).any(dim=1).sum())
     print(f"full chain {precision}: worst relative error {worst:.2e}, type flips {flips} of {sum(sizes)}")
     assert worst <= tol
-    assert flips == 0 if precision == "fp32" else flips <= 1
+    assert flips == 0 if precision != "bf16" else flips <= 1
 
 
 @pytest.fixture(scope="module")
@@ -87,7 +90,7 @@ def oracle_batches():
     return out
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16"])
 def test_sampled_structure_statistics_match_oracle(precision, oracle_batches):
     net, sd, A, T, proc = _net(precision)
     for n in (3, 9):

@@ -108,8 +108,10 @@ def test_gradients_match_oracle_autograd(norm_scope, widths, monkeypatch):
 @pytest.mark.gpu
 def test_gradients_full_width_64_atom_graphs():
     """BASELINE configs[3] shape per graph: 64-atom fully connected graphs at the reference widths (W = 1024, m = 256,
-    H = 36), three graphs = 12,096 edges in backward chunks of 5,000 (so a layer spans several chunks): fp32 gradients
-    against the oracle's autograd at 2e-3, bf16-mode gradients against the fp32 ones at 8e-2."""
+    H = 36), three graphs = 12,096 edges in backward chunks of 5,000 (so a layer spans several chunks).  EVERY precision
+    against the ORACLE's autograd (no self-comparison): fp32 and bf16x3 (whose backward is the fp32 chain) at 2e-3; bf16
+    (bf16 MFMA forward, saved bf16 activations / bf16 dgrad + wgrad operands) and fp16 (fp16 forward, bf16 backward kernels)
+    at the tolerance below, set from the printed measurement (profiles/r04d_gpu_tests.log)."""
     from diffusion_model_amd import autograd as _ag
     H, A, T = 36, 2, 50
     d = dims_for(H, 256, 1024, 1024, 1024)
@@ -130,7 +132,7 @@ def test_gradients_full_width_64_atom_graphs():
     old_chunk = _ag.EDGE_CHUNK
     _ag.EDGE_CHUNK = 5000
     try:
-        for prec in ("fp32", "bf16"):
+        for prec in ("fp32", "bf16x3", "bf16", "fp16"):
             m = dma.EquivariantGNN(2, **d)
             m.load_state_dict({k: v.detach() for k, v in sd.items()})
             m.to(dev).train()
@@ -140,14 +142,19 @@ def test_gradients_full_width_64_atom_graphs():
             loss, ex, eh = dma.training_loss(m, ei.to(dev), batch.to(dev), noised, cond.to(dev), A, num_graphs=3)
             loss.backward()
             grads[prec] = {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
-            if prec == "fp32":
+            if prec in ("fp32", "bf16x3"):
                 assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 1e-4 * abs(float(loss_ref.detach()))
                 assert rel_err(ex.detach().cpu(), ex_ref.detach()) <= 1e-4 and rel_err(eh.detach().cpu(), eh_ref.detach()) <= 1e-4
     finally:
         _ag.EDGE_CHUNK = old_chunk
-    for k in grads["fp32"]:
-        assert rel_err(grads["fp32"][k], sd[k].grad) <= 2e-3, k
-        assert rel_err(grads["bf16"][k], grads["fp32"][k]) <= 8e-2, k
+    # measured (profiles/r04d_gpu_tests.log): fp32 5.8e-6, bf16x3 2.1e-5, bf16 6.5e-3, fp16 4.2e-3 (worst parameter tensor)
+    GRAD_TOL = {"fp32": 2e-3, "bf16x3": 2e-3, "bf16": 2e-2, "fp16": 2e-2}
+    for prec, gr in grads.items():
+        errs = {k: rel_err(gr[k], sd[k].grad) for k in gr}
+        worst = max(errs, key=errs.get)
+        print(f"gradients vs oracle autograd, W = 1024, {prec}: worst {errs[worst]:.2e} ({worst}), median {sorted(errs.values())[len(errs) // 2]:.2e}")
+        for k, e in errs.items():
+            assert e <= GRAD_TOL[prec], (prec, k, e)
 
 
 @pytest.mark.gpu
@@ -356,25 +363,36 @@ def test_partitioned_exchange_world_size_2_gloo(tmp_path):
 
 
 @pytest.mark.gpu
-def test_bf16_training_gradients_close_to_fp32():
-    """bf16 mode: HIP bf16 forward + bf16-autocast recompute backward; gradients within bf16 accuracy of fp32."""
+def test_half_precision_training_gradients_against_oracle():
+    """Width 256 (the generic backward chain of csrc/backward.hip with bf16 stage buffers around library GEMMs): bf16 and fp16
+    gradients against the ORACLE's autograd, tolerance from the printed measurement."""
     H, A, T = 36, 2, 50
     d = dims_for(H, 128, 256, 256, 256)
     pos0, x0, cond, batch, ei, npos, nh, times = _problem()
+    torch.manual_seed(5)
+    net0 = dma.EquivariantGNN(2, **d)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in net0.state_dict().items()}
+    ref = DiffusionRef(1e-5, 2.0, T)
+    loss_ref, *_ = oracle_training_loss(sd, ref, pos0, x0, cond, ei, batch, times, npos.clone(), nh.clone(), atom_type_size=A,
+                                        norm_scope="graph", graph_ptr=torch.tensor([0, 6, 10, 17]))
+    loss_ref.backward()
     dev = "cuda"
     proc = dma.E3DiffusionProcess(1e-5, 2.0, T)
-    grads = {}
-    for prec in ("fp32", "bf16"):
-        torch.manual_seed(5)
-        net = dma.EquivariantGNN(2, **d).to(dev).train()
+    for prec, tol in (("bf16", 2.5e-2), ("fp16", 2.5e-2)):   # measured 7.7e-3 / 4.3e-3 (profiles/r04d_gpu_tests.log)
+        net = dma.EquivariantGNN(2, **d)
+        net.load_state_dict({k: v.detach() for k, v in sd.items()})
+        net.to(dev).train()
         net.precision, net.norm_scope = prec, "graph"
         noised = dma.diffuse_as_batch(pos0.to(dev), x0.to(dev), batch.to(dev), proc, times=times,
                                       noise_pos=npos.to(dev), noise_h=nh.to(dev))
         loss, _, _ = dma.training_loss(net, ei.to(dev), batch.to(dev), noised, cond.to(dev), A)
         loss.backward()
-        grads[prec] = {k: p.grad.detach().cpu() for k, p in net.named_parameters()}
-    for k in grads["fp32"]:
-        assert rel_err(grads["bf16"][k], grads["fp32"][k]) <= 8e-2, k
+        errs = {k: rel_err(p.grad.detach().cpu(), sd[k].grad) for k, p in net.named_parameters()}
+        worst = max(errs, key=errs.get)
+        print(f"gradients vs oracle autograd, W = 256, {prec}: loss {float(loss):.6f} (oracle {float(loss_ref):.6f}), worst {errs[worst]:.2e} ({worst})")
+        assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 2e-2 * abs(float(loss_ref.detach()))
+        for k, e in errs.items():
+            assert e <= tol, (prec, k, e)
 
 
 @pytest.mark.gpu
