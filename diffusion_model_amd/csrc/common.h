@@ -52,6 +52,7 @@ struct LayerPack {
   void* w2x_bf16s_lo = nullptr;   // bf16 remainders of the scaled second-layer weights (precision bf16x3)
   void* w2m_bf16s_lo = nullptr;
   void* w2x_bf16s16 = nullptr;  // mlp_x.2 scaled, as v_mfma_f32_16x16x32_bf16 B fragments [N/16][K/32][64][8]
+  void* w2m_bf16s16 = nullptr;  // mlp_m.2 scaled, same 16-column layout (edge_small.hip)
   void* w2xT_bf16 = nullptr;  // mlp_x.2 TRANSPOSED bf16 fragments for the backward dgrad (k = output n, column = hidden k)
   void* w2mT_bf16 = nullptr;  // mlp_m.2 transposed (K = MP, N = WmP)
   void* w1hl_bf16 = nullptr;  // scaled first layers as bf16 hi/lo B fragments [TC/32][3][hi|lo][64][8] (node_pre_hilo_kernel)
@@ -60,6 +61,7 @@ struct LayerPack {
   // precision fp16: the streams of the bf16 path as fp16 fragments, every one multiplied by kF16WScale = 2^8 (kernels.h)
   void* w2x_f16s16 = nullptr;  // mlp_x.2 scaled, v_mfma_f32_16x16x32_f16 B fragments
   void* w2m_f16s = nullptr;    // mlp_m.2 scaled, v_mfma_f32_32x32x16_f16 B fragments
+  void* w2m_f16s16 = nullptr;  // mlp_m.2 scaled, v_mfma_f32_16x16x32_f16 B fragments (edge_small.hip)
   void* w1h_f16 = nullptr;     // mlp_h.0
   void* w2h_f16p = nullptr;    // mlp_h.2, k in accumulator-row order
   // split-operand node MLP (node_post_bf16_kernel<., f16x8, true>): mlp_h.0 head / remainder with K padded to its ring's two
@@ -111,6 +113,7 @@ struct egnn_ctx {
   float* gscale = nullptr;   // [B] sum of d^2 per graph (G^2); node_post applies 1/(G+1)
   int last_R = 64, last_nsplit_x = 1, last_path = 1;   // edge path chosen by the last launch_layer_begin
   bool sq_from_agg = false;             // node_post takes the d^2 sums from the coordinate sums' component 3
+  bool small_ok = false;                // the partial slots were sized for 32-edge tiles (E <= 65536): edge_small.hip may run
   float* h_partial = nullptr;  // [8][N][H] partial node-MLP outputs (hidden-split node_post at small N)
   float* bwd_s = nullptr;    // [nsplit][chunk edges] column-split shares of s_e (backward recompute)
   size_t cap_bwd_s = 0;

@@ -905,7 +905,9 @@ static int dev_alloc(T** p, size_t count) {
 int reserve(egnn_ctx* c) {
   if (c->L == 0 || c->N == 0) { set_error("model and graph must be set first"); return EGNN_ESTATE; }
   const int R = edge_rows_per_tile(0);
-  const size_t tiles = (size_t)(c->E + R - 1) / R;
+  // partial slots per tile: 64-row tiles are the smallest, except for small graphs, which may run on 32-row tiles
+  c->small_ok = c->E <= (1 << 16);
+  const size_t tiles = c->small_ok ? (size_t)(c->E + 31) / 32 : (size_t)(c->E + R - 1) / R;
   int rc = EGNN_OK;
   if ((size_t)c->N > c->cap_nodes) {
     const size_t n = c->N;
@@ -1009,6 +1011,17 @@ static int launch_edge(const EdgeParams& p, int tiles, size_t smem, hipStream_t 
   return EGNN_OK;
 }
 
+// 32-edge tiles (edge_small.hip) for graphs of up to ~2 k edges (a 20-40-atom molecule, the toy graphs of configs[0]): measured
+// (profiles/r04e_latency_small_tiles.log, hipGraph replay, ms per reverse step) 20-atom cell 0.289 -> 0.277, 4 x 2-atom graphs
+// 0.258 -> 0.223; but one 64-atom cell (4,032 edges) 0.313 -> 0.343 and five 0.41 -> 0.70: a layer's weight traffic through L2
+// is (E / tile rows) x 2.5 MB whatever the column split, 315 MB at 32 rows for ONE 64-atom graph, and the chip's L2 delivers
+// ~7 TB/s to 256 streaming CUs, not the 34 TB/s of 64 B/clk/CU -- 128-row tiles are within 3x of that floor already.
+// EGNN_SMALL_EDGES overrides the edge-count limit (0 = never): measurement switch.
+static bool small_tiles(const egnn_ctx* c, const EdgeParams& p) {
+  static const long limit = getenv("EGNN_SMALL_EDGES") ? atol(getenv("EGNN_SMALL_EDGES")) : 2048;
+  return c->E > 0 && (long)c->E <= limit && c->small_ok && edge_small_supported(p);
+}
+
 // EdgeParams of layer `layer` over the graph set on the context (unscaled parameter vectors, fp32 / bf16 fragments)
 static void fill_edge_params(egnn_ctx* c, int layer, int prec, const float* x, EdgeParams& p) {
   const LayerPack& lp = c->layers[layer];
@@ -1042,7 +1055,7 @@ static void use_scaled_pack(egnn_ctx* c, int layer, EdgeParams& p, const float*&
   p.b2m = o; o += c->MP;
   p.wa = o;
   p.w2x = lp.w2x_bf16s; p.w2m = lp.w2m_bf16s;
-  p.w2x16 = lp.w2x_bf16s16;
+  p.w2x16 = lp.w2x_bf16s16; p.w2m16 = lp.w2m_bf16s16;
   p.w2x_lo = lp.w2x_bf16s_lo; p.w2m_lo = lp.w2m_bf16s_lo;
 }
 // first-layer table of the v3 / v4 kernels (fp16, pre-scaled) for node features h
@@ -1214,6 +1227,25 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
       R = 128;
       nsplit_x = p.WxP / 256;
       rc = launch_edge_bf16x3(p, st);
+    } else if ((path == 6 || path == 4) && !c->save_s1x && small_tiles(c, p)) {
+      // small graphs (the reference's per-call workload): 32-edge tiles, weight-stream-bound workgroups (edge_small.hip);
+      // coordinate and message kernel side by side when the caller gave a side stream
+      const bool f16 = path == 6;
+      R = edge_small_rows();
+      nsplit_x = p.WxP / 512;
+      if (f16) { p.w2x16 = lp.w2x_f16s16; p.w2m16 = lp.w2m_f16s16; }
+      const bool fork = !c->prof && st != nullptr && c->side != nullptr && c->ev_fork != nullptr;
+      if (fork) {
+        EGNN_HIP(hipEventRecord(c->ev_fork, st));
+        EGNN_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+        rc = launch_edge_small_x(p, st, f16);
+        if (!rc) rc = launch_edge_small_m(p, c->side, f16);
+        EGNN_HIP(hipEventRecord(c->ev_join, c->side));
+        EGNN_HIP(hipStreamWaitEvent(st, c->ev_join, 0));
+      } else {
+        rc = launch_edge_small_x(p, st, f16);
+        if (!rc) rc = launch_edge_small_m(p, st, f16);
+      }
     } else if (path == 6) {   // precision fp16: the path-4 kernels on fp16 operands (same tiles, same launch structure)
       R = edge_v4_rows();
       nsplit_x = p.WxP / 512;
@@ -1367,7 +1399,8 @@ static void free_layer(LayerPack& lp) {
   void* ptrs[] = {lp.w1catT, lp.b1cat, lp.wdx, lp.wdm, lp.w2x_f32, lp.w2x_bf16, lp.b2x, lp.w3x, lp.w2m_f32,
                   lp.w2m_bf16, lp.b2m, lp.wa, lp.scal, lp.w1h_f32, lp.b1h, lp.w2h_f32, lp.b2h, lp.sc, lp.w2x_bf16s, lp.w2m_bf16s, lp.w1h_bf16, lp.w2h_bf16p,
                   lp.w2xT_bf16, lp.w2mT_bf16, lp.w1hl_bf16, lp.w2x_bf16s16, lp.w2x_bf16s_lo, lp.w2m_bf16s_lo,
-                  lp.w2x_f16s16, lp.w2m_f16s, lp.w1h_f16, lp.w2h_f16p, lp.w1h_f16k, lp.w1h_f16k_lo, lp.w2h_f16p_lo};
+                  lp.w2x_f16s16, lp.w2m_f16s, lp.w1h_f16, lp.w2h_f16p, lp.w1h_f16k, lp.w1h_f16k_lo, lp.w2h_f16p_lo,
+                  lp.w2m_bf16s16, lp.w2m_f16s16};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   lp = LayerPack();
@@ -1471,6 +1504,10 @@ int egnn_pack_layer(egnn_ctx* c, void* stream, int l, const float* m0_w, const f
     lp.w2mT_bf16 = tmp; tmp = nullptr;
     if ((rc = dev_alloc(&tmp, (size_t)(TC / 32) * 3 * 2 * 512))) return rc;
     lp.w1hl_bf16 = tmp; tmp = nullptr;
+    if ((rc = dev_alloc(&tmp, (size_t)MP * WmP))) return rc;
+    lp.w2m_bf16s16 = tmp; tmp = nullptr;
+    if ((rc = dev_alloc(&tmp, (size_t)MP * WmP))) return rc;
+    lp.w2m_f16s16 = tmp; tmp = nullptr;
     if ((rc = dev_alloc(&tmp, (size_t)WxP * WxP))) return rc;      // fp16 streams: same sizes as their bf16 twins
     lp.w2x_f16s16 = tmp; tmp = nullptr;
     if ((rc = dev_alloc(&tmp, (size_t)MP * WmP))) return rc;
@@ -1521,6 +1558,8 @@ int egnn_pack_layer(egnn_ctx* c, void* stream, int l, const float* m0_w, const f
     hipLaunchKernelGGL(pack_frags_bf16<__bf16>, g, b, 0, st, x2_w, Wx, Wx, Wx, WxP, WxP, reinterpret_cast<__bf16*>(lp.w2x_bf16s), s2);
     hipLaunchKernelGGL(pack_frags_bf16<__bf16>, g, b, 0, st, m2_w, M, Wm, Wm, MP, WmP, reinterpret_cast<__bf16*>(lp.w2m_bf16s), s2);
     hipLaunchKernelGGL(pack_frags_bf16_n16<__bf16>, g, b, 0, st, x2_w, Wx, Wx, Wx, WxP, WxP, reinterpret_cast<__bf16*>(lp.w2x_bf16s16), s2);
+    hipLaunchKernelGGL(pack_frags_bf16_n16<__bf16>, g, b, 0, st, m2_w, M, Wm, Wm, MP, WmP, reinterpret_cast<__bf16*>(lp.w2m_bf16s16), s2);
+    hipLaunchKernelGGL(pack_frags_bf16_n16<_Float16>, g, b, 0, st, m2_w, M, Wm, Wm, MP, WmP, reinterpret_cast<_Float16*>(lp.w2m_f16s16), s2 * kF16WScale);
     // precision fp16: the same streams as fp16 fragments, times 2^8 (kernels.h "MFMA operand type")
     hipLaunchKernelGGL(pack_frags_bf16_n16<_Float16>, g, b, 0, st, x2_w, Wx, Wx, Wx, WxP, WxP, reinterpret_cast<_Float16*>(lp.w2x_f16s16), s2 * kF16WScale);
     hipLaunchKernelGGL(pack_frags_bf16<_Float16>, g, b, 0, st, m2_w, M, Wm, Wm, MP, WmP, reinterpret_cast<_Float16*>(lp.w2m_f16s), s2 * kF16WScale);

@@ -42,6 +42,7 @@ struct EdgeParams {
   const void *w2x, *w2m;
   const void *w2x_lo, *w2m_lo;   // bf16 remainders W - bf16(W) of the scaled second-layer weights, same fragment layout (bf16x3)
   const void* w2x16;   // mlp_x.2 as 16x16x32 B fragments (edge_x_m16.hip), scaled; null when not packed
+  const void* w2m16;   // mlp_m.2 as 16x16x32 B fragments (edge_small.hip), scaled; null when not packed
   float *agg_m, *agg_x, *part_m, *part_x;
   size_t agg_x_stride, part_x_stride;  // elements between the column-split copies of agg_x / part_x
   unsigned long long* stamps;  // diagnostic builds only (EGNN_EXP_STAMP): s_memtime stamps of one workgroup
@@ -330,6 +331,11 @@ int launch_edge_x_m16_f16(const EdgeParams& p, hipStream_t st);   // precision f
 int launch_edge_f16_v4_m(const EdgeParams& p, hipStream_t st);    // precision fp16 message kernel (p.w2m = fp16 fragments)
 bool edge_x_m16_supported(const EdgeParams& p);
 int init_edge_x_m16_attributes();
+// 32-edge tiles for small graphs (edge_small.hip): p.w2x16 / p.w2m16 = 16-column fragment streams of the operand type
+int launch_edge_small_x(const EdgeParams& p, hipStream_t st, bool f16);
+int launch_edge_small_m(const EdgeParams& p, hipStream_t st, bool f16);
+bool edge_small_supported(const EdgeParams& p);
+int edge_small_rows();
 int launch_edge_bf16x3(const EdgeParams& p, hipStream_t st);    // precision 'bf16x3': head / remainder split operands
 bool edge_bf16x3_supported(const EdgeParams& p);
 int init_edge_bf16x3_attributes();
