@@ -53,6 +53,8 @@ SIGNATURES = {
     "egcl_backward_l1_grad": (_i, [_vp, _i, _i, _i] + [_vp] * 7),
     "egcl_backward_gather_in": (_i, [_vp, _i, _i, _i, _i] + [_vp] * 6),
     "egcl_backward_scatter": (_i, [_vp, _i, _i, _i, _i] + [_vp] * 9),
+    "egcl_backward_first_reduce": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i] + [_vp] * 9),
+    "egcl_backward_scatter_geom": (_i, [_vp, _i, _i] + [_vp] * 8),
     "egcl_backward_fused_supported": (_i, [_vp]),
     "egcl_backward_table": (_i, [_vp, _vp, _i, _vp]),
     "egcl_backward_edge_recompute": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i] + [_vp] * 11),

@@ -87,7 +87,7 @@ def _wgrad(g, a, n_pad, splits):
     return torch.bmm(gv.transpose(1, 2), av).float().sum(0)
 
 
-def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_S, g_h, g_x, grads, fused=None, kept=None):
+def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_S, g_h, g_x, grads, fused=None, kept=None, plan=None):
     """adds the edge part's contributions to g_h, g_x and to the parameter gradients in `grads`.
     ``fused`` = (context handle, layer index) when the bf16 recompute runs on the forward's own MFMA edge kernels
     (egcl_backward_edge_recompute) instead of l1_act -> GEMM -> heads.
@@ -131,6 +131,22 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_
     g_am, g_ax = g_am.contiguous(), g_ax.contiguous()
     E = dst32.numel()
     rows = ws.rows
+    # First Linear layers factorised as the forward factorises them (csrc/edge_bwd_first.hip): per-node sums of dL/da1 over the
+    # edges a node receives / sends in ONE pass, then node-level products -- instead of gather + 2 wgrad GEMMs over all edges +
+    # the row-streaming dgrad GEMM + the feature half of the scatter.  Batches of graphs of at most 64 nodes (the sender sums of a
+    # graph live in LDS).  OPT-IN (EGNN_BWD_FIRST=1): correct, deterministic and tested against the oracle's autograd, but the
+    # one-pass kernel runs at 2.1 TB/s (a chain of per-node memory latencies) and the step is 62.8 ms with it against 59.5 ms
+    # without (profiles/r04f_first_layer_factorised.txt); the gain it is after needs dL/da1 not to be written at all, i.e. the
+    # same sums inside the dgrad kernel's epilogue.
+    first = (hip and plan is not None and getattr(plan, "max_graph_nodes", 1 << 30) <= 64 and Wx % 256 == 0 and Wm % 256 == 0 and
+             os.environ.get("EGNN_BWD_FIRST", "0") == "1")
+    if first:
+        N, nparts = h.shape[0], (Wx + Wm) // 256
+        Gd_x, Gs_x, Gd_m, Gs_m = (torch.zeros(N, w, **f32) for w in (Wx, Wx, Wm, Wm))
+        cd_x, cd_m = torch.zeros(plan.B, Wx, **f32), torch.zeros(plan.B, Wm, **f32)
+        gd2_part = torch.empty(nparts * min(rows, E), **f32)
+        wdx_f = lin_x0.weight.detach()[:, 2 * H].float().contiguous()
+        wdm_f = lin_m0.weight.detach()[:, 2 * H].float().contiguous()
     if fused is not None:
         _lib.check(L.egcl_backward_table(fused[0], st, fused[1], P(h)))
     for a in range(0, E, rows):
@@ -146,7 +162,8 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_
         if n_pad > n and not hip:   # rows the split library products read beyond the chunk (the own GEMMs stop at row n)
             for t in ((ws.g1x, ws.g1m, ws.inp) if kept is not None else (ws.s1x, ws.s1m, ws.a2x, ws.a2m, ws.g1x, ws.g1m, ws.inp)):
                 t[n:n_pad].zero_()
-        _lib.check(L.egcl_backward_gather_in(st, prec, n, H, K1P, P(d32), P(s32), P(h), P(x), P(inp), P(d2)))
+        if not first:
+            _lib.check(L.egcl_backward_gather_in(st, prec, n, H, K1P, P(d32), P(s32), P(h), P(x), P(inp), P(d2)))
         if kept is not None:
             # dL/da2 in place over the kept pre-activations, g_diff and the bias / w3 / wa column sums: one element-wise pass
             _lib.check(L.egcl_backward_heads_saved(fused[0], st, fused[1], P(x), P(g_ax), P(g_am), a, n, P(a2x), P(a2m),
@@ -181,6 +198,13 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_
             _lib.check(L.egcl_backward_l1_grad(st, prec, n, Wx, P(d32), P(s32), P(Px), P(Qx), P(wdx), P(d2), P(g1x)))
             _lib.check(L.egcl_backward_l1_grad(st, prec, n, Wm, P(d32), P(s32), P(Pm), P(Qm), P(wdm), P(d2), P(g1m)))
         # first Linear layers: wgrad against in = [h_i | h_j | d2 | 1], dgrad back to the gathered inputs
+        if first:
+            _lib.check(L.egcl_backward_first_reduce(st, plan.B, plan.max_graph_nodes, a, n, P(plan.graph_ptr), P(plan.row_ptr),
+                                                    P(src32), P(x), P(g1x), Wx, P(g1m), Wm, P(wdx_f), P(wdm_f), P(Gd_x), P(Gs_x),
+                                                    P(Gd_m), P(Gs_m), P(cd_x), P(cd_m), P(gd2_part)))
+            _lib.check(L.egcl_backward_scatter_geom(st, n, nparts, P(d32), P(s32), P(x), P(gd2_part), P(g_diff), P(g_S),
+                                                    P(node_seg), P(g_x)))
+            continue
         if hip:
             gemm_tn(g1x, inp, cols=2 * H + 2, out=g_w1x, accumulate=True)
             gemm_tn(g1m, inp, cols=2 * H + 2, out=g_w1m, accumulate=True)
@@ -196,6 +220,16 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_
     if fused is not None:   # the recompute kernels store s1 as the MFMA consumed it: -log2(e) * SiLU(a1)
         g_w2x *= -math.log(2.0)
         g_w2m *= -math.log(2.0)
+    if first:   # node-level products of the factorised first layers (N rows; fp32)
+        hf = h.float()
+        for g_w1, Gd, Gs, cd, lin in ((g_w1x, Gd_x, Gs_x, cd_x, lin_x0), (g_w1m, Gd_m, Gs_m, cd_m, lin_m0)):
+            g_w1[:, :H] = Gd.t() @ hf
+            g_w1[:, H:2 * H] = Gs.t() @ hf
+            g_w1[:, 2 * H] = cd.sum(0)
+            g_w1[:, 2 * H + 1] = Gd.sum(0)
+            w1 = lin.weight.detach().float()
+            g_h.addmm_(Gd, w1[:, :H])
+            g_h.addmm_(Gs, w1[:, H:2 * H])
 
     def acc(p, g):
         grads[p] = grads.get(p, 0) + g.reshape(p.shape)
@@ -375,7 +409,7 @@ class _EGNNFunction(torch.autograd.Function):
             if E > 0:
                 _edge_backward(layer, prec, ws, h_l, x_l, dst32, src32, node_seg, g_am, g_ax, g_S.contiguous(), g_h, g_x, grads,
                                fused=(c.handle, l) if use_fused else None,
-                               kept=kept[l] if kept is not None else None)
+                               kept=kept[l] if kept is not None else None, plan=plan)
                 if kept is not None:
                     ctx.kept[l] = None   # this layer's buffers are spent
             gh, gx = g_h, g_x

@@ -72,6 +72,7 @@ class GraphPlan:
             raise ValueError("graphs must be contiguous in the node order (PyG collate order)")
         self.B = int(batch.max().item()) + 1
         cnt = torch.bincount(batch, minlength=self.B)
+        self.max_graph_nodes = int(cnt.max())     # (host value: the constructor synchronises anyway)
         if bool((cnt == 0).any()):
             raise ValueError("batch ids must be consecutive")
         self.graph_ptr = torch.zeros(self.B + 1, dtype=torch.int32, device=dev)
@@ -110,6 +111,7 @@ def _plan_from_sizes(sizes, device):
     plan.batch = torch.repeat_interleave(torch.arange(plan.B), sz).to(dev)
     plan.node_graph = plan.batch.to(torch.int32).contiguous()
     plan._sizes = sz
+    plan.max_graph_nodes = int(sz.max())
     return plan, _lib
 
 

@@ -157,6 +157,25 @@ int egcl_backward_scatter(void* stream, int prec, int n_edges, int H, int K1P, c
                           const int32_t* d_src, const float* d_x, const void* d_g_in, const float* d_g_diff,
                           const float* d_g_sq_sums, const int32_t* d_node_segment, float* d_g_h, float* d_g_x);
 
+/* First Linear layers of both edge MLPs, factorised as the forward factorises them (csrc/edge_bwd_first.hip): ONE pass over
+ * dL/da1 (d_g1x [n_edges, Wx], d_g1m [n_edges, Wm], bf16; the outputs of egcl_backward_dgrad for the edges
+ * [e_first, e_first + n_edges) of the plan) produces, for batches of graphs of at most 64 nodes, the per-node sums
+ * Gd[n] = sum of g1 over the edges n receives, Gs[n] = over the edges n sends ([N, W] fp32, ACCUMULATED: zero them per layer),
+ * cd[graph] = sum_e g1[e] d2_e ([B, W], accumulated) and the (Wx + Wm) / 256 shares of dL/d(d2_e) = g1[e] . W1[:, 2H]
+ * (d_gd2_part [(Wx + Wm) / 256, n_edges], assigned).  The first-layer weight gradients and dL/dh are then node-level products
+ * (dL/dW1[:, :H] = Gd^T h, dL/dW1[:, H:2H] = Gs^T h, dL/dW1[:, 2H] = sum of cd, dL/db1 = sum of Gd, dL/dh += Gd W1[:, :H] +
+ * Gs W1[:, H:2H]) -- replaces egcl_backward_gather_in, two weight-gradient GEMMs over all edges, the row-streaming dgrad GEMM and
+ * the feature half of egcl_backward_scatter (torch autograd over EquivariantGraphNeuralNetwork.py:13-25, :56). */
+int egcl_backward_first_reduce(void* stream, int B, int max_graph_nodes, int e_first, int n_edges, const int32_t* d_graph_ptr,
+                               const int32_t* d_row_ptr, const int32_t* d_edge_src, const float* d_x, const void* d_g1x, int Wx,
+                               const void* d_g1m, int Wm, const float* d_wdx, const float* d_wdm, float* d_Gd_x, float* d_Gs_x,
+                               float* d_Gd_m, float* d_Gs_m, float* d_cd_x, float* d_cd_m, float* d_gd2_part);
+/* The geometry half of egcl_backward_scatter for that path: dL/d(x_i - x_j) = g_diff[e] + 2 (sum of the nparts shares of
+ * dL/d(d2_e) + g_sq_sums[segment of i]) (x_i - x_j), added to g_x[i] and subtracted from g_x[j] (fp32 atomic adds). */
+int egcl_backward_scatter_geom(void* stream, int n_edges, int nparts, const int32_t* d_dst, const int32_t* d_src, const float* d_x,
+                               const float* d_gd2_part, const float* d_g_diff, const float* d_g_sq_sums,
+                               const int32_t* d_node_segment, float* d_g_x);
+
 /* Fused first half of the chain above for the bf16 fast path (reference widths: hidden 256 / 512 / 1024, m = 256, unpadded):
  * one pass of the forward's own MFMA edge kernels in "backward" mode replaces gather/l1_act -> GEMM -> heads.  For the
  * edges [e_first, e_first + n_edges) of the graph set on ctx it recomputes SiLU(P[dst] + Q[src] + wd d2) (fp16 table built

@@ -106,13 +106,17 @@ def test_gradients_match_oracle_autograd(norm_scope, widths, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_gradients_full_width_64_atom_graphs():
+@pytest.mark.parametrize("first_layer", ["chain", "factorised"])
+def test_gradients_full_width_64_atom_graphs(first_layer, monkeypatch):
     """BASELINE configs[3] shape per graph: 64-atom fully connected graphs at the reference widths (W = 1024, m = 256,
     H = 36), three graphs = 12,096 edges in backward chunks of 5,000 (so a layer spans several chunks).  EVERY precision
     against the ORACLE's autograd (no self-comparison): fp32 and bf16x3 (whose backward is the fp32 chain) at 2e-3; bf16
     (bf16 MFMA forward, saved bf16 activations / bf16 dgrad + wgrad operands) and fp16 (fp16 forward, bf16 backward kernels)
     at the tolerance below, set from the printed measurement (profiles/r04d_gpu_tests.log)."""
     from diffusion_model_amd import autograd as _ag
+    # "factorised": the opt-in one-pass first-layer backward (csrc/edge_bwd_first.hip: per-node receive / send sums of dL/da1,
+    # node-level products); the 5,000-edge chunks cut through the graphs, so its accumulation across chunks is exercised too
+    monkeypatch.setenv("EGNN_BWD_FIRST", "1" if first_layer == "factorised" else "0")
     H, A, T = 36, 2, 50
     d = dims_for(H, 256, 1024, 1024, 1024)
     torch.manual_seed(6)
