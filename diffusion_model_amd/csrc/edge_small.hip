@@ -7,8 +7,8 @@
 // instead of by 128 rows of MFMA + SiLU work.  Same arithmetic as the large-tile kernels (EquivariantGraphNeuralNetwork.py
 // :55-65: fp16 first-layer table, SiLU as t * rcp(1 + exp2(t)) on pre-scaled arguments, bf16 or fp16 MFMA operands with fp32
 // accumulation, fp32 heads and segment sums, tile partials added by node_post in tile order: deterministic, no atomics);
-// the K loop is the plain double-buffered form (build chunk c + 1 | multiply chunk c | one barrier): at 32 rows there is
-// no matrix / vector balance to tune, the loop waits for weights.
+// the K loop is the plain double-buffered form (build chunk c + 1 | multiply chunk c | one barrier) with the weight fragments
+// requested two chunks ahead: at 32 rows there is no matrix / vector balance to tune, the loop waits for weights.
 //
 //   workgroup = 8 wave64, v_mfma_f32_16x16x32_{bf16,f16}: 2 row blocks x CBW column blocks of 16 per wave
 //     IS_M = false  coordinate branch (:62-65): 512 columns of mlp_x.2 per workgroup (WxP / 512 column shares per tile), CBW = 4
@@ -20,25 +20,34 @@ namespace egnn {
 
 namespace {
 
-constexpr int kRS = 32;          // edges per tile
 constexpr int kTS = 512;
 constexpr int kKCS = 64;         // activation chunk depth
-constexpr size_t kA1S = (size_t)8 * kRS * 16;   // one activation chunk image
-// LDS carve (bytes)
-constexpr size_t kSOffDst = 0, kSOffSrc = kSOffDst + kRS * 4, kSOffD2 = kSOffSrc + kRS * 4, kSOffDiff = kSOffD2 + kRS * 4,
-                 kSOffVal = kSOffDiff + 3 * kRS * 4, kSOffPart = kSOffVal + kRS * 4, kSOffSegRow = kSOffPart + 8 * kRS * 4,
-                 kSOffSegNode = kSOffSegRow + kRS * 4, kSOffSegRs = kSOffSegNode + kRS * 4, kSOffSegRe = kSOffSegRs + kRS * 4,
-                 kSOffSegMode = kSOffSegRe + kRS * 4, kSOffMisc = kSOffSegMode + kRS * 4, kSOffA1 = kSOffMisc + 64;
-constexpr int kMLd = 257;        // row stride (floats) of the message tile [32][256] (odd: column walks hit 32 banks)
-__host__ __device__ inline size_t small_smem_bytes(int KP, bool is_m) {
-  return kSOffA1 + 2 * kA1S + (size_t)KP * 4 + (is_m ? (size_t)kRS * kMLd * 4 : 0);
-}
+constexpr int kMLd = 257;        // row stride (floats) of the message tile [R][256] (odd: column walks hit 32 banks)
+// LDS carve (bytes) for a tile of R edges: per-row arrays (19 x R words), then the activation images, wd[KP], the message tile
+template <int R> struct SmallLds {
+  static constexpr size_t kA1S = (size_t)8 * R * 16;   // one activation chunk image [8 k-groups][R rows][16 B]
+  static constexpr size_t kSOffDst = 0, kSOffSrc = kSOffDst + R * 4, kSOffD2 = kSOffSrc + R * 4, kSOffDiff = kSOffD2 + R * 4,
+                          kSOffVal = kSOffDiff + 3 * R * 4, kSOffPart = kSOffVal + R * 4, kSOffSegRow = kSOffPart + 8 * R * 4,
+                          kSOffSegNode = kSOffSegRow + R * 4, kSOffSegRs = kSOffSegNode + R * 4, kSOffSegRe = kSOffSegRs + R * 4,
+                          kSOffSegMode = kSOffSegRe + R * 4, kSOffMisc = kSOffSegMode + R * 4, kSOffA1 = kSOffMisc + 64;
+  static __host__ __device__ size_t bytes(int KP, bool is_m) { return kSOffA1 + 2 * kA1S + (size_t)KP * 4 + (is_m ? (size_t)R * kMLd * 4 : 0); }
+};
 
-template <bool IS_M, typename V8>
-__global__ __launch_bounds__(kTS, 2) void edge_small_kernel(const EdgeParams p) {
+// kRS = edges per tile.  32 is what is launched; the 64-row instantiation was measured for ONE 64-atom graph (4,032 edges) and is
+// no faster than the 128-row kernels there (coordinate kernel 32.2 vs 28.8 us, message kernel 26.0 vs 23.8 us per layer,
+// profiles/r04h_latency.log): at that size every kernel of a layer -- whatever its tiling -- takes ~25 us, the length of its
+// chain of dependent memory round trips at the clocks the chip holds between tiny kernels, not its arithmetic.
+template <bool IS_M, typename V8, int kRS>
+__global__ __launch_bounds__(kTS, 1) void edge_small_kernel(const EdgeParams p) {
   if constexpr (OpTraits<V8>::f16) f16_saturate_mode();
   constexpr int CBW = IS_M ? 2 : 4;                      // 16-column blocks per wave
+  constexpr int RB = kRS / 16;                           // 16-row blocks per tile
   constexpr float kAcc = kNegLog2e / OpTraits<V8>::wscale;
+  typedef SmallLds<kRS> LY;
+  constexpr size_t kA1S = LY::kA1S, kSOffDst = LY::kSOffDst, kSOffSrc = LY::kSOffSrc, kSOffD2 = LY::kSOffD2, kSOffDiff = LY::kSOffDiff,
+                   kSOffVal = LY::kSOffVal, kSOffPart = LY::kSOffPart, kSOffSegRow = LY::kSOffSegRow, kSOffSegNode = LY::kSOffSegNode,
+                   kSOffSegRs = LY::kSOffSegRs, kSOffSegRe = LY::kSOffSegRe, kSOffSegMode = LY::kSOffSegMode, kSOffMisc = LY::kSOffMisc,
+                   kSOffA1 = LY::kSOffA1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* const s_dst = reinterpret_cast<int*>(smem + kSOffDst);
   int* const s_src = reinterpret_cast<int*>(smem + kSOffSrc);
@@ -71,11 +80,18 @@ __global__ __launch_bounds__(kTS, 2) void edge_small_kernel(const EdgeParams p) 
   const rsrc_t rs_w = make_rsrc(IS_M ? p.w2m : p.w2x, (unsigned)((size_t)(IS_M ? p.MP : p.WxP) * KP * 2));
   const int cb0 = IS_M ? wave * CBW : half * 32 + wave * CBW;   // first 16-column block of this wave
   const unsigned w0 = (unsigned)cb0 * KS * 1024u, lane16 = lane * 16u;
-  V8 bq[2][CBW], bn[2][CBW];
+  // three register sets of weight fragments: chunk c is multiplied from set c % 3 while chunk c + 2 is requested into the set
+  // chunk c - 1 used (two chunks of distance: one L2 round trip under load is longer than one chunk of this short loop)
+  V8 ws0[2][CBW], ws1[2][CBW], ws2[2][CBW];
+  auto wload = [&](V8 (&w)[2][CBW], const int c) {
+    const unsigned ks = (unsigned)(c * 2) * 1024u;
 #pragma unroll
-  for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
-    for (int cb = 0; cb < CBW; ++cb) bq[s][cb] = ldbuf_v8<V8>(rs_w, lane16, w0 + ((unsigned)cb * KS + s) * 1024u);
+      for (int cb = 0; cb < CBW; ++cb) w[s][cb] = ldbuf_v8<V8>(rs_w, lane16, w0 + (unsigned)cb * KS * 1024u + ks + (unsigned)s * 1024u);
+  };
+  wload(ws0, 0);
+  if (NC > 1) wload(ws1, 1);
 
   // ---- prologue: edge rows, geometry (:56), segment structure of the CSR tile ----
   const float* wd = IS_M ? p.wdm : p.wdx;
@@ -95,7 +111,7 @@ __global__ __launch_bounds__(kTS, 2) void edge_small_kernel(const EdgeParams p) 
     s_diff[tid] = dx; s_diff[kRS + tid] = dy; s_diff[2 * kRS + tid] = dz;
     const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
     s_d2[tid] = nrm * nrm;
-    // consecutive rows with the same receiving node form a segment (lanes 0..31 of wave 0: neighbours by shuffle)
+    // consecutive rows with the same receiving node form a segment (the first kRS lanes of wave 0: neighbours by shuffle)
     const int dp = __shfl_up(d, 1), dn = __shfl_down(d, 1);
     const bool valid = tid < nvalid;
     is_start = valid && (tid == 0 || dp != d);
@@ -119,7 +135,7 @@ __global__ __launch_bounds__(kTS, 2) void edge_small_kernel(const EdgeParams p) 
 
   // ---- K loop ----
   // build: threads 0..255 finish one unit (8 hidden units of one row) per chunk: SiLU(P[dst] + Q[src] + wd * d2) -> operand type
-  const bool builder = tid < 8 * kRS;
+  const bool builder = tid < 8 * kRS;   // (kRS = 64: every thread)
   const int brow = (tid >> 3) & (kRS - 1), kg = tid & 7;
   const rsrc_t rs_tab = make_rsrc(p.table, (unsigned)((size_t)p.N * p.TC * 2));
   const unsigned vdst = (unsigned)s_dst[brow] * (unsigned)p.TC * 2u + (unsigned)kg * 16u;
@@ -130,9 +146,9 @@ __global__ __launch_bounds__(kTS, 2) void edge_small_kernel(const EdgeParams p) 
   const char* const afrag0 = s_a1 + (size_t)q4 * (kRS * 16) + (size_t)(r15 ^ q4) * 16;            // k-step 0: k-group q4
   const char* const afrag1 = s_a1 + (size_t)(4 + q4) * (kRS * 16) + (size_t)(r15 ^ (4 + q4)) * 16;   // k-step 1: k-group 4 + q4
 
-  f32x4 acc[2][CBW];
+  f32x4 acc[RB][CBW];
 #pragma unroll
-  for (int rb = 0; rb < 2; ++rb)
+  for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
     for (int cb = 0; cb < CBW; ++cb) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -144,62 +160,56 @@ __global__ __launch_bounds__(kTS, 2) void edge_small_kernel(const EdgeParams p) 
   }
   if (tid < S) s_seg_mode[tid] = my_mode;
   __syncthreads();
-  for (int c = 0; c < NC; ++c) {
+  auto step = [&](const int c, V8 (&wc)[2][CBW], V8 (&wn2)[2][CBW]) {
     const size_t boff = (size_t)(c & 1) * kA1S, noff = (size_t)((c + 1) & 1) * kA1S;
-    if (c + 1 < NC) {   // next chunk's weights in flight under this chunk's work
-      const unsigned ksn = (unsigned)((c + 1) * 2) * 1024u;
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int cb = 0; cb < CBW; ++cb) bn[s][cb] = ldbuf_v8<V8>(rs_w, lane16, w0 + (unsigned)cb * KS * 1024u + ksn + (unsigned)s * 1024u);
-      if (builder) {
-        unith_finish<V8>(u, s_wd + (c + 1) * kKCS + kg * 8, d2r, slot + noff);
-        if (c + 2 < NC) unith_load(u, rs_tab, vdst, vsrc, offP + (unsigned)(c + 2) * kKCS * 2u, offQ + (unsigned)(c + 2) * kKCS * 2u);
-      }
+    if (c + 2 < NC) wload(wn2, c + 2);
+    if (c + 1 < NC && builder) {
+      unith_finish<V8>(u, s_wd + (c + 1) * kKCS + kg * 8, d2r, slot + noff);
+      if (c + 2 < NC) unith_load(u, rs_tab, vdst, vsrc, offP + (unsigned)(c + 2) * kKCS * 2u, offQ + (unsigned)(c + 2) * kKCS * 2u);
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const char* af = (s == 0 ? afrag0 : afrag1) + boff;
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
+      for (int rb = 0; rb < RB; ++rb) {
         const V8 a = *reinterpret_cast<const V8*>(af + rb * 256);   // rows 16 rb + r15 (the XOR only touches the low 3 bits)
 #pragma unroll
-        for (int cb = 0; cb < CBW; ++cb) acc[rb][cb] = mfma16(a, bq[s][cb], acc[rb][cb]);
+        for (int cb = 0; cb < CBW; ++cb) acc[rb][cb] = mfma16(a, wc[s][cb], acc[rb][cb]);
       }
     }
-    if (c + 1 < NC) {
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int cb = 0; cb < CBW; ++cb) bq[s][cb] = bn[s][cb];
-    }
     __syncthreads();
+  };
+  {
+    int c = 0;
+    for (; c + 3 <= NC; c += 3) { step(c, ws0, ws2); step(c + 1, ws1, ws0); step(c + 2, ws2, ws1); }
+    if (c < NC) { step(c, ws0, ws2); ++c; }
+    if (c < NC) step(c, ws1, ws0);
   }
 
   // ---- epilogue ----
   // accumulator layout of a 16x16 tile: column = lane & 15, row = 4 (lane >> 4) + register
   if constexpr (!IS_M) {
     // s[row] = [b3] + sum over this workgroup's 512 columns of w3[n] SiLU(a2[row][n] + b2[n])   (:62-63)
-    float part[8];
+    float part[RB * 4];
 #pragma unroll
-    for (int v = 0; v < 8; ++v) part[v] = 0.f;
+    for (int v = 0; v < RB * 4; ++v) part[v] = 0.f;
 #pragma unroll
     for (int cb = 0; cb < CBW; ++cb) {
       const int n = 16 * (cb0 + cb) + r15;
       const float bb = p.b2x[n], w = p.w3x[n];
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb)
+      for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int i = 0; i < 4; ++i) part[rb * 4 + i] = fmaf(w, silu_s(fmaf(acc[rb][cb][i], kAcc, bb)), part[rb * 4 + i]);
     }
 #pragma unroll
-    for (int v = 0; v < 8; ++v) {
+    for (int v = 0; v < RB * 4; ++v) {
 #pragma unroll
       for (int m = 8; m >= 1; m >>= 1) part[v] += __shfl_xor(part[v], m);   // over the 16 columns of the lane group
     }
     if (r15 == 0) {
 #pragma unroll
-      for (int v = 0; v < 8; ++v) s_part[wave * kRS + 16 * (v >> 2) + 4 * q4 + (v & 3)] = part[v];
+      for (int v = 0; v < RB * 4; ++v) s_part[wave * kRS + 16 * (v >> 2) + 4 * q4 + (v & 3)] = part[v];
     }
     __syncthreads();
     if (tid < kRS) {
@@ -227,16 +237,16 @@ __global__ __launch_bounds__(kTS, 2) void edge_small_kernel(const EdgeParams p) 
     }
   } else {
     // m = SiLU(a2 + b2), gate = sigmoid(wa . m + ba), messages m * gate summed per receiving node   (:57-61)
-    float mval[2][CBW][4];
-    float zp[8];
+    float mval[RB][CBW][4];
+    float zp[RB * 4];
 #pragma unroll
-    for (int v = 0; v < 8; ++v) zp[v] = 0.f;
+    for (int v = 0; v < RB * 4; ++v) zp[v] = 0.f;
 #pragma unroll
     for (int cb = 0; cb < CBW; ++cb) {
       const int n = 16 * (cb0 + cb) + r15;
       const float bb = p.b2m[n], wa = p.wa[n];
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb)
+      for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float m = silu_s(fmaf(acc[rb][cb][i], kAcc, bb));   // = -log2(e) * m
@@ -245,13 +255,13 @@ __global__ __launch_bounds__(kTS, 2) void edge_small_kernel(const EdgeParams p) 
         }
     }
 #pragma unroll
-    for (int v = 0; v < 8; ++v) {
+    for (int v = 0; v < RB * 4; ++v) {
 #pragma unroll
       for (int m = 8; m >= 1; m >>= 1) zp[v] += __shfl_xor(zp[v], m);
     }
     if (r15 == 0) {
 #pragma unroll
-      for (int v = 0; v < 8; ++v) s_part[wave * kRS + 16 * (v >> 2) + 4 * q4 + (v & 3)] = zp[v];
+      for (int v = 0; v < RB * 4; ++v) s_part[wave * kRS + 16 * (v >> 2) + 4 * q4 + (v & 3)] = zp[v];
     }
     __syncthreads();
     if (tid < kRS) {
@@ -262,7 +272,7 @@ __global__ __launch_bounds__(kTS, 2) void edge_small_kernel(const EdgeParams p) 
     }
     __syncthreads();
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = 16 * rb + 4 * q4 + i;
@@ -287,18 +297,22 @@ __global__ __launch_bounds__(kTS, 2) void edge_small_kernel(const EdgeParams p) 
   }
 }
 
-template <bool IS_M, typename V8>
+template <bool IS_M, typename V8, int R>
 int launch_small(const EdgeParams& p, hipStream_t st) {
-  const int tiles = (p.E + kRS - 1) / kRS;
+  const int tiles = (p.E + R - 1) / R;
   const int nsplit = IS_M ? 1 : p.WxP / 512;
-  hipLaunchKernelGGL((edge_small_kernel<IS_M, V8>), dim3(tiles * nsplit), dim3(kTS), small_smem_bytes(IS_M ? p.WmP : p.WxP, IS_M), st, p);
+  static bool attr_done = false;   // (per instantiation) the 64-row message kernel needs more than the default 64 KiB of LDS
+  if (!attr_done) {
+    EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_small_kernel<IS_M, V8, R>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 160 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((edge_small_kernel<IS_M, V8, R>), dim3(tiles * nsplit), dim3(kTS), SmallLds<R>::bytes(IS_M ? p.WmP : p.WxP, IS_M), st, p);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }
 
 }  // namespace
-
-int edge_small_rows() { return kRS; }
 
 // the shapes of edge_x_m16.hip / edge_bf16_v4.hip (hidden width 512 / 1024, 256 message columns), 16-column fragment streams packed
 bool edge_small_supported(const EdgeParams& p) {
@@ -306,16 +320,18 @@ bool edge_small_supported(const EdgeParams& p) {
          (size_t)p.N * p.TC * 2 < ((size_t)1 << 32);
 }
 
+int edge_small_rows() { return 32; }
+
 // p.w2x16 / p.w2m16 = the 16-column fragment streams of the chosen operand type (scaled)
 int launch_edge_small_x(const EdgeParams& p, hipStream_t st, bool f16) {
   EdgeParams q = p;
   q.w2x = p.w2x16;
-  return f16 ? launch_small<false, f16x8>(q, st) : launch_small<false, bf16x8>(q, st);
+  return f16 ? launch_small<false, f16x8, 32>(q, st) : launch_small<false, bf16x8, 32>(q, st);
 }
 int launch_edge_small_m(const EdgeParams& p, hipStream_t st, bool f16) {
   EdgeParams q = p;
   q.w2m = p.w2m16;
-  return f16 ? launch_small<true, f16x8>(q, st) : launch_small<true, bf16x8>(q, st);
+  return f16 ? launch_small<true, f16x8, 32>(q, st) : launch_small<true, bf16x8, 32>(q, st);
 }
 
 }  // namespace egnn
