@@ -14,7 +14,8 @@
 
 #if !defined(EGNN_DIAG) && (defined(EGNN_EXP_STAMP) || defined(EGNN_EXP_STAMP2) || defined(EGNN_EXP_WGSTAMP) || defined(EGNN_EXP_DGSTAMP) || \
     defined(EGNN_EXP_NO_S1) || defined(EGNN_EXP_NO_T2) || defined(EGNN_EXP_DG_NOK) || defined(EGNN_EXP_DG_NOG) || defined(EGNN_EXP_DG_NOW) || \
-    defined(EGNN_EXP_DG_L2G) || defined(EGNN_EXP_DG_NOTAB) || defined(EGNN_EXP_DG_NOEPI))
+    defined(EGNN_EXP_DG_L2G) || defined(EGNN_EXP_DG_NOTAB) || defined(EGNN_EXP_DG_NOEPI) || defined(EGNN_EXP_NP_NONORM) ||                    \
+    defined(EGNN_EXP_NP_NOMLP))
 #error "EGNN_EXP_* switches are diagnostic builds: add -DEGNN_DIAG (tools/exp_build.sh)"
 #endif
 
@@ -60,6 +61,16 @@ EGNN_DIAG_FLAG(kDgNoTab, false);
 EGNN_DIAG_FLAG(kDgNoEpi, true);
 #else
 EGNN_DIAG_FLAG(kDgNoEpi, false);
+#endif
+#ifdef EGNN_EXP_NP_NONORM   // node_post timing builds (tools/lat_ab.sh): without the normaliser / coordinate update, without the MLP
+EGNN_DIAG_FLAG(kNpNoNorm, true);
+#else
+EGNN_DIAG_FLAG(kNpNoNorm, false);
+#endif
+#ifdef EGNN_EXP_NP_NOMLP
+EGNN_DIAG_FLAG(kNpNoMlp, true);
+#else
+EGNN_DIAG_FLAG(kNpNoMlp, false);
 #endif
 #undef EGNN_DIAG_FLAG
 // EdgeParams::dbg (environment EGNN_DEBUG, read by a diagnostic build only): bit 0 = zero-size weight descriptor, bit 1 =

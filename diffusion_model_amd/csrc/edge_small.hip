@@ -14,6 +14,7 @@
 //     IS_M = false  coordinate branch (:62-65): 512 columns of mlp_x.2 per workgroup (WxP / 512 column shares per tile), CBW = 4
 //     IS_M = true   message branch (:57-61): all 256 columns of mlp_m.2 + the attention gate, CBW = 2
 //   LDS activation image [8 k-groups][32 rows][16 B], rows XOR-swizzled by the k-group as in edge_x_m16.hip.
+#include "diag.h"
 #include "edge_tile.h"
 
 namespace egnn {
@@ -30,7 +31,7 @@ template <int R> struct SmallLds {
                           kSOffVal = kSOffDiff + 3 * R * 4, kSOffPart = kSOffVal + R * 4, kSOffSegRow = kSOffPart + 8 * R * 4,
                           kSOffSegNode = kSOffSegRow + R * 4, kSOffSegRs = kSOffSegNode + R * 4, kSOffSegRe = kSOffSegRs + R * 4,
                           kSOffSegMode = kSOffSegRe + R * 4, kSOffMisc = kSOffSegMode + R * 4, kSOffA1 = kSOffMisc + 64;
-  static __host__ __device__ size_t bytes(int KP, bool is_m) { return kSOffA1 + 2 * kA1S + (size_t)KP * 4 + (is_m ? (size_t)R * kMLd * 4 : 0); }
+  static __host__ __device__ size_t bytes(int KP, bool is_m) { return kSOffA1 + 2 * kA1S + (size_t)KP * 4 + (is_m ? ((size_t)R * kMLd + 256) * 4 : 0); }
 };
 
 // kRS = edges per tile.  32 is what is launched; the 64-row instantiation was measured for ONE 64-atom graph (4,032 edges) and is
@@ -75,14 +76,16 @@ __global__ __launch_bounds__(kTS, 1) void edge_small_kernel(const EdgeParams p) 
   const int e0 = tile * kRS;
   const int nvalid = min(kRS, p.E - e0);
 
+  DIAG_STAMP_SETUP(p.stamps + ((size_t)(IS_M ? 1 : 0) * 8 + wave) * 32 * 4);
+  DIAG_STAMP(30, 0);   // kernel entry
   // ---- weights of the first chunk: they depend on nothing, requested before anything else ----
   const int NC = KP / kKCS, KS = KP / 32;
   const rsrc_t rs_w = make_rsrc(IS_M ? p.w2m : p.w2x, (unsigned)((size_t)(IS_M ? p.MP : p.WxP) * KP * 2));
   const int cb0 = IS_M ? wave * CBW : half * 32 + wave * CBW;   // first 16-column block of this wave
   const unsigned w0 = (unsigned)cb0 * KS * 1024u, lane16 = lane * 16u;
-  // three register sets of weight fragments: chunk c is multiplied from set c % 3 while chunk c + 2 is requested into the set
-  // chunk c - 1 used (two chunks of distance: one L2 round trip under load is longer than one chunk of this short loop)
-  V8 ws0[2][CBW], ws1[2][CBW], ws2[2][CBW];
+  // two register sets of weight fragments: chunk c is multiplied from set c % 2, which is re-requested for chunk c + 2 as soon as
+  // its MFMAs were issued (a third set made the 64-row coordinate kernel spill once both wave orders were instantiated)
+  V8 ws0[2][CBW], ws1[2][CBW];
   auto wload = [&](V8 (&w)[2][CBW], const int c) {
     const unsigned ks = (unsigned)(c * 2) * 1024u;
 #pragma unroll
@@ -124,6 +127,7 @@ __global__ __launch_bounds__(kTS, 1) void edge_small_kernel(const EdgeParams p) 
     if (tid == 0) s_misc[0] = __popcll(starts);
   }
   __syncthreads();
+  DIAG_STAMP(30, 1);   // edge rows, geometry, segments ready
   const int S = s_misc[0];
   int my_mode = 0;
   if (tid < S) {   // 2 = all edges of the node are in this segment, 1 = the node's edges start here, 0 = continue (edge_tile.h)
@@ -135,7 +139,6 @@ __global__ __launch_bounds__(kTS, 1) void edge_small_kernel(const EdgeParams p) 
 
   // ---- K loop ----
   // build: threads 0..255 finish one unit (8 hidden units of one row) per chunk: SiLU(P[dst] + Q[src] + wd * d2) -> operand type
-  const bool builder = tid < 8 * kRS;   // (kRS = 64: every thread)
   const int brow = (tid >> 3) & (kRS - 1), kg = tid & 7;
   const rsrc_t rs_tab = make_rsrc(p.table, (unsigned)((size_t)p.N * p.TC * 2));
   const unsigned vdst = (unsigned)s_dst[brow] * (unsigned)p.TC * 2u + (unsigned)kg * 16u;
@@ -152,40 +155,70 @@ __global__ __launch_bounds__(kTS, 1) void edge_small_kernel(const EdgeParams p) 
 #pragma unroll
     for (int cb = 0; cb < CBW; ++cb) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  UnitH u;
-  if (builder) {
-    unith_load(u, rs_tab, vdst, vsrc, offP, offQ);
-    unith_finish<V8>(u, s_wd + kg * 8, d2r, slot);
-    if (NC > 1) unith_load(u, rs_tab, vdst, vsrc, offP + kKCS * 2u, offQ + kKCS * 2u);
-  }
+  // first-layer table rows: two register sets, chunk k in set k % 2, re-requested for chunk k + 2 the moment chunk k was built
+  // (a handful of workgroups cannot hide a memory latency behind each other, only behind their own earlier requests)
+  UnitH u0, u1;
+  auto tload = [&](UnitH& u, const int c) {
+    const int cc = c < NC ? c : NC - 1;   // past the end: a harmless repeat
+    unith_load(u, rs_tab, vdst, vsrc, offP + (unsigned)cc * kKCS * 2u, offQ + (unsigned)cc * kKCS * 2u);
+  };
+  // (every thread builds: at 32 rows waves 4-7 mirror waves 0-3 -- same units, same values written twice -- so that the loop
+  // below has no branch: behind a control-flow join hipcc waits for EVERY outstanding load (vmcnt(0)), i.e. also for the weight
+  // fragments requested a moment ago, which cost one L2 round trip per chunk: 2.8 k cycles per chunk against 0.9 k of MFMAs
+  // in the first build, tools/stamps.py)
+  tload(u0, 0); tload(u1, 1);
+  unith_finish<V8>(u0, s_wd + kg * 8, d2r, slot);
+  tload(u0, 2);
   if (tid < S) s_seg_mode[tid] = my_mode;
   __syncthreads();
-  auto step = [&](const int c, V8 (&wc)[2][CBW], V8 (&wn2)[2][CBW]) {
+  DIAG_STAMP(30, 2);   // chunk 0 built
+  DIAG_RSTAMP(31, 1);
+  // step c: multiply chunk c (weights wc), request the weights of chunk c + 2 (into wn2), finish the activations of chunk c + 1
+  // from the table set ut and re-request that set for chunk c + 4.  No branch inside (clamped repeats past the end).
+  // The two waves of a SIMD (w and w + 4) run a step in OPPOSITE order -- multiply chunk c then build chunk c + 1, or build then
+  // multiply -- so that one's vector work (8 SiLUs per thread and chunk) runs under the other's matrix work, as in
+  // edge_x_m16.hip: with all eight waves in the same phase a chunk cost build (both waves of a SIMD in turn, 1.8 k cycles) PLUS
+  // MFMAs (1.0 k), tools/stamps.py.
+  auto step = [&](const int c, V8 (&wc)[2][CBW], UnitH& ut, const bool mfma_first) {
     const size_t boff = (size_t)(c & 1) * kA1S, noff = (size_t)((c + 1) & 1) * kA1S;
-    if (c + 2 < NC) wload(wn2, c + 2);
-    if (c + 1 < NC && builder) {
-      unith_finish<V8>(u, s_wd + (c + 1) * kKCS + kg * 8, d2r, slot + noff);
-      if (c + 2 < NC) unith_load(u, rs_tab, vdst, vsrc, offP + (unsigned)(c + 2) * kKCS * 2u, offQ + (unsigned)(c + 2) * kKCS * 2u);
-    }
+    DIAG_STAMP(c, 0);
+    const int cn = c + 1 < NC ? c + 1 : NC - 1;
+    auto build = [&]() {   // activations of chunk c + 1 from the table set ut, which is then re-requested for chunk c + 3
+      unith_finish<V8>(ut, s_wd + cn * kKCS + kg * 8, d2r, slot + noff);   // (last step: rebuilds the last chunk into the free buffer)
+      tload(ut, c + 3);
+    };
+    auto multiply = [&]() {   // chunk c from the weight set wc, which is then re-requested for chunk c + 2
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const char* af = (s == 0 ? afrag0 : afrag1) + boff;
+      for (int s = 0; s < 2; ++s) {
+        const char* af = (s == 0 ? afrag0 : afrag1) + boff;
 #pragma unroll
-      for (int rb = 0; rb < RB; ++rb) {
-        const V8 a = *reinterpret_cast<const V8*>(af + rb * 256);   // rows 16 rb + r15 (the XOR only touches the low 3 bits)
+        for (int rb = 0; rb < RB; ++rb) {
+          const V8 a = *reinterpret_cast<const V8*>(af + rb * 256);   // rows 16 rb + r15 (the XOR only touches the low 3 bits)
 #pragma unroll
-        for (int cb = 0; cb < CBW; ++cb) acc[rb][cb] = mfma16(a, wc[s][cb], acc[rb][cb]);
+          for (int cb = 0; cb < CBW; ++cb) acc[rb][cb] = mfma16(a, wc[s][cb], acc[rb][cb]);
+        }
       }
-    }
+      wload(wc, c + 2 < NC ? c + 2 : NC - 1);              // (past the end: harmless repeats instead of branches)
+    };
+    if (mfma_first) { multiply(); DIAG_STAMP(c, 1); __builtin_amdgcn_sched_barrier(0); build(); }
+    else { build(); DIAG_STAMP(c, 1); __builtin_amdgcn_sched_barrier(0); multiply(); }
+    DIAG_STAMP(c, 2);
     __syncthreads();
+    DIAG_STAMP(c, 3);
   };
-  {
-    int c = 0;
-    for (; c + 3 <= NC; c += 3) { step(c, ws0, ws2); step(c + 1, ws1, ws0); step(c + 2, ws2, ws1); }
-    if (c < NC) { step(c, ws0, ws2); ++c; }
-    if (c < NC) step(c, ws1, ws0);
-  }
+  // The register sets rotate statically, two steps per loop iteration, and the FIRST iteration is peeled: hipcc's wait insertion
+  // joins the load counts of the two ways into the loop header, and with the prologue's request pattern on one side the first
+  // step of EVERY iteration waited for almost every outstanding load (s_waitcnt vmcnt(1) in front of the activation build);
+  // behind a peeled iteration both ways in carry the same pattern.  (NC even and >= 4: edge_small_supported.)
+  auto kloop = [&](const bool mf) {
+    step(0, ws0, u1, mf); step(1, ws1, u0, mf);
+    for (int c = 2; c + 2 <= NC; c += 2) { step(c, ws0, u1, mf); step(c + 1, ws1, u0, mf); }
+  };
+  if (wave < 4) kloop(true);
+  else kloop(false);
 
+  DIAG_STAMP(30, 3);   // K loop done
+  DIAG_RSTAMP(31, 2);
   // ---- epilogue ----
   // accumulator layout of a 16x16 tile: column = lane & 15, row = 4 (lane >> 4) + register
   if constexpr (!IS_M) {
@@ -222,7 +255,30 @@ __global__ __launch_bounds__(kTS, 1) void edge_small_kernel(const EdgeParams p) 
     // coordinate messages (:64-65): per segment sum of (x_i - x_j) s_ij; component 3 = the segment's sum of |x_i - x_j|^2
     float* aggx = p.agg_x + (size_t)half * p.agg_x_stride;
     float* partx = p.part_x + (size_t)half * p.part_x_stride;
-    if (tid < 4 * S) {
+    if (S <= 8) {
+      // few segments (a dense graph: 1-3 receiving nodes per tile): wave d < 4 owns component d, its lanes the rows, one
+      // cross-lane sum per segment (a serial walk over a segment's rows was 9 k of the first build's 16 k epilogue cycles)
+      if (wave < 4) {
+        const int d = wave, row = lane;
+        float v = 0.f;
+        int sg = -1;
+        if (row < kRS && row < nvalid) {
+          sg = s_seg_of_row[row];
+          if (d < 3) v = s_diff[d * kRS + row] * s_val[row];
+          else { const float dx = s_diff[row], dy = s_diff[kRS + row], dz = s_diff[2 * kRS + row]; v = dx * dx + dy * dy + dz * dz; }
+        }
+        for (int seg = 0; seg < S; ++seg) {
+          float t = sg == seg ? v : 0.f;
+#pragma unroll
+          for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m);
+          if (lane == 0) {
+            const int mode = s_seg_mode[seg];
+            float* dstp = mode == 2 ? aggx + (size_t)s_seg_node[seg] * 4 : partx + ((size_t)tile * 2 + mode) * 4;
+            dstp[d] = t;
+          }
+        }
+      }
+    } else if (tid < 4 * S) {
       const int seg = tid >> 2, d = tid & 3, mode = s_seg_mode[seg];
       float sum = 0.f;
       for (int rr = s_seg_rs[seg]; rr <= s_seg_re[seg]; ++rr) {
@@ -281,20 +337,29 @@ __global__ __launch_bounds__(kTS, 1) void edge_small_kernel(const EdgeParams p) 
         for (int cb = 0; cb < CBW; ++cb) s_mt[row * kMLd + 16 * (cb0 + cb) + r15] = mval[rb][cb][i] * g;
       }
     __syncthreads();
-    if (tid < p.MP) {   // one column per thread: walk the tile's rows, flush at segment ends (rows of a segment are consecutive)
-      float sum = 0.f;
-      for (int rr = 0; rr < nvalid; ++rr) {
-        sum += s_mt[rr * kMLd + tid];
-        const int seg = s_seg_of_row[rr];
-        if (s_seg_re[seg] == rr) {
+    // two half-columns of threads per message column (tid and tid + 256 take alternate rows of a segment), segment by segment:
+    // the row reads of a segment are independent LDS reads (a walk that looked the segment up per row was a chain of dependent
+    // LDS round trips: 20 k cycles of the first build's message epilogue)
+    {
+      const int col = tid & 255, par = tid >> 8;
+      float* const s_half = s_mt + (size_t)kRS * kMLd;   // [256] sums of the odd rows (the tile itself is no longer needed there)
+      for (int seg = 0; seg < S; ++seg) {
+        const int rs = s_seg_rs[seg], re = s_seg_re[seg];
+        float sum = 0.f;
+#pragma unroll 8
+        for (int rr = rs + par; rr <= re; rr += 2) sum += s_mt[rr * kMLd + col];
+        if (seg > 0) __syncthreads();                  // the previous segment's exchange has been read
+        if (par == 1) s_half[col] = sum;
+        __syncthreads();
+        if (par == 0 && col < p.MP) {
           const int mode = s_seg_mode[seg];
           float* dstp = mode == 2 ? p.agg_m + (size_t)s_seg_node[seg] * p.MP : p.part_m + ((size_t)tile * 2 + mode) * p.MP;
-          dstp[tid] = sum;
-          sum = 0.f;
+          dstp[col] = sum + s_half[col];
         }
       }
     }
   }
+  DIAG_STAMP(31, 0);   // epilogue done
 }
 
 template <bool IS_M, typename V8, int R>
@@ -316,21 +381,21 @@ int launch_small(const EdgeParams& p, hipStream_t st) {
 
 // the shapes of edge_x_m16.hip / edge_bf16_v4.hip (hidden width 512 / 1024, 256 message columns), 16-column fragment streams packed
 bool edge_small_supported(const EdgeParams& p) {
-  return (p.WxP == 512 || p.WxP == 1024) && p.MP == 256 && p.WmP % 64 == 0 && p.w2x16 != nullptr && p.w2m16 != nullptr &&
+  return (p.WxP == 512 || p.WxP == 1024) && p.MP == 256 && p.WmP % 128 == 0 && p.WmP >= 256 && p.w2x16 != nullptr && p.w2m16 != nullptr &&
          (size_t)p.N * p.TC * 2 < ((size_t)1 << 32);
 }
 
-int edge_small_rows() { return 32; }
-
-// p.w2x16 / p.w2m16 = the 16-column fragment streams of the chosen operand type (scaled)
-int launch_edge_small_x(const EdgeParams& p, hipStream_t st, bool f16) {
+// p.w2x16 / p.w2m16 = the 16-column fragment streams of the chosen operand type (scaled); rows = 32 or 64 edges per tile
+int launch_edge_small_x(const EdgeParams& p, hipStream_t st, bool f16, int rows) {
   EdgeParams q = p;
   q.w2x = p.w2x16;
+  if (rows == 64) return f16 ? launch_small<false, f16x8, 64>(q, st) : launch_small<false, bf16x8, 64>(q, st);
   return f16 ? launch_small<false, f16x8, 32>(q, st) : launch_small<false, bf16x8, 32>(q, st);
 }
-int launch_edge_small_m(const EdgeParams& p, hipStream_t st, bool f16) {
+int launch_edge_small_m(const EdgeParams& p, hipStream_t st, bool f16, int rows) {
   EdgeParams q = p;
   q.w2m = p.w2m16;
+  if (rows == 64) return f16 ? launch_small<true, f16x8, 64>(q, st) : launch_small<true, bf16x8, 64>(q, st);
   return f16 ? launch_small<true, f16x8, 32>(q, st) : launch_small<true, bf16x8, 32>(q, st);
 }
 

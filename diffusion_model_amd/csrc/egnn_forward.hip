@@ -1017,9 +1017,12 @@ static int launch_edge(const EdgeParams& p, int tiles, size_t smem, hipStream_t 
 // is (E / tile rows) x 2.5 MB whatever the column split, 315 MB at 32 rows for ONE 64-atom graph, and the chip's L2 delivers
 // ~7 TB/s to 256 streaming CUs, not the 34 TB/s of 64 B/clk/CU -- 128-row tiles are within 3x of that floor already.
 // EGNN_SMALL_EDGES overrides the edge-count limit (0 = never): measurement switch.
-static bool small_tiles(const egnn_ctx* c, const EdgeParams& p) {
+// -> edges per tile (32 / 64) or 0 = the 128-edge-tile kernels.  EGNN_SMALL64_EDGES: limit of the 64-row form (one 64-atom graph).
+static int small_tiles(const egnn_ctx* c, const EdgeParams& p) {
   static const long limit = getenv("EGNN_SMALL_EDGES") ? atol(getenv("EGNN_SMALL_EDGES")) : 2048;
-  return c->E > 0 && (long)c->E <= limit && c->small_ok && edge_small_supported(p);
+  static const long limit64 = getenv("EGNN_SMALL64_EDGES") ? atol(getenv("EGNN_SMALL64_EDGES")) : 6144;
+  if (c->E <= 0 || !c->small_ok || !edge_small_supported(p)) return 0;
+  return (long)c->E <= limit ? 32 : ((long)c->E <= limit64 ? 64 : 0);
 }
 
 // EdgeParams of layer `layer` over the graph set on the context (unscaled parameter vectors, fp32 / bf16 fragments)
@@ -1227,24 +1230,24 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
       R = 128;
       nsplit_x = p.WxP / 256;
       rc = launch_edge_bf16x3(p, st);
-    } else if ((path == 6 || path == 4) && !c->save_s1x && small_tiles(c, p)) {
+    } else if ((path == 6 || path == 4) && !c->save_s1x && small_tiles(c, p) != 0) {
       // small graphs (the reference's per-call workload): 32-edge tiles, weight-stream-bound workgroups (edge_small.hip);
       // coordinate and message kernel side by side when the caller gave a side stream
       const bool f16 = path == 6;
-      R = edge_small_rows();
+      R = small_tiles(c, p);
       nsplit_x = p.WxP / 512;
       if (f16) { p.w2x16 = lp.w2x_f16s16; p.w2m16 = lp.w2m_f16s16; }
       const bool fork = !c->prof && st != nullptr && c->side != nullptr && c->ev_fork != nullptr;
       if (fork) {
         EGNN_HIP(hipEventRecord(c->ev_fork, st));
         EGNN_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-        rc = launch_edge_small_x(p, st, f16);
-        if (!rc) rc = launch_edge_small_m(p, c->side, f16);
+        rc = launch_edge_small_x(p, st, f16, R);
+        if (!rc) rc = launch_edge_small_m(p, c->side, f16, R);
         EGNN_HIP(hipEventRecord(c->ev_join, c->side));
         EGNN_HIP(hipStreamWaitEvent(st, c->ev_join, 0));
       } else {
-        rc = launch_edge_small_x(p, st, f16);
-        if (!rc) rc = launch_edge_small_m(p, st, f16);
+        rc = launch_edge_small_x(p, st, f16, R);
+        if (!rc) rc = launch_edge_small_m(p, st, f16, R);
       }
     } else if (path == 6) {   // precision fp16: the path-4 kernels on fp16 operands (same tiles, same launch structure)
       R = edge_v4_rows();

@@ -332,10 +332,9 @@ int launch_edge_f16_v4_m(const EdgeParams& p, hipStream_t st);    // precision f
 bool edge_x_m16_supported(const EdgeParams& p);
 int init_edge_x_m16_attributes();
 // 32-edge tiles for small graphs (edge_small.hip): p.w2x16 / p.w2m16 = 16-column fragment streams of the operand type
-int launch_edge_small_x(const EdgeParams& p, hipStream_t st, bool f16);
-int launch_edge_small_m(const EdgeParams& p, hipStream_t st, bool f16);
+int launch_edge_small_x(const EdgeParams& p, hipStream_t st, bool f16, int rows);   // rows = 32 or 64 edges per tile
+int launch_edge_small_m(const EdgeParams& p, hipStream_t st, bool f16, int rows);
 bool edge_small_supported(const EdgeParams& p);
-int edge_small_rows();
 int launch_edge_bf16x3(const EdgeParams& p, hipStream_t st);    // precision 'bf16x3': head / remainder split operands
 bool edge_bf16x3_supported(const EdgeParams& p);
 int init_edge_bf16x3_attributes();

@@ -9,6 +9,7 @@
 // tiles are added through LDS in a fixed order.
 #include <stdlib.h>
 
+#include "diag.h"
 #include "kernels.h"
 
 namespace egnn {
@@ -38,12 +39,19 @@ __host__ __device__ inline size_t nb_smem_bytes(int K1Q, int OB, bool split = fa
 // on eps_x) and costs 0.4 % of a layer's FLOP.  W1h head / remainder fragments stream through a ring of kRingD k-steps
 // (requested kRingD k-steps ahead, across hidden-block boundaries) instead of living in registers for a whole block;
 // K is padded to kSplitK = 2 ring turns so that the ring slot of a k-step is a compile-time constant.
-template <int OBT, typename V8 = bf16x8, bool SPLIT = false>
+// HS = true: the hidden-split launch of small graphs (8 workgroups per node tile, ONE hidden block per wave; a layer is then a
+// handful of workgroups and the kernel's duration is the length of its chains of dependent memory round trips): no
+// next-block prefetch (there is no next block; its 80 registers go to the gather), and the gather of [h | sum_m] is BRANCH-FREE:
+// one or two unconditional loads per element from a selected address (the node's own slot or the first two tile partials),
+// 20 loads of a thread in flight at once (four batches; all 80 at once spill).  With `if (k < H) ... else if (t0 == t1) ...` around the loads every iteration
+// was a control-flow join, behind which hipcc waits for all outstanding loads: 19 serial round trips, 12 of the kernel's 27 us
+// at one 64-atom graph (timing builds EGNN_EXP_NP_*, profiles/r04h_latency.log).
+template <int OBT, typename V8 = bf16x8, bool SPLIT = false, bool HS = false>
 __global__ __launch_bounds__(kThreadsN, (OBT > 2 ? 1 : 2)) void node_post_bf16_kernel(const PostParams p) {
   typedef typename OpTraits<V8>::elem elem;
   constexpr float kInvW = 1.0f / OpTraits<V8>::wscale;
   if constexpr (OpTraits<V8>::f16) f16_saturate_mode();
-  constexpr bool PF = true;   // the W1h fragments of the next hidden block are requested while this one is multiplied
+  constexpr bool PF = !HS;   // the W1h fragments of the next hidden block are requested while this one is multiplied
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Xb = smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
@@ -106,6 +114,63 @@ __global__ __launch_bounds__(kThreadsN, (OBT > 2 ? 1 : 2)) void node_post_bf16_k
     s_t0[tid] = t0; s_t1[tid] = t1;
   }
   __syncthreads();
+  if constexpr (HS) {
+    constexpr int kIt = (kNodes * (kMaxKS1 * 16 / 2) + kThreadsN - 1) / kThreadsN;   // 20 pairs per thread at K1Q = 320
+    constexpr int kBatch = 5;                                                          // pairs whose loads fly together
+    static_assert(kIt % kBatch == 0, "batches of equal size");
+#pragma unroll
+    for (int b0 = 0; b0 < kIt; b0 += kBatch) {
+      float va[kBatch][2], vb[kBatch][2];
+      bool more = false;
+#pragma unroll
+      for (int it = 0; it < kBatch; ++it) {
+        const int i = min(tid + kThreadsN * (b0 + it), kNodes * (K1Q / 2) - 1);
+        const int node = i / (K1Q / 2), kp = i % (K1Q / 2), n = min(n0 + node, p.N - 1);
+        const int t0 = s_t0[node], t1 = s_t1[node];
+        more |= t1 > t0 + 1;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int k = 2 * kp + u, c = k - p.H;
+          const bool is_h = k < p.H, is_m = !is_h && c < p.MP && t0 >= 0;
+          const float* a = is_h ? p.h + (size_t)n * p.H + k
+                                : (t0 == t1 ? p.agg_m + (size_t)n * p.MP + (is_m ? c : 0) : p.part_m + ((size_t)(is_m ? t0 : 0) * 2 + 1) * p.MP + (is_m ? c : 0));
+          const bool two = is_m && t1 > t0;
+          const float* b = two ? p.part_m + ((size_t)(t0 + 1) * 2) * p.MP + c : p.h;
+          const float x0 = *a, x1 = *b;      // unconditional: no branch between the loads
+          va[it][u] = (is_h || is_m) ? x0 : 0.f;
+          vb[it][u] = two ? x1 : 0.f;
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < kBatch; ++it) {
+        const int i = tid + kThreadsN * (b0 + it);
+        if (i < kNodes * (K1Q / 2)) {
+          const int node = i / (K1Q / 2), kp = i % (K1Q / 2), n = n0 + node;
+          float v[2] = {va[it][0] + vb[it][0], va[it][1] + vb[it][1]};
+          if (n >= p.N) v[0] = v[1] = 0.f;
+          else if (more) {   // a node whose edges span more than two tiles (degree > 2 R): the remaining partials
+            const int t0 = s_t0[node], t1 = s_t1[node];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int c = 2 * kp + u - p.H;
+              if (c >= 0 && c < p.MP)
+                for (int t = t0 + 2; t <= t1; ++t) v[u] += p.part_m[((size_t)t * 2) * p.MP + c];
+            }
+          }
+          const int k = 2 * kp;
+          elem* dst = reinterpret_cast<elem*>(Xb + ((size_t)(k >> 3) * 33 + node) * 16) + (k & 7);
+          const elem e0 = (elem)v[0], e1 = (elem)v[1];
+          dst[0] = e0;
+          dst[1] = e1;
+          if constexpr (SPLIT) {
+            elem* dl = reinterpret_cast<elem*>(Xl + ((size_t)(k >> 3) * 33 + node) * 16) + (k & 7);
+            dl[0] = (elem)(v[0] - (float)e0);
+            dl[1] = (elem)(v[1] - (float)e1);
+          }
+        }
+      }
+    }
+  } else
 #pragma unroll 4
   for (int i = tid; i < kNodes * (K1Q / 2); i += kThreadsN) {
     const int node = i / (K1Q / 2), kp = i % (K1Q / 2), n = n0 + node;
@@ -143,7 +208,7 @@ __global__ __launch_bounds__(kThreadsN, (OBT > 2 ? 1 : 2)) void node_post_bf16_k
   // 32 nodes (a latency-bound loop of dependent loads otherwise).  Either way every workgroup that needs a graph's
   // sum adds the same values in the same order: the result is bitwise the same everywhere.
   float* gsq = reinterpret_cast<float*>(smem + nb_smem_bytes(K1Q, p.HP / 32, SPLIT));   // [kNodes] then [kThreadsN] scratch
-  if (p.sq_from_agg && blockIdx.y == 0) {
+  if (p.sq_from_agg && blockIdx.y == 0 && !diag::kNpNoNorm) {
     float* red = gsq + kNodes;
     const int node = tid >> 3, n = n0 + node;
     int g = -1, lo = 0, hi = 0;
@@ -172,7 +237,7 @@ __global__ __launch_bounds__(kThreadsN, (OBT > 2 ? 1 : 2)) void node_post_bf16_k
     __syncthreads();
   }
   // coordinate update (by the first of the workgroups that share this node tile)
-  if (blockIdx.y == 0 && tid < kNodes * 3) {
+  if (blockIdx.y == 0 && tid < kNodes * 3 && !diag::kNpNoNorm) {
     const int node = tid / 3, d = tid % 3, n = n0 + node;
     if (n < p.N) {
       const int t0 = s_t0[node], t1 = s_t1[node];
@@ -207,7 +272,7 @@ __global__ __launch_bounds__(kThreadsN, (OBT > 2 ? 1 : 2)) void node_post_bf16_k
   // wave instead of one per k-step.
   V8 wn[SPLIT ? 1 : kMaxKS1];
   const char* xfrag_lo = Xl + ((size_t)hh * 33 + r) * 16;
-  for (int q = 0; q < hb_per_wave; ++q) {
+  for (int q = 0; q < (diag::kNpNoMlp ? 0 : hb_per_wave); ++q) {
     const int hb = hb0 + wave * hb_per_wave + q;
     if constexpr (SPLIT) {
     } else if constexpr (PF) {
@@ -331,7 +396,9 @@ int init_node_bf16_attributes() {
                        reinterpret_cast<const void*>(&node_post_bf16_kernel<kPostMaxOB>),
                        reinterpret_cast<const void*>(&node_post_bf16_kernel<2, f16x8>),
                        reinterpret_cast<const void*>(&node_post_bf16_kernel<kPostMaxOB, f16x8>),
-                       reinterpret_cast<const void*>(&node_post_bf16_kernel<2, f16x8, true>)};
+                       reinterpret_cast<const void*>(&node_post_bf16_kernel<2, f16x8, true>),
+                       reinterpret_cast<const void*>(&node_post_bf16_kernel<2, bf16x8, false, true>),
+                       reinterpret_cast<const void*>(&node_post_bf16_kernel<2, f16x8, true, true>)};
   for (const void* f : fns) EGNN_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   return EGNN_OK;
 }
@@ -358,8 +425,14 @@ int launch_node_post_bf16(const PostParams& q, hipStream_t st, bool f16, bool sp
   if (q.h_partial && tiles * 8 <= 256 && (q.WhP / 32) % 32 == 0) hs = 8;
   const dim3 grid(tiles, hs);
   const size_t sm = nb_smem_bytes(split ? kSplitK : q.K1Q, q.HP / 32, split) + (kNodes + kThreadsN) * 4;
+  // (the branch-free gather of the HS form loads for every lane, also the clamped ones of absent nodes: with fewer nodes than one
+  // tile -- the 2-atom toy graphs -- the plain form is faster, 0.24 vs 0.22 ms per reverse step)
+  const bool hsk = hs > 1 && q.N >= kNodes;
   if (split) {
-    hipLaunchKernelGGL((node_post_bf16_kernel<2, f16x8, true>), grid, dim3(kThreadsN), sm, st, q);
+    if (hsk) hipLaunchKernelGGL((node_post_bf16_kernel<2, f16x8, true, true>), grid, dim3(kThreadsN), sm, st, q);
+    else hipLaunchKernelGGL((node_post_bf16_kernel<2, f16x8, true>), grid, dim3(kThreadsN), sm, st, q);
+  } else if (hsk && !f16 && q.HP <= 64) {
+    hipLaunchKernelGGL((node_post_bf16_kernel<2, bf16x8, false, true>), grid, dim3(kThreadsN), sm, st, q);
   } else if (f16) {
     if (q.HP <= 64) hipLaunchKernelGGL((node_post_bf16_kernel<2, f16x8>), grid, dim3(kThreadsN), sm, st, q);
     else hipLaunchKernelGGL((node_post_bf16_kernel<kPostMaxOB, f16x8>), grid, dim3(kThreadsN), sm, st, q);

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import diffusion_model_amd as dma
 from diffusion_model_amd import _lib
-H, M, W, A, T, L, B, n = 36, 256, 1024, 2, 1000, 1, 256, 64
+H, M, W, A, T, L, B, n = 36, 256, 1024, 2, 1000, 1, int(os.environ.get("EGNN_STAMP_B", "256")), 64
 torch.manual_seed(0)
 net = dma.EquivariantGNN(L, 2*H+1, W, M, 2*H+1, W, 1, H+M, W, H).cuda().eval(); net.precision = "bf16"
 for l in net.egcl_list:
