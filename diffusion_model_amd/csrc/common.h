@@ -114,6 +114,9 @@ struct egnn_ctx {
   int last_R = 64, last_nsplit_x = 1, last_path = 1;   // edge path chosen by the last launch_layer_begin
   bool sq_from_agg = false;             // node_post takes the d^2 sums from the coordinate sums' component 3
   bool small_ok = false;                // the partial slots were sized for 32-edge tiles (E <= 65536): edge_small.hip may run
+  // A layer's hidden-split node_post leaves its 8 partial h' in h_partial; inside a multi-layer call the NEXT layer's node_pre
+  // adds them up (and writes h') instead of a launch of its own (small graphs: every launch is a serial link of the step)
+  struct { bool active = false; int hs = 0; const float* b2h = nullptr; float* h_out = nullptr; } pend;
   float* h_partial = nullptr;  // [8][N][H] partial node-MLP outputs (hidden-split node_post at small N)
   float* bwd_s = nullptr;    // [nsplit][chunk edges] column-split shares of s_e (backward recompute)
   size_t cap_bwd_s = 0;
@@ -136,7 +139,7 @@ struct egnn_ctx {
 namespace egnn {
 int reserve(egnn_ctx* c);
 int launch_layer(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_scope, const float* h,
-                 const float* x, float* h_out, float* x_out, bool need_gscale = false);
+                 const float* x, float* h_out, float* x_out, bool need_gscale = false, bool defer_finish = false);
 int edge_rows_per_tile(int prec);
 // backward recompute on the forward's bf16 edge kernels (egcl_backward_edge_recompute)
 int backward_recompute_supported(egnn_ctx* c);

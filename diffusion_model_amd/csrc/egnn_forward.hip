@@ -299,17 +299,34 @@ __global__ void pack_w1_hilo(const float* __restrict__ w1catT, int H, int TC, __
 // workgroup = 32 nodes x (4 waves x NBW column blocks): NBW = 8 (1024 columns) to amortise the h tile at large N,
 // NBW = 2 (256 columns) when the whole launch is a handful of workgroups and their serial length is the layer's latency
 constexpr int kPre3Nodes = 32;
+// fin_hs > 0: h is not there yet -- the previous layer's hidden-split node_post left fin_hs partial sums in fin_partial
+// [fin_hs][N][H]; this kernel adds them up in split order (+ the bias fin_b2h: what node_post_finish_kernel does) and the
+// workgroups of column block 0 write h' to h_write (the next node_post and the caller read it there).
 template <int NBW>
 __global__ __launch_bounds__(kThreads) void node_pre_hilo_kernel(const float* __restrict__ h, int N, int H,
                                                                  const bf16x8* __restrict__ w1hl,
                                                                  const float* __restrict__ b1cat, int TC,
-                                                                 _Float16* __restrict__ table) {
+                                                                 _Float16* __restrict__ table, int fin_hs,
+                                                                 const float* __restrict__ fin_partial,
+                                                                 const float* __restrict__ fin_b2h, float* __restrict__ h_write) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* hs = reinterpret_cast<float*>(smem_raw);   // [48][33] transposed h tile, zero-padded to K = 48
   const int n0 = blockIdx.x * kPre3Nodes;
   for (int i = threadIdx.x; i < kPre3Nodes * 48; i += kThreads) {
     const int node = i / 48, k = i % 48, n = n0 + node;
-    hs[k * 33 + node] = (n < N && k < H) ? h[(size_t)n * H + k] : 0.f;
+    float v = 0.f;
+    if (n < N && k < H) {
+      if (fin_hs > 0) {
+        float pv[8];   // (the split is 8-fold: all loads first, then the sum in split order -- a load + add loop is 8 serial round trips)
+#pragma unroll
+        for (int sp = 0; sp < 8; ++sp) pv[sp] = fin_partial[((size_t)(sp < fin_hs ? sp : 0) * N + n) * H + k];
+        v = fin_b2h[k];
+#pragma unroll
+        for (int sp = 0; sp < 8; ++sp) v += sp < fin_hs ? pv[sp] : 0.f;
+        if (blockIdx.y == 0) h_write[(size_t)n * H + k] = v;
+      } else v = h[(size_t)n * H + k];
+    }
+    hs[k * 33 + node] = v;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
@@ -1070,12 +1087,18 @@ static int launch_node_pre_f16(egnn_ctx* c, hipStream_t st, int layer, const flo
     const size_t sm = (size_t)48 * 33 * 4 + (size_t)4 * 32 * (128 + 8) * 2;
     const bf16x8* w1hl = reinterpret_cast<const bf16x8*>(c->layers[layer].w1hl_bf16);
     _Float16* tab = reinterpret_cast<_Float16*>(c->table);
+    // a pending hidden-split finish of the previous layer (c->pend) rides in this launch
+    const bool fin = c->pend.active && c->pend.h_out == h;
+    const int fhs = fin ? c->pend.hs : 0;
+    const float* fb = fin ? c->pend.b2h : nullptr;
+    float* fw = fin ? c->pend.h_out : nullptr;
+    if (fin) c->pend.active = false;
     if (ntile * (c->TC / 1024) >= 256)
       hipLaunchKernelGGL(node_pre_hilo_kernel<8>, dim3(ntile, (c->TC + 1023) / 1024), dim3(kThreads), sm, st, h, N, c->H, w1hl,
-                         b1cat, c->TC, tab);
+                         b1cat, c->TC, tab, fhs, c->h_partial, fb, fw);
     else
       hipLaunchKernelGGL(node_pre_hilo_kernel<2>, dim3(ntile, (c->TC + 255) / 256), dim3(kThreads), sm, st, h, N, c->H, w1hl,
-                         b1cat, c->TC, tab);
+                         b1cat, c->TC, tab, fhs, c->h_partial, fb, fw);
   } else if (c->H <= 64) {
     dim3 grid((N + kPre2Nodes - 1) / kPre2Nodes, (c->TC + kPre2Cols - 1) / kPre2Cols);
     const size_t sm = (size_t)((c->H + 1) & ~1) * 33 * sizeof(float);
@@ -1187,6 +1210,13 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
   const float* b1cat = lp.b1cat;
   if (path >= 4) use_scaled_pack(c, layer, p, w1catT, b1cat);
 
+  // a pending hidden-split finish (previous layer of a multi-layer call) is fused into the half-precision node_pre for H <= 48;
+  // every other case runs the finish launch now
+  if (c->pend.active && !((path == 4 || path == 6) && c->H <= 48 && c->pend.h_out == h)) {
+    int rc = launch_node_post_finish(N, c->H, c->pend.hs, c->h_partial, c->pend.b2h, c->pend.h_out, st);
+    c->pend.active = false;
+    if (rc) return rc;
+  }
   prof_begin(c, st, 1);
   {
     if (path == 5) {   // bf16x3: exact fp32 table of the scaled first layers
@@ -1313,7 +1343,7 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
 
 // Stage 2: node_post with the normaliser sums in c->gscale (possibly replaced by a cross-rank total).
 int launch_layer_end(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_scope, const float* h, const float* x,
-                     float* h_out, float* x_out) {
+                     float* h_out, float* x_out, bool defer_finish = false) {
   const LayerPack& lp = c->layers[layer];
   const int N = c->N, R = c->last_R, nsplit_x = c->last_nsplit_x;
   const size_t agg_x_stride = (size_t)c->cap_nodes * 4, part_x_stride = (c->cap_tiles + 1) * 2 * 4;
@@ -1339,15 +1369,16 @@ int launch_layer_end(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_
     PostParams qs = q;
     qs.w1h_bf16 = lp.w1h_f16k; qs.w2h_bf16p = lp.w2h_f16p; qs.w1h_lo = lp.w1h_f16k_lo; qs.w2h_lo = lp.w2h_f16p_lo;
     const bool half_path = (prec == EGNN_PREC_F16 && c->last_path == 6) || (prec == EGNN_PREC_BF16X3 && c->last_path == 5);
+    int hs_used = 1;
     if (half_path && f16_node == 2 && node_post_split_supported(qs)) {
-      int rc = launch_node_post_bf16(qs, st, true, true);
+      int rc = launch_node_post_bf16(qs, st, true, true, defer_finish, &hs_used);
       if (rc) return rc;
     } else if (prec == EGNN_PREC_F16 && c->last_path == 6 && f16_node == 1 && node_post_bf16_supported(q)) {
       q.w1h_bf16 = lp.w1h_f16; q.w2h_bf16p = lp.w2h_f16p;
       int rc = launch_node_post_bf16(q, st, true);
       if (rc) return rc;
     } else if (prec == EGNN_PREC_BF16 && node_post_bf16_supported(q)) {
-      int rc = launch_node_post_bf16(q, st);
+      int rc = launch_node_post_bf16(q, st, false, false, defer_finish, &hs_used);
       if (rc) return rc;
     } else {
       if (q.sq_from_agg) {   // the fp32 node kernel reads gscale
@@ -1358,17 +1389,24 @@ int launch_layer_end(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_
       hipLaunchKernelGGL(node_post_kernel, dim3((N + kPostNodes - 1) / kPostNodes), dim3(kThreads),
                          post_smem_bytes(c->K1P, c->WhP), st, q);
     }
+    if (defer_finish && hs_used > 1) {   // the next layer's node_pre (or launch_layer_begin's flush) adds the partials up
+      c->pend.active = true; c->pend.hs = hs_used; c->pend.b2h = lp.b2h; c->pend.h_out = h_out;
+    }
     prof_end(c, st);
     EGNN_HIP(hipGetLastError());
   }
   return EGNN_OK;
 }
 
+// defer_finish: only from a loop that launches the NEXT layer on h_out right away (egnn_forward, the sampler's step)
 int launch_layer(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_scope, const float* h,
-                 const float* x, float* h_out, float* x_out, bool need_gscale) {
+                 const float* x, float* h_out, float* x_out, bool need_gscale, bool defer_finish) {
+  if (layer == 0) c->pend.active = false;   // (a call that failed half-way leaves nothing behind)
+  static const bool defer_ok = !(getenv("EGNN_DEFER_FINISH") && atoi(getenv("EGNN_DEFER_FINISH")) == 0);   // A/B switch
+  defer_finish = defer_finish && defer_ok;
   int rc = launch_layer_begin(c, st, layer, prec, norm_scope, h, x, need_gscale);
   if (rc) return rc;
-  return launch_layer_end(c, st, layer, prec, norm_scope, h, x, h_out, x_out);
+  return launch_layer_end(c, st, layer, prec, norm_scope, h, x, h_out, x_out, defer_finish);
 }
 
 }  // namespace egnn
@@ -1692,7 +1730,7 @@ int egnn_forward(egnn_ctx* c, void* stream, int prec, int norm_scope, const floa
   for (int l = 0; l < c->L; ++l) {
     float* ho = (l == c->L - 1) ? h_out : c->h_tmp[l & 1];
     float* xo = (l == c->L - 1) ? x_out : c->x_tmp[l & 1];
-    if ((rc = launch_layer(c, st, l, prec, norm_scope, hc, xc, ho, xo))) return rc;
+    if ((rc = launch_layer(c, st, l, prec, norm_scope, hc, xc, ho, xo, false, l + 1 < c->L))) return rc;
     hc = ho; xc = xo;
   }
   return EGNN_OK;

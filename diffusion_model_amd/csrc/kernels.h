@@ -307,7 +307,10 @@ struct PostParams {
   float *h_out, *x_out;
   float* h_partial;   // [8][N][H] scratch of the hidden-split form (small N), or null
 };
-int launch_node_post_bf16(const PostParams& q, hipStream_t st, bool f16 = false, bool split = false);
+// hs_out: the hidden split that was launched (1 = none); defer_finish: leave the partial h' of a split launch to the caller
+int launch_node_post_bf16(const PostParams& q, hipStream_t st, bool f16 = false, bool split = false, bool defer_finish = false,
+                          int* hs_out = nullptr);
+int launch_node_post_finish(int N, int H, int hs, const float* partial, const float* b2h, float* h_out, hipStream_t st);
 bool node_post_split_supported(const PostParams& q);   // head + remainder fp16 operands, three MFMAs per product (node_bf16.hip)
 int node_post_split_k();
 bool node_post_bf16_supported(const PostParams& q);

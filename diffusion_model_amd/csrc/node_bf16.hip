@@ -241,21 +241,36 @@ __global__ __launch_bounds__(kThreadsN, (OBT > 2 ? 1 : 2)) void node_post_bf16_k
     const int node = tid / 3, d = tid % 3, n = n0 + node;
     if (n < p.N) {
       const int t0 = s_t0[node], t1 = s_t1[node];
+      // the column-split copies of the coordinate sums (at most 4): every load unconditional from a selected address -- the
+      // node's own slot or the first two tile partials -- so that they fly together (a branch per copy was a serial round
+      // trip per copy in the small-graph regime); more than two tiles per node (degree > 2 R) adds the rest in a loop
+      const bool has = t0 >= 0, one = t0 == t1;
+      const float xin = p.x[3 * n + d];
+      float va[4], vb[4];
+#pragma unroll
+      for (int hs = 0; hs < 4; ++hs) {
+        const bool on = has && hs < p.nsplit_x;
+        const float* ax = p.agg_x + (size_t)(on ? hs : 0) * p.agg_x_stride;
+        const float* px = p.part_x + (size_t)(on ? hs : 0) * p.part_x_stride;
+        const float* a = one || !on ? ax + (size_t)n * 4 + d : px + ((size_t)t0 * 2 + 1) * 4 + d;
+        const float* b = on && !one ? px + ((size_t)(t0 + 1) * 2) * 4 + d : ax + (size_t)n * 4 + d;
+        const float x0 = *a, x1 = *b;
+        va[hs] = on ? x0 : 0.f;
+        vb[hs] = on && !one ? x1 : 0.f;
+      }
       float v = 0.f;
-      if (t0 >= 0) {
-        for (int hs = 0; hs < p.nsplit_x; ++hs) {
-          const float* ax = p.agg_x + (size_t)hs * p.agg_x_stride;
+#pragma unroll
+      for (int hs = 0; hs < 4; ++hs) {
+        float w = va[hs] + vb[hs];
+        if (has && hs < p.nsplit_x && t1 > t0 + 1) {
           const float* px = p.part_x + (size_t)hs * p.part_x_stride;
-          if (t0 == t1) v += ax[(size_t)n * 4 + d];
-          else {
-            v += px[((size_t)t0 * 2 + 1) * 4 + d];
-            for (int t = t0 + 1; t <= t1; ++t) v += px[((size_t)t * 2) * 4 + d];
-          }
+          for (int t = t0 + 2; t <= t1; ++t) w += px[((size_t)t * 2) * 4 + d];
         }
+        v += w;
       }
       const float sq = p.sq_from_agg ? gsq[node] : p.gscale[p.per_graph ? p.node_graph[n] : 0];
       const float g = 1.0f / (sqrtf(sq) + 1.0f);
-      p.x_out[3 * n + d] = p.x[3 * n + d] + v * g;
+      p.x_out[3 * n + d] = xin + v * g;
     }
   }
   __syncthreads();
@@ -384,8 +399,12 @@ __global__ void node_post_finish_kernel(int N, int H, int hsplit, const float* _
                                         const float* __restrict__ b2h, float* __restrict__ h_out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N * H) return;
+  float pv[8];   // (the split is at most 8-fold: all loads first, then the sum in split order)
+#pragma unroll
+  for (int s = 0; s < 8; ++s) pv[s] = partial[(size_t)(s < hsplit ? s : 0) * N * H + i];
   float v = b2h[i % H];
-  for (int s = 0; s < hsplit; ++s) v += partial[(size_t)s * N * H + i];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) v += s < hsplit ? pv[s] : 0.f;
   h_out[i] = v;
 }
 
@@ -416,7 +435,13 @@ bool node_post_split_supported(const PostParams& q) {
 int node_post_split_k() { return kSplitK; }
 
 // f16: q.w1h_bf16 / q.w2h_bf16p are the fp16 fragment streams (precision fp16); split: + q.w1h_lo / q.w2h_lo (K = kSplitK)
-int launch_node_post_bf16(const PostParams& q, hipStream_t st, bool f16, bool split) {
+int launch_node_post_finish(int N, int H, int hs, const float* partial, const float* b2h, float* h_out, hipStream_t st) {
+  hipLaunchKernelGGL(node_post_finish_kernel, dim3((N * H + 255) / 256), dim3(256), 0, st, N, H, hs, partial, b2h, h_out);
+  EGNN_HIP(hipGetLastError());
+  return EGNN_OK;
+}
+
+int launch_node_post_bf16(const PostParams& q, hipStream_t st, bool f16, bool split, bool defer_finish, int* hs_out) {
   const int tiles = (q.N + kNodes - 1) / kNodes;
   // Few node tiles (small graphs): a layer would wait for ONE workgroup's serial chain over all hidden blocks (40 us).
   // Split the hidden units over `hs` workgroups per tile (partial h' to scratch) and add them up in a second tiny launch:
@@ -438,7 +463,8 @@ int launch_node_post_bf16(const PostParams& q, hipStream_t st, bool f16, bool sp
     else hipLaunchKernelGGL((node_post_bf16_kernel<kPostMaxOB, f16x8>), grid, dim3(kThreadsN), sm, st, q);
   } else if (q.HP <= 64) hipLaunchKernelGGL(node_post_bf16_kernel<2>, grid, dim3(kThreadsN), sm, st, q);
   else hipLaunchKernelGGL(node_post_bf16_kernel<kPostMaxOB>, grid, dim3(kThreadsN), sm, st, q);
-  if (hs > 1)
+  if (hs_out) *hs_out = hs;
+  if (hs > 1 && !defer_finish)
     hipLaunchKernelGGL(node_post_finish_kernel, dim3((q.N * q.H + 255) / 256), dim3(256), 0, st, q.N, q.H, hs, q.h_partial,
                        q.b2h, q.h_out);
   EGNN_HIP(hipGetLastError());

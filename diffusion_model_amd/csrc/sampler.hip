@@ -299,7 +299,7 @@ static int enqueue_step(egnn_ctx* c, hipStream_t st, int prec, int norm_scope, c
   for (int l = 0; l < c->L; ++l) {
     float* ho = (l == c->L - 1) ? s.h_out : c->h_tmp[l & 1];
     float* xo = (l == c->L - 1) ? s.x_out : c->x_tmp[l & 1];
-    if ((rc = launch_layer(c, st, l, prec, norm_scope, hc, xc, ho, xo))) return rc;
+    if ((rc = launch_layer(c, st, l, prec, norm_scope, hc, xc, ho, xo, false, l + 1 < c->L))) return rc;
     hc = ho; xc = xo;
   }
   StepParams p = make_params(c);
@@ -540,7 +540,7 @@ int egnn_sampler_final(egnn_ctx* c, void* stream, int prec, int norm_scope, cons
   for (int l = 0; l < c->L; ++l) {
     float* ho = (l == c->L - 1) ? s.h_out : c->h_tmp[l & 1];
     float* xo = (l == c->L - 1) ? s.x_out : c->x_tmp[l & 1];
-    if ((rc = launch_layer(c, st, l, prec, norm_scope, hc, xc, ho, xo))) return rc;
+    if ((rc = launch_layer(c, st, l, prec, norm_scope, hc, xc, ho, xo, false, l + 1 < c->L))) return rc;
     hc = ho; xc = xo;
   }
   StepParams p = make_params(c);
