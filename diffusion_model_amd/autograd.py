@@ -38,6 +38,7 @@ EDGE_CHUNK = int(os.environ.get("EGNN_BWD_CHUNK", 1 << 20))   # edges per backwa
 # training.GradAllReducer.arm() puts itself here: the backward below hands it every layer's parameter gradients as soon
 # as they are final, so the bucket's all-reduce runs under the backward of the earlier layers
 ACTIVE_REDUCER = None
+LAST_FIRST_LAYER_FORM = None   # how the last edge backward took the first Linear layers: None (chain) / "graph" / "reduce" (tests)
 
 
 def _segment_scale(S, scope_graph, node_graph):
@@ -73,6 +74,22 @@ def _hip_gemm_shapes(H, Wx, Wm, M):
     """the bf16 backward's GEMMs run on the library's own kernels (gemm_tn.hip, gemm_rows.hip) when the widths fit their
     tiles: reduction widths multiples of 64, output widths multiples of 256 / 128"""
     return Wx % 256 == 0 and Wm % 256 == 0 and M % 256 == 0 and 2 * H + 2 <= 128
+
+
+def _graph_chunks(plan, rows):
+    """[(first edge, edges)] chunks of WHOLE graphs with at most `rows` edges each (None: a graph alone has more)"""
+    import bisect
+    gep = getattr(plan, "graph_edge_ptr", None)
+    if gep is None:
+        return None
+    out, a, E = [], 0, gep[-1]
+    while a < E:
+        b = gep[bisect.bisect_right(gep, a + rows) - 1]
+        if b <= a:
+            return None
+        out.append((a, b - a))
+        a = b
+    return out
 
 
 def _wgrad(g, a, n_pad, splits):
@@ -131,26 +148,35 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_
     g_am, g_ax = g_am.contiguous(), g_ax.contiguous()
     E = dst32.numel()
     rows = ws.rows
-    # First Linear layers factorised as the forward factorises them (csrc/edge_bwd_first.hip): per-node sums of dL/da1 over the
-    # edges a node receives / sends in ONE pass, then node-level products -- instead of gather + 2 wgrad GEMMs over all edges +
-    # the row-streaming dgrad GEMM + the feature half of the scatter.  Batches of graphs of at most 64 nodes (the sender sums of a
-    # graph live in LDS).  OPT-IN (EGNN_BWD_FIRST=1): correct, deterministic and tested against the oracle's autograd, but the
-    # one-pass kernel runs at 2.1 TB/s (a chain of per-node memory latencies) and the step is 62.8 ms with it against 59.5 ms
-    # without (profiles/r04f_first_layer_factorised.txt); the gain it is after needs dL/da1 not to be written at all, i.e. the
-    # same sums inside the dgrad kernel's epilogue.
-    first = (hip and plan is not None and getattr(plan, "max_graph_nodes", 1 << 30) <= 64 and Wx % 256 == 0 and Wm % 256 == 0 and
-             os.environ.get("EGNN_BWD_FIRST", "0") == "1")
+    # First Linear layers factorised as the forward factorises them: per-node sums of dL/da1 over the edges a node receives /
+    # sends, then node-level products -- instead of gather + 2 wgrad GEMMs over all edges + the row-streaming dgrad GEMM + the
+    # feature half of the scatter.  Batches of graphs of at most 64 nodes.  Two forms:
+    #   "graph"  (default; EGNN_BWD_GRAPH=0 turns it off): the sums are taken INSIDE the dgrad kernel's epilogue
+    #            (csrc/edge_bwd_dgrad_graph.hip, one workgroup per graph and 256 hidden units): dL/da1 is never written;
+    #   "reduce" (EGNN_BWD_FIRST=1): one extra pass over the stored dL/da1 (csrc/edge_bwd_first.hip) -- correct and tested, but
+    #            slower than the chain it replaces (profiles/r04f_first_layer_factorised.txt); kept as the reference form.
+    first = None
+    chunks = [(a, min(rows, E - a)) for a in range(0, E, rows)]
+    if hip and plan is not None and getattr(plan, "max_graph_nodes", 1 << 30) <= 64 and Wx % 256 == 0 and Wm % 256 == 0:
+        if os.environ.get("EGNN_BWD_FIRST", "0") == "1":
+            first = "reduce"
+        elif os.environ.get("EGNN_BWD_GRAPH", "1") != "0" and fused is not None:
+            cut = _graph_chunks(plan, rows)   # chunks of whole graphs
+            if cut is not None:
+                first, chunks = "graph", cut
+    global LAST_FIRST_LAYER_FORM
+    LAST_FIRST_LAYER_FORM = first
     if first:
         N, nparts = h.shape[0], (Wx + Wm) // 256
         Gd_x, Gs_x, Gd_m, Gs_m = (torch.zeros(N, w, **f32) for w in (Wx, Wx, Wm, Wm))
         cd_x, cd_m = torch.zeros(plan.B, Wx, **f32), torch.zeros(plan.B, Wm, **f32)
         gd2_part = torch.empty(nparts * min(rows, E), **f32)
+    if first == "reduce":
         wdx_f = lin_x0.weight.detach()[:, 2 * H].float().contiguous()
         wdm_f = lin_m0.weight.detach()[:, 2 * H].float().contiguous()
     if fused is not None:
         _lib.check(L.egcl_backward_table(fused[0], st, fused[1], P(h)))
-    for a in range(0, E, rows):
-        n = min(rows, E - a)
+    for a, n in chunks:
         n_pad = _round_up(n, 64)
         d32, s32 = dst32[a:a + n], src32[a:a + n]
         if kept is not None:   # chunk views of the layer-long buffers (their rows beyond E are zero)
@@ -189,7 +215,11 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_
         else:
             g_w2x += _wgrad(A2X, S1X, n_pad, 16)
             g_w2m += _wgrad(A2M, S1M, n_pad, 32)
-        if fused is not None:
+        if first == "graph":
+            # dgrad of the second layers, SiLU'(a1) and the first layers' per-node sums in one kernel: no dL/da1 in memory
+            _lib.check(L.egcl_backward_dgrad_reduce(fused[0], st, fused[1], P(x), a, n, P(a2x), P(a2m), P(Gd_x), P(Gs_x), P(Gd_m),
+                                                    P(Gs_m), P(cd_x), P(cd_m), P(gd2_part)))
+        elif fused is not None:
             # dgrad of the second layers with SiLU'(a1) in the epilogue, on MFMA (no [n, W] round trip in between)
             _lib.check(L.egcl_backward_dgrad(fused[0], st, fused[1], P(x), a, n, P(a2x), P(a2m), P(g1x), P(g1m)))
         else:
@@ -199,9 +229,10 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_
             _lib.check(L.egcl_backward_l1_grad(st, prec, n, Wm, P(d32), P(s32), P(Pm), P(Qm), P(wdm), P(d2), P(g1m)))
         # first Linear layers: wgrad against in = [h_i | h_j | d2 | 1], dgrad back to the gathered inputs
         if first:
-            _lib.check(L.egcl_backward_first_reduce(st, plan.B, plan.max_graph_nodes, a, n, P(plan.graph_ptr), P(plan.row_ptr),
-                                                    P(src32), P(x), P(g1x), Wx, P(g1m), Wm, P(wdx_f), P(wdm_f), P(Gd_x), P(Gs_x),
-                                                    P(Gd_m), P(Gs_m), P(cd_x), P(cd_m), P(gd2_part)))
+            if first == "reduce":
+                _lib.check(L.egcl_backward_first_reduce(st, plan.B, plan.max_graph_nodes, a, n, P(plan.graph_ptr), P(plan.row_ptr),
+                                                        P(src32), P(x), P(g1x), Wx, P(g1m), Wm, P(wdx_f), P(wdm_f), P(Gd_x),
+                                                        P(Gs_x), P(Gd_m), P(Gs_m), P(cd_x), P(cd_m), P(gd2_part)))
             _lib.check(L.egcl_backward_scatter_geom(st, n, nparts, P(d32), P(s32), P(x), P(gd2_part), P(g_diff), P(g_S),
                                                     P(node_seg), P(g_x)))
             continue

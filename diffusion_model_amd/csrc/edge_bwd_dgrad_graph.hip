@@ -1,0 +1,355 @@
+// Training backward of the edge MLPs' first half WITHOUT dL/da1 in HBM (round 4): the dgrad of the second Linear layers fused with
+// the first layer's SiLU derivative (edge_bwd_dgrad.hip) AND with the four reductions the first Linear layers need
+// (edge_bwd_first.hip: the backward of the forward's first-layer factorisation),
+//
+//     g1[e][k]  = ( sum_n dL/da2[e][n] W2[n][k] ) SiLU'(a1[e][k])          a1 = P[dst e] + Q[src e] + wd d2_e      (never stored)
+//     Gd[n][k]  = sum over the edges n receives of g1          Gs[n][k] = sum over the edges n sends of g1
+//     cd[k]     = sum_e g1[e][k] d2_e                           gd2[e]   = sum_k g1[e][k] wd[k]
+//
+// for one edge MLP (mlp_x: n, k < Wx; mlp_m: n < M, k < Wm; EquivariantGraphNeuralNetwork.py:13-25 under autograd).  Round 3 wrote
+// g1 ([edges, 1024] bf16, 2 GB per MLP and layer) and read it three times (two weight-gradient GEMMs, the row-streaming GEMM).
+//
+// Workgroup = (graph, 256-column slice of k), persistent over the graph's 128-edge tiles; 8 waves, wave w owns columns
+// [32 w, 32 w + 32) of the slice for all 128 rows (4 accumulator tiles of 32 x 32).  What makes the fusion fit:
+//   * the graph's slice of the first-layer table (P and Q of its <= 64 nodes x 256 columns, fp16, 66 KB) is staged in LDS once per
+//     workgroup, so SiLU'(a1) is evaluated IN ACCUMULATOR LAYOUT from 2-byte LDS reads -- no transpose, no global gathers;
+//   * an accumulator tile (column on the lane, rows in the registers) is exactly the B operand of a product that sums over its
+//     rows (cdna_hip_programming.md "an accumulator tile as the next MFMA's operand"; node_bf16.hip): Gd = D^T g1 and
+//     Gs = S^T g1 with the one-hot incidence matrices D, S ([local node][edge of the tile], bf16 images in LDS that the tile's
+//     prologue sets and its epilogue clears: 2 x 128 two-byte stores) are four MFMAs per 32 rows and live in 64 accumulator
+//     registers per wave for the whole graph -- no LDS accumulator, no atomics (ds_add_f32 costs ~180 cycles per instruction:
+//     edge_bwd_first.hip);
+//   * cd is a per-lane sum (column on the lane), gd2 a row sum over lanes (the forward's butterfly).
+// K loop: edge_bwd_dgrad.hip's (3-deep LDS ring of dL/da2 chunks, W2 packed transposed), at one 32-column block per wave.
+// Graphs of more than 64 nodes, or edge chunks that cut through graphs, take the round-3 chain.
+#include <stdlib.h>
+
+#include "kernels.h"
+
+namespace egnn {
+namespace {
+
+constexpr int kTG = 512, kRG = 128, kRBG = 4, kRPADG = kRG + 1, kKCG = 64, kNodesG = 64, kColsG = 256;
+constexpr size_t kA1G = (size_t)8 * kRPADG * 16;   // one A chunk [8 k-groups][129][8 bf16]
+constexpr int kRingG = 3;
+constexpr int kTabStride = kColsG * 2 + 16;        // bytes per node of the staged table slice (+16: rows 4 apart on different banks)
+constexpr int kHotStride = kRG * 2 + 16;           // bytes per node of a one-hot image (68 dwords: b128 reads of 16 nodes cover all banks)
+// LDS carve (byte offsets)
+constexpr size_t kGOffPo = 0;                                  // int[R]   byte offset of the receiver's P row (row 64 = "no edge")
+constexpr size_t kGOffQo = kGOffPo + kRG * 4;                  // int[R]   byte offset of the sender's Q row
+constexpr size_t kGOffD2 = kGOffQo + kRG * 4;                  // float[R]
+constexpr size_t kGOffWd = kGOffD2 + kRG * 4;                  // float[256] scaled d^2 column of this slice
+constexpr size_t kGOffX = kGOffWd + kColsG * 4;                // float[64][3]
+constexpr size_t kGOffPart = kGOffX + kNodesG * 3 * 4;         // float[8][R] per-wave row sums
+constexpr size_t kGOffP = kGOffPart + 8 * kRG * 4;             // fp16[65][256 (+8)]
+constexpr size_t kGOffQ = kGOffP + (size_t)(kNodesG + 1) * kTabStride;
+constexpr size_t kGOffHd = kGOffQ + (size_t)kNodesG * kTabStride;    // bf16[64][128 (+8)] receiver one-hot, rows in MFMA k order
+constexpr size_t kGOffHs = kGOffHd + (size_t)kNodesG * kHotStride;   // sender one-hot
+constexpr size_t kGOffA1 = kGOffHs + (size_t)kNodesG * kHotStride;   // ring
+constexpr size_t kSmemG = kGOffA1 + kRingG * kA1G;
+static_assert(kSmemG <= 160 * 1024, "LDS budget");
+static_assert(kGOffP % 16 == 0 && kGOffHd % 16 == 0 && kGOffA1 % 16 == 0, "16-byte LDS accesses");
+
+struct DgradGraphParams {
+  int N, B;                        // nodes; graphs
+  const int *graph_ptr, *row_ptr;  // [B+1] node ranges; [N+1] edge ranges (ids in the plan's edge list)
+  const int *edge_dst, *edge_src;  // the plan's edge list
+  int e_base, n_edges;             // the chunk [e_base, e_base + n_edges): whole graphs; dL/da2 rows are chunk-relative
+  const float* x;                  // [N][3]
+  const void* table;               // fp16 [N][TC] (scaled by -log2 e)
+  int TC, offP, offQ;
+  const float* wd;                 // [KP] scaled d^2 column
+  const void* g_a2;                // bf16 [n_edges][Kd]
+  int Kd;
+  const void* w2t;                 // bf16 fragments, transposed pack [KP/32][Kd/16][64][8]
+  int KP;
+  float *Gd, *Gs;                  // [N][KP] fp32 (assigned: every (node, column) by exactly one workgroup)
+  float* cd;                       // [B][KP]
+  float* gd2_part;                 // [KP / 256][n_edges] shares of dL/d(d2_e) (already in unscaled units)
+};
+
+// position of tile row `row` inside a one-hot image: the k order of the accumulator-as-B-operand products (k-step s of row block
+// rb holds rows 32 rb + 16 s + 8 (j >> 2) + 4 hh + (j & 3) at k = 8 hh + j)
+__device__ __forceinline__ int hot_pos(int row) {
+  const int o = row & 15;
+  return (row & ~15) + 8 * ((o >> 2) & 1) + 4 * (o >> 3) + (o & 3);
+}
+
+__global__ __launch_bounds__(kTG, 2) void edge_dgrad_graph_kernel(const DgradGraphParams p) {
+  constexpr int NW = 8, PP = 2, NSET = 3;
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  typedef __attribute__((ext_vector_type(4))) int i32x4;
+  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* const s_po = reinterpret_cast<int*>(smem + kGOffPo);
+  int* const s_qo = reinterpret_cast<int*>(smem + kGOffQo);
+  float* const s_d2 = reinterpret_cast<float*>(smem + kGOffD2);
+  float* const s_wd = reinterpret_cast<float*>(smem + kGOffWd);
+  float* const s_x = reinterpret_cast<float*>(smem + kGOffX);
+  float* const s_part = reinterpret_cast<float*>(smem + kGOffPart);
+  char* const s_a1 = smem + kGOffA1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int nslice = p.KP / kColsG;
+  const int j = xcd_tile(blockIdx.x, gridDim.x);   // the column slices of a graph read the same dL/da2 rows: same XCD (one L2)
+  const int g = j / nslice, slice = j - g * nslice;
+  const int n0 = p.graph_ptr[g], nn = p.graph_ptr[g + 1] - n0;
+  const int e_lo = p.row_ptr[n0], e_hi = p.row_ptr[n0 + nn];
+  // (uniform) no edges / not this chunk's graph / a graph this kernel is not for (the caller's plan keeps those away)
+  if (e_hi <= e_lo || e_lo < p.e_base || e_hi > p.e_base + p.n_edges || nn > kNodesG) return;
+
+  // ---- once per workgroup: the graph's table slice, its coordinates, the slice's d^2 weights, empty one-hot images ----
+  {
+    const char* tab = static_cast<const char*>(p.table);
+    for (int i = tid; i < kNodesG * 32 * 2; i += kTG) {   // 16-byte pieces: [P | Q][64 nodes][32 pieces]
+      const int which = i / (kNodesG * 32), rem = i - which * (kNodesG * 32), node = rem >> 5, piece = rem & 31;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (node < nn)
+        v = *reinterpret_cast<const u32x4*>(tab + ((size_t)(n0 + node) * p.TC + (which ? p.offQ : p.offP) + slice * kColsG + piece * 8) * 2);
+      *reinterpret_cast<u32x4*>(smem + (which ? kGOffQ : kGOffP) + (size_t)node * kTabStride + piece * 16) = v;
+    }
+    // P row 64 = "no edge": -log2(e) a1 = +60000 gives exp2 = inf, sigmoid = 0, SiLU' = 0 exactly
+    if (tid < kColsG) reinterpret_cast<_Float16*>(smem + kGOffP + (size_t)kNodesG * kTabStride)[tid] = (_Float16)60000.0f;
+    for (int i = tid; i < 2 * kNodesG * kHotStride / 16; i += kTG) reinterpret_cast<u32x4*>(smem + kGOffHd)[i] = u32x4{0u, 0u, 0u, 0u};
+    for (int i = tid; i < nn * 3; i += kTG) s_x[i] = p.x[(size_t)3 * n0 + i];
+    if (tid < kColsG) s_wd[tid] = p.wd[slice * kColsG + tid];
+  }
+  // persistent accumulators: receive / send sums of the graph's nodes x this wave's 32 columns (node in the register, column on the lane)
+  f32x16 gd[2], gs[2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { gd[mb][i] = 0.f; gs[mb][i] = 0.f; }
+  f32x2 cd2 = {0.f, 0.f};
+  const int col = 32 * wave + r;                      // this lane's column inside the slice
+  const unsigned colb = 2u * (unsigned)col;
+  const int NC = p.Kd / kKCG, KS = p.Kd / 16;
+  const int brow = tid >> 3, kg = tid & 7;
+  const rsrc_t rs_g = make_rsrc(p.g_a2, (unsigned)((size_t)p.n_edges * p.Kd * 2));   // rows past the chunk read as zero
+  const rsrc_t rs_w = make_rsrc(p.w2t, (unsigned)((size_t)p.KP * p.Kd * 2));
+  const unsigned vstep = (unsigned)(8 * NW) * (unsigned)p.Kd * 2u;
+  char* const slot0 = s_a1 + ((size_t)kg * kRPADG + brow) * 16;
+  constexpr unsigned kSlotStep = 8 * NW * 16;
+  const unsigned lane16 = lane * 16u;
+  const unsigned lds_a1_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(s_a1 + ((size_t)hh * kRPADG + r) * 16);
+  const int colblk0 = slice * NW + wave;
+  const unsigned w0off = (unsigned)colblk0 * KS * 1024u;
+  float* const part_out = p.gd2_part + (size_t)slice * p.n_edges;
+  const char* const hot_rd = smem + kGOffHd + (size_t)r * kHotStride + 16 * hh;   // this lane's A-operand pieces of the one-hot images
+
+  const int ntiles = (e_hi - e_lo + kRG - 1) / kRG;
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int e0 = e_lo + tile * kRG;
+    const int nvalid = min(kRG, e_hi - e0);
+    __syncthreads();   // the previous tile's images are cleared and its row arrays read; (first tile) the staged data are complete
+    if (tid < kRG) {
+      int dl = kNodesG, sl = 0;
+      float dd = 0.f;
+      if (tid < nvalid) {
+        dl = p.edge_dst[e0 + tid] - n0;
+        sl = p.edge_src[e0 + tid] - n0;
+        const float dx = s_x[3 * dl] - s_x[3 * sl], dy = s_x[3 * dl + 1] - s_x[3 * sl + 1], dz = s_x[3 * dl + 2] - s_x[3 * sl + 2];
+        const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);   // norm(...)**2 as in the forward (:56)
+        dd = nrm * nrm;
+        const int pos = hot_pos(tid);
+        *reinterpret_cast<unsigned short*>(smem + kGOffHd + (size_t)dl * kHotStride + 2 * pos) = 0x3F80;   // bf16 1.0
+        *reinterpret_cast<unsigned short*>(smem + kGOffHs + (size_t)sl * kHotStride + 2 * pos) = 0x3F80;
+      }
+      s_po[tid] = (int)kGOffP + dl * kTabStride;
+      s_qo[tid] = (int)kGOffQ + sl * kTabStride;
+      s_d2[tid] = dd;
+    }
+    // ---- K loop (edge_bwd_dgrad.hip at one column block per wave, 8 waves): acc = dL/da2 tile . W2 slice ----
+    f32x16 acc[kRBG];
+#pragma unroll
+    for (int rb = 0; rb < kRBG; ++rb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[rb][i] = 0.f;
+    const unsigned vrow0 = (unsigned)(e0 - p.e_base + brow) * (unsigned)p.Kd * 2u + (unsigned)kg * 16u;
+    auto gload = [&](const unsigned vrow, const int cq) {
+      const int c = cq < NC ? cq : NC - 1;   // past the end: a harmless repeat of the last chunk
+      return ldbuf_bf16x8(rs_g, vrow, (unsigned)c * kKCG * 2u);
+    };
+    bf16x8 gsr[NSET][PP];
+#pragma unroll
+    for (int c0 = 0; c0 < 2; ++c0) {
+#pragma unroll
+      for (int i = 0; i < PP; ++i) gsr[0][i] = gload(vrow0 + i * vstep, c0);
+#pragma unroll
+      for (int i = 0; i < PP; ++i) *reinterpret_cast<bf16x8*>(slot0 + i * kSlotStep + c0 * kA1G) = gsr[0][i];
+    }
+#pragma unroll
+    for (int q = 0; q < NSET; ++q)
+#pragma unroll
+      for (int i = 0; i < PP; ++i) gsr[q][i] = gload(vrow0 + i * vstep, 2 + q);
+    bf16x8 bq[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) bq[s] = ldbuf_bf16x8(rs_w, lane16, w0off + (unsigned)s * 1024u);
+    __syncthreads();
+
+    unsigned off_cur = 0u, off_nxt = (unsigned)kA1G, off_wr = 2u * (unsigned)kA1G;
+    bf16x8 a[kRBG];
+#define LDS_RD(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(off))
+#define LDS_WAIT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
+    LDS_RD(a[0], lds_a1_base, 0); LDS_RD(a[1], lds_a1_base, 512); LDS_RD(a[2], lds_a1_base, 1024); LDS_RD(a[3], lds_a1_base, 1536);
+    auto chunk = [&](const int c, const bool copy, const bool last, bf16x8 (&xs)[PP]) {
+      const unsigned abase = lds_a1_base + off_cur, nbase = lds_a1_base + off_nxt;
+#define GROUP(S, RB)                                                                                          \
+      {                                                                                                       \
+        if (!last || (S) < 3 || (RB) == 0) LDS_WAIT(3);                                                       \
+        else if ((RB) == 1) LDS_WAIT(2);                                                                      \
+        else if ((RB) == 2) LDS_WAIT(1);                                                                      \
+        else LDS_WAIT(0);                                                                                     \
+        asm volatile("" : "+v"(a[RB]));                                                                       \
+        acc[RB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[RB], bq[S], acc[RB], 0, 0, 0);                    \
+        if ((S) < 3) LDS_RD(a[RB], abase, ((S) + 1) * 4128 + (RB) * 512);                                     \
+        else if (!last) LDS_RD(a[RB], nbase, (RB) * 512);                                                     \
+      }
+#define KSTEP(S)                                                                                              \
+      GROUP(S, 0) GROUP(S, 1) GROUP(S, 2) GROUP(S, 3)                                                         \
+      if (copy && ((S) % (4 / PP)) == 4 / PP - 1) {                                                           \
+        constexpr int pi = (S) / (4 / PP);                                                                    \
+        *reinterpret_cast<bf16x8*>(slot0 + pi * kSlotStep + off_wr) = xs[pi];                                 \
+        xs[pi] = gload(vrow0 + pi * vstep, c + 2 + NSET);                                                     \
+      }                                                                                                       \
+      if (!last) {                                                                                            \
+        const unsigned ksn = (unsigned)((c + 1) * 4 + (S)) * 1024u;                                           \
+        bq[S] = ldbuf_bf16x8(rs_w, lane16, w0off + ksn);                                                      \
+      }
+      KSTEP(0) KSTEP(1) KSTEP(2) KSTEP(3)
+#undef KSTEP
+#undef GROUP
+      const unsigned tmp = off_cur; off_cur = off_nxt; off_nxt = off_wr; off_wr = tmp;
+    };
+    {
+      const int ncopy = NC - 2;
+      int c = 0;
+      for (; c + NSET <= ncopy; c += NSET) {
+#pragma unroll
+        for (int q = 0; q < NSET; ++q) { chunk(c + q, true, false, gsr[q]); __syncthreads(); }
+      }
+#pragma unroll
+      for (int q = 0; q < NSET - 1; ++q)
+        if (c < ncopy) { chunk(c, true, false, gsr[q]); __syncthreads(); ++c; }
+    }
+    chunk(NC - 2, false, false, gsr[0]);
+    __syncthreads();
+    chunk(NC - 1, false, true, gsr[0]);
+#undef LDS_WAIT
+#undef LDS_RD
+
+    // ---- epilogue in accumulator layout: row = 32 rb + acc_row(i, lane), column = col ----
+    const float wdc = s_wd[col];
+    const f32x2 one2 = {1.0f, 1.0f}, k2 = {kNegInvLog2e, kNegInvLog2e}, wd2 = {wdc, wdc};
+    float rowdot[32];
+#pragma unroll
+    for (int rb = 0; rb < kRBG; ++rb) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        // rows 32 rb + 8 q + 4 hh + (0..3): registers 4 q .. 4 q + 3
+        const int rbase = 32 * rb + 8 * q + 4 * hh;
+        const i32x4 po = *reinterpret_cast<const i32x4*>(s_po + rbase), qo = *reinterpret_cast<const i32x4*>(s_qo + rbase);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(s_d2 + rbase);
+#pragma unroll
+        for (int jj = 0; jj < 4; jj += 2) {
+          // g1 = acc * SiLU'(a1), a1 (scaled) = P[receiver][col] + Q[sender][col] (added in fp16 as the forward adds them) + wd d2
+          const f16x2 pv = {*reinterpret_cast<const _Float16*>(smem + (unsigned)po[jj] + colb),
+                            *reinterpret_cast<const _Float16*>(smem + (unsigned)po[jj + 1] + colb)};
+          const f16x2 qv = {*reinterpret_cast<const _Float16*>(smem + (unsigned)qo[jj] + colb),
+                            *reinterpret_cast<const _Float16*>(smem + (unsigned)qo[jj + 1] + colb)};
+          const f16x2 a1 = pv + qv;
+          const f32x2 dd = {d4[jj], d4[jj + 1]};
+          const f32x2 a1f = {(float)a1.x, (float)a1.y};
+          const f32x2 t2 = __builtin_elementwise_fma(wd2, dd, a1f);
+          const f32x2 e = {__builtin_amdgcn_exp2f(t2.x), __builtin_amdgcn_exp2f(t2.y)};
+          const f32x2 den = e + one2;
+          const f32x2 sg = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+          const f32x2 sv = (t2 * k2) * sg;                                    // SiLU(a1)
+          const f32x2 ds = __builtin_elementwise_fma(sv, one2 - sg, sg);      // SiLU'(a1) = sig + s (1 - sig)
+          const f32x2 gg = {acc[rb][4 * q + jj], acc[rb][4 * q + jj + 1]};
+          const f32x2 g1 = gg * ds;
+          acc[rb][4 * q + jj] = g1.x;
+          acc[rb][4 * q + jj + 1] = g1.y;
+          cd2 = __builtin_elementwise_fma(g1, dd, cd2);
+          const f32x2 rd = g1 * wd2;
+          rowdot[(rb & 1) * 16 + 4 * q + jj] = rd.x;
+          rowdot[(rb & 1) * 16 + 4 * q + jj + 1] = rd.y;
+        }
+      }
+      // receive / send sums on the matrix cores: B operand = this row block's g1 (registers 8 s .. 8 s + 7 = k-step s, k in
+      // accumulator-row order), A operand = the one-hot images (node on the lane, the same k order)
+      bf16x8 hf[2];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) hf[i >> 3][i & 7] = (__bf16)acc[rb][i];
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          const bf16x8 od = *reinterpret_cast<const bf16x8*>(hot_rd + (size_t)(32 * mb) * kHotStride + (32 * rb + 16 * s) * 2);
+          const bf16x8 os = *reinterpret_cast<const bf16x8*>(hot_rd + (kGOffHs - kGOffHd) + (size_t)(32 * mb) * kHotStride + (32 * rb + 16 * s) * 2);
+          gd[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(od, hf[s], gd[mb], 0, 0, 0);
+          gs[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(os, hf[s], gs[mb], 0, 0, 0);
+        }
+      // dL/d(d2_e) share of this slice: row sums over the 32 lanes of a half-wave (every second row block: 32 values per lane)
+      if (rb & 1) {
+        const float t = butterfly32(rowdot, lane);
+        const int row = 32 * (r >> 4) + acc_row(r & 15, lane);   // row of value index q = lane & 31
+        s_part[wave * kRG + 32 * (rb - 1) + row] = t;
+      }
+    }
+    __syncthreads();
+    if (tid < nvalid) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v += s_part[w * kRG + tid];
+      part_out[e0 - p.e_base + tid] = v * kNegInvLog2e;   // wd is the scaled column (-log2 e x W1[:, 2H])
+      // clear this tile's one-hot entries
+      const int pos = hot_pos(tid);
+      const int dl = (s_po[tid] - (int)kGOffP) / kTabStride, sl = (s_qo[tid] - (int)kGOffQ) / kTabStride;
+      *reinterpret_cast<unsigned short*>(smem + kGOffHd + (size_t)dl * kHotStride + 2 * pos) = 0;
+      *reinterpret_cast<unsigned short*>(smem + kGOffHs + (size_t)sl * kHotStride + 2 * pos) = 0;
+    }
+  }
+  // ---- the graph's sums: node = 32 mb + acc_row(i, lane), column on the lane ----
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int node = 32 * mb + acc_row(i, lane);
+      if (node < nn) {
+        const size_t o = (size_t)(n0 + node) * p.KP + slice * kColsG + col;
+        p.Gd[o] = gd[mb][i];
+        p.Gs[o] = gs[mb][i];
+      }
+    }
+  float cdv = cd2.x + cd2.y;
+  cdv += __shfl_xor(cdv, 32);
+  if (hh == 0) p.cd[(size_t)g * p.KP + slice * kColsG + col] = cdv;
+}
+
+}  // namespace
+
+int init_edge_dgrad_graph_attributes() {
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_dgrad_graph_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  return EGNN_OK;
+}
+
+// one MLP; the chunk [e_first, e_first + n_edges) must consist of whole graphs of at most 64 nodes (the caller's plan says so; a
+// workgroup whose graph is not inside the chunk leaves without writing).  Gd / Gs / cd rows of graphs without edges are not written.
+int launch_edge_dgrad_graph(int N, int B, const int* graph_ptr, const int* row_ptr, const int* dst, const int* src, int e_first,
+                            int n_edges, const float* x, const void* table, int TC, int offP, int offQ, const float* wd,
+                            const void* g_a2, int Kd, const void* w2t, int KP, float* Gd, float* Gs, float* cd, float* gd2_part,
+                            hipStream_t st) {
+  if (Kd % 64 != 0 || Kd < 256 || KP % kColsG != 0) { set_error("edge dgrad (graph form): unsupported widths Kd=%d KP=%d", Kd, KP); return EGNN_EINVAL; }
+  if (((size_t)n_edges + kRG) * Kd * 2 >= ((size_t)1 << 32)) { set_error("edge dgrad (graph form): chunk too large"); return EGNN_EINVAL; }
+  DgradGraphParams p;
+  p.N = N; p.B = B; p.graph_ptr = graph_ptr; p.row_ptr = row_ptr; p.edge_dst = dst; p.edge_src = src; p.e_base = e_first;
+  p.n_edges = n_edges; p.x = x; p.table = table; p.TC = TC; p.offP = offP; p.offQ = offQ; p.wd = wd; p.g_a2 = g_a2; p.Kd = Kd;
+  p.w2t = w2t; p.KP = KP; p.Gd = Gd; p.Gs = Gs; p.cd = cd; p.gd2_part = gd2_part;
+  hipLaunchKernelGGL(edge_dgrad_graph_kernel, dim3(B * (KP / kColsG)), dim3(kTG), kSmemG, st, p);
+  EGNN_HIP(hipGetLastError());
+  return EGNN_OK;
+}
+
+}  // namespace egnn

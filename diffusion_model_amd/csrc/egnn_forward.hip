@@ -23,6 +23,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 
+#include "bwd_graph.h"
 #include "common.h"
 #include "kernels.h"
 
@@ -1015,6 +1016,7 @@ int init_kernel_attributes() {
   if ((rc = init_edge_bf16_v4_attributes())) return rc;
   if ((rc = init_node_bf16_attributes())) return rc;
   if ((rc = init_edge_dgrad_attributes())) return rc;
+  if ((rc = init_edge_dgrad_graph_attributes())) return rc;
   if ((rc = init_edge_x_m16_attributes())) return rc;
   if ((rc = init_edge_bf16x3_attributes())) return rc;
   done = true;
@@ -1167,6 +1169,22 @@ int backward_dgrad(egnn_ctx* c, hipStream_t st, int layer, const float* x, int e
   if (rc) return rc;
   return launch_edge_dgrad(c->N, n_edges, c->edge_dst + e_first, c->edge_src + e_first, x, c->table, c->TC, 2 * c->WxP,
                            2 * c->WxP + c->WmP, wdm_s, g_a2m, c->MP, lp.w2mT_bf16, c->WmP, g_a1m, st);
+}
+
+// the same dgrad WITHOUT dL/da1 in memory: per-graph workgroups that also reduce it for the first Linear layers
+// (edge_bwd_dgrad_graph.hip); gd2_part = [(WxP + WmP) / 256][n_edges]
+int backward_dgrad_graph(egnn_ctx* c, hipStream_t st, int layer, const float* x, int e_first, int n_edges, const void* g_a2x,
+                         const void* g_a2m, float* Gd_x, float* Gs_x, float* Gd_m, float* Gs_m, float* cd_x, float* cd_m,
+                         float* gd2_part) {
+  const LayerPack& lp = c->layers[layer];
+  const float* wdx_s = lp.sc + (size_t)(c->H + 1) * c->TC;
+  const float* wdm_s = wdx_s + c->WxP;
+  int rc = launch_edge_dgrad_graph(c->N, c->B, c->graph_ptr, c->row_ptr, c->edge_dst, c->edge_src, e_first, n_edges, x, c->table,
+                                   c->TC, 0, c->WxP, wdx_s, g_a2x, c->WxP, lp.w2xT_bf16, c->WxP, Gd_x, Gs_x, cd_x, gd2_part, st);
+  if (rc) return rc;
+  return launch_edge_dgrad_graph(c->N, c->B, c->graph_ptr, c->row_ptr, c->edge_dst, c->edge_src, e_first, n_edges, x, c->table,
+                                 c->TC, 2 * c->WxP, 2 * c->WxP + c->WmP, wdm_s, g_a2m, c->MP, lp.w2mT_bf16, c->WmP, Gd_m, Gs_m,
+                                 cd_m, gd2_part + (size_t)(c->WxP / 256) * n_edges, st);
 }
 
 // Stage 1 of a layer: node_pre, squared-distance sums and the fused edge pass.  gsum (c->gscale) then holds the

@@ -79,6 +79,9 @@ class GraphPlan:
         self.graph_ptr[1:] = torch.cumsum(cnt, 0).to(torch.int32)
         self.node_graph = batch.to(torch.int32).contiguous()
         self.batch = batch
+        # host copy of the edge range of every graph (edges are sorted by receiving node, graphs contiguous): the training
+        # backward cuts its edge chunks at graph boundaries with it
+        self.graph_edge_ptr = self.row_ptr[self.graph_ptr.long()].tolist()
         if self.E > 0 and bool((batch[row] != batch[col]).any()):
             raise ValueError("an edge connects two different graphs")
 

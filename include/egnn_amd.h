@@ -218,6 +218,18 @@ int egcl_backward_heads_saved(egnn_ctx* ctx, void* stream, int layer, const floa
 int egcl_backward_dgrad(egnn_ctx* ctx, void* stream, int layer, const float* d_x, int e_first, int n_edges,
                         const void* d_g_a2x, const void* d_g_a2m, void* d_g_a1x_out, void* d_g_a1m_out);
 
+/* The same dgrad WITHOUT dL/da1 in memory (csrc/edge_bwd_dgrad_graph.hip; replaces egcl_backward_dgrad +
+ * egcl_backward_first_reduce for batches of graphs of at most 64 nodes): one workgroup per (graph, 256 hidden units) multiplies
+ * g_a2 . W2, applies SiLU'(a1) on the accumulator tile and reduces it there for the first Linear layers -- Gd[n] / Gs[n] =
+ * sums of g1 over the edges node n receives / sends ([N, W] fp32), cd[graph] = sum_e g1[e] d2_e ([B, W]) and the
+ * (Wx + Wm) / 256 shares of dL/d(d2_e) (d_gd2_part [(Wx + Wm) / 256, n_edges]); all ASSIGNED for the graphs of the chunk (rows
+ * of graphs without edges are left as they are: zero them once).  The chunk [e_first, e_first + n_edges) must consist of WHOLE
+ * graphs (egnn_set_graph's graph ranges); d_g_a2x / d_g_a2m are the chunk's rows.  Follow with the node-level products and
+ * egcl_backward_scatter_geom as after egcl_backward_first_reduce. */
+int egcl_backward_dgrad_reduce(egnn_ctx* ctx, void* stream, int layer, const float* d_x, int e_first, int n_edges,
+                               const void* d_g_a2x, const void* d_g_a2m, float* d_Gd_x, float* d_Gs_x, float* d_Gd_m,
+                               float* d_Gs_m, float* d_cd_x, float* d_cd_m, float* d_gd2_part);
+
 /* Weight gradients of the backward (loss.backward() of parts/train_per_iretation.py:172 through the Linear layers of
  * EquivariantGraphNeuralNetwork.py:13-30): a reduction over ALL edges (or nodes) on the matrix cores,
  *     C[m][n] (+)= scale * sum_e A[e][m] * B[e][n],   m < rows, n < cols,

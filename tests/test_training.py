@@ -24,7 +24,7 @@ def _problem(seed=0, sizes=(6, 4, 7), H=36, A=2):
     batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
     ei = fully_connected_edge_index(list(sizes))
     noise_pos, noise_h = torch.randn(n, 3, generator=g), torch.randn(n, A, generator=g)
-    times = [17, 3, 40][: len(sizes)]
+    times = [17, 3, 40, 9, 28, 33, 1, 22][: len(sizes)]
     return pos0, x0, cond, batch, ei, noise_pos, noise_h, times
 
 
@@ -106,8 +106,9 @@ def test_gradients_match_oracle_autograd(norm_scope, widths, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("first_layer", ["chain", "factorised"])
-def test_gradients_full_width_64_atom_graphs(first_layer, monkeypatch):
+@pytest.mark.parametrize("first_layer,sizes", [("chain", (64, 64, 64)), ("factorised", (64, 64, 64)), ("graph", (64, 64, 64)),
+                                               ("graph", (40, 64, 7, 1, 25))], ids=["chain", "factorised", "graph", "graph-ragged"])
+def test_gradients_full_width_64_atom_graphs(first_layer, sizes, monkeypatch):
     """BASELINE configs[3] shape per graph: 64-atom fully connected graphs at the reference widths (W = 1024, m = 256,
     H = 36), three graphs = 12,096 edges in backward chunks of 5,000 (so a layer spans several chunks).  EVERY precision
     against the ORACLE's autograd (no self-comparison): fp32 and bf16x3 (whose backward is the fp32 chain) at 2e-3; bf16
@@ -116,17 +117,20 @@ def test_gradients_full_width_64_atom_graphs(first_layer, monkeypatch):
     from diffusion_model_amd import autograd as _ag
     # "factorised": the opt-in one-pass first-layer backward (csrc/edge_bwd_first.hip: per-node receive / send sums of dL/da1,
     # node-level products); the 5,000-edge chunks cut through the graphs, so its accumulation across chunks is exercised too
+    # "graph" (the default form): the same sums inside the dgrad kernel (csrc/edge_bwd_dgrad_graph.hip, no dL/da1 in memory); its
+    # chunks are cut at graph boundaries (one 4,032-edge graph per chunk here; ragged: graphs of 40 / 64 / 7 / 1 / 25 atoms, the
+    # single atom has no edges at all)
     monkeypatch.setenv("EGNN_BWD_FIRST", "1" if first_layer == "factorised" else "0")
+    monkeypatch.setenv("EGNN_BWD_GRAPH", "1" if first_layer == "graph" else "0")
     H, A, T = 36, 2, 50
     d = dims_for(H, 256, 1024, 1024, 1024)
     torch.manual_seed(6)
     net = dma.EquivariantGNN(2, **d)
     sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
-    sizes = (64, 64, 64)
     pos0, x0, cond, batch, ei, npos, nh, times = _problem(seed=2, sizes=sizes)
     pos0 = pos0 * 2.0
     ref = DiffusionRef(1e-5, 2.0, T)
-    ptr = torch.tensor([0, 64, 128, 192])
+    ptr = torch.tensor([0] + torch.cumsum(torch.tensor(sizes), 0).tolist())
     loss_ref, ex_ref, eh_ref, _, _ = oracle_training_loss(sd, ref, pos0, x0, cond, ei, batch, times, npos.clone(), nh.clone(),
                                                          atom_type_size=A, norm_scope="graph", graph_ptr=ptr)
     loss_ref.backward()
@@ -142,10 +146,12 @@ def test_gradients_full_width_64_atom_graphs(first_layer, monkeypatch):
             m.to(dev).train()
             m.precision, m.norm_scope = prec, "graph"
             noised = dma.diffuse_as_batch(pos0.to(dev), x0.to(dev), batch.to(dev), proc, times=times,
-                                          noise_pos=npos.to(dev), noise_h=nh.to(dev), num_graphs=3)
-            loss, ex, eh = dma.training_loss(m, ei.to(dev), batch.to(dev), noised, cond.to(dev), A, num_graphs=3)
+                                          noise_pos=npos.to(dev), noise_h=nh.to(dev), num_graphs=len(sizes))
+            loss, ex, eh = dma.training_loss(m, ei.to(dev), batch.to(dev), noised, cond.to(dev), A, num_graphs=len(sizes))
             loss.backward()
             grads[prec] = {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
+            if prec in ("bf16", "fp16"):   # the form under test is the one that ran
+                assert _ag.LAST_FIRST_LAYER_FORM == {"chain": None, "factorised": "reduce", "graph": "graph"}[first_layer]
             if prec in ("fp32", "bf16x3"):
                 assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 1e-4 * abs(float(loss_ref.detach()))
                 assert rel_err(ex.detach().cpu(), ex_ref.detach()) <= 1e-4 and rel_err(eh.detach().cpu(), eh_ref.detach()) <= 1e-4
