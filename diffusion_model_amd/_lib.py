@@ -59,7 +59,7 @@ SIGNATURES = {
     "egcl_backward_table": (_i, [_vp, _vp, _i, _vp]),
     "egcl_backward_edge_recompute": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i] + [_vp] * 11),
     "egcl_backward_dgrad": (_i, [_vp, _vp, _i, _vp, _i, _i] + [_vp] * 4),
-    "egcl_backward_dgrad_reduce": (_i, [_vp, _vp, _i, _vp, _i, _i] + [_vp] * 9),
+    "egcl_backward_dgrad_reduce": (_i, [_vp, _vp, _i, _vp, _i, _i] + [_vp] * 6),
     "egcl_forward_save": (_i, [_vp, _vp, _i, _i] + [_vp] * 9),
     "egcl_backward_heads_saved": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i] + [_vp] * 10),
     "egnn_gemm_tn_workspace_bytes": (C.c_size_t, [_i, _i, _i]),

@@ -124,28 +124,6 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_
     if hip:
         from .gemm import gemm_rows, gemm_tn, pack_rows_weights
 
-    def tables(lin):   # per-node halves of the first Linear layer (:56's concatenation factorised)
-        w = lin.weight.detach()
-        if hip:        # the fused kernels take P / Q from the forward's table; the dgrad runs on packed fragments
-            return None, None, None, pack_rows_weights(w.float().contiguous(), 2 * H + 1)
-        Pn = torch.addmm(lin.bias.detach(), h, w[:, :H].t()).contiguous()
-        Qn = torch.mm(h, w[:, H:2 * H].t()).contiguous()
-        wpad = torch.zeros(w.shape[0], K1P, dtype=dt, device=h.device)
-        wpad[:, :2 * H + 1] = w
-        return Pn, Qn, w[:, 2 * H].contiguous(), wpad
-
-    Px, Qx, wdx, w1x = tables(lin_x0)
-    Pm, Qm, wdm, w1m = tables(lin_m0)
-    w2x, w2m = lin_x2.weight.detach().to(dt), lin_m2.weight.detach().to(dt)
-    b2x, b2m = lin_x2.bias.detach().contiguous(), lin_m2.bias.detach().contiguous()
-    w3, b3 = lin_x4.weight.detach().reshape(-1).contiguous(), lin_x4.bias.detach().contiguous()
-    wa, ba = att.weight.detach().reshape(-1).contiguous(), att.bias.detach().contiguous()
-    # fp32 accumulators; the first Linear layers carry their bias gradient in column 2H+1 (ones column of `in`)
-    g_w1x, g_w1m = torch.zeros(Wx, K1P, **f32), torch.zeros(Wm, K1P, **f32)
-    g_w2x, g_w2m = torch.zeros(Wx, Wx, **f32), torch.zeros(M, Wm, **f32)
-    g_b2x, g_w3, g_b3 = torch.zeros(Wx, **f32), torch.zeros(Wx, **f32), torch.zeros(1, **f32)
-    g_b2m, g_wa, g_ba = torch.zeros(M, **f32), torch.zeros(M, **f32), torch.zeros(1, **f32)
-    g_am, g_ax = g_am.contiguous(), g_ax.contiguous()
     E = dst32.numel()
     rows = ws.rows
     # First Linear layers factorised as the forward factorises them: per-node sums of dL/da1 over the edges a node receives /
@@ -164,13 +142,39 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_
             cut = _graph_chunks(plan, rows)   # chunks of whole graphs
             if cut is not None:
                 first, chunks = "graph", cut
+
+    def tables(lin):   # per-node halves of the first Linear layer (:56's concatenation factorised)
+        w = lin.weight.detach()
+        if hip:        # the fused kernels take P / Q from the forward's table; the dgrad runs on packed fragments
+            return None, None, None, (None if first else pack_rows_weights(w.float().contiguous(), 2 * H + 1))
+        Pn = torch.addmm(lin.bias.detach(), h, w[:, :H].t()).contiguous()
+        Qn = torch.mm(h, w[:, H:2 * H].t()).contiguous()
+        wpad = torch.zeros(w.shape[0], K1P, dtype=dt, device=h.device)
+        wpad[:, :2 * H + 1] = w
+        return Pn, Qn, w[:, 2 * H].contiguous(), wpad
+
+    Px, Qx, wdx, w1x = tables(lin_x0)
+    Pm, Qm, wdm, w1m = tables(lin_m0)
+    w2x, w2m = lin_x2.weight.detach().to(dt), lin_m2.weight.detach().to(dt)
+    b2x, b2m = lin_x2.bias.detach().contiguous(), lin_m2.bias.detach().contiguous()
+    w3, b3 = lin_x4.weight.detach().reshape(-1).contiguous(), lin_x4.bias.detach().contiguous()
+    wa, ba = att.weight.detach().reshape(-1).contiguous(), att.bias.detach().contiguous()
+    # fp32 accumulators; the first Linear layers carry their bias gradient in column 2H+1 (ones column of `in`)
+    g_w1x, g_w1m = torch.zeros(Wx, K1P, **f32), torch.zeros(Wm, K1P, **f32)
+    g_w2x, g_w2m = torch.zeros(Wx, Wx, **f32), torch.zeros(M, Wm, **f32)
+    g_b2x, g_w3, g_b3 = torch.zeros(Wx, **f32), torch.zeros(Wx, **f32), torch.zeros(1, **f32)
+    g_b2m, g_wa, g_ba = torch.zeros(M, **f32), torch.zeros(M, **f32), torch.zeros(1, **f32)
+    g_am, g_ax = g_am.contiguous(), g_ax.contiguous()
     global LAST_FIRST_LAYER_FORM
     LAST_FIRST_LAYER_FORM = first
     if first:
         N, nparts = h.shape[0], (Wx + Wm) // 256
-        Gd_x, Gs_x, Gd_m, Gs_m = (torch.zeros(N, w, **f32) for w in (Wx, Wx, Wm, Wm))
         cd_x, cd_m = torch.zeros(plan.B, Wx, **f32), torch.zeros(plan.B, Wm, **f32)
         gd2_part = torch.empty(nparts * min(rows, E), **f32)
+    if first == "graph":     # the kernel leaves the sums as the bf16 operands of the node-level products: [Gd_x | Gs_x | Gd_m | Gs_m]
+        G = torch.zeros(N, 2 * Wx + 2 * Wm, dtype=torch.bfloat16, device=h.device)
+    elif first == "reduce":
+        Gd_x, Gs_x, Gd_m, Gs_m = (torch.zeros(N, w, **f32) for w in (Wx, Wx, Wm, Wm))
     if first == "reduce":
         wdx_f = lin_x0.weight.detach()[:, 2 * H].float().contiguous()
         wdm_f = lin_m0.weight.detach()[:, 2 * H].float().contiguous()
@@ -217,8 +221,8 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_
             g_w2m += _wgrad(A2M, S1M, n_pad, 32)
         if first == "graph":
             # dgrad of the second layers, SiLU'(a1) and the first layers' per-node sums in one kernel: no dL/da1 in memory
-            _lib.check(L.egcl_backward_dgrad_reduce(fused[0], st, fused[1], P(x), a, n, P(a2x), P(a2m), P(Gd_x), P(Gs_x), P(Gd_m),
-                                                    P(Gs_m), P(cd_x), P(cd_m), P(gd2_part)))
+            _lib.check(L.egcl_backward_dgrad_reduce(fused[0], st, fused[1], P(x), a, n, P(a2x), P(a2m), P(G), P(cd_x), P(cd_m),
+                                                    P(gd2_part)))
         elif fused is not None:
             # dgrad of the second layers with SiLU'(a1) in the epilogue, on MFMA (no [n, W] round trip in between)
             _lib.check(L.egcl_backward_dgrad(fused[0], st, fused[1], P(x), a, n, P(a2x), P(a2m), P(g1x), P(g1m)))
@@ -251,7 +255,23 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_
     if fused is not None:   # the recompute kernels store s1 as the MFMA consumed it: -log2(e) * SiLU(a1)
         g_w2x *= -math.log(2.0)
         g_w2m *= -math.log(2.0)
-    if first:   # node-level products of the factorised first layers (N rows; fp32)
+    if first == "graph":   # node-level products of the factorised first layers on the library's own GEMMs (N rows, bf16 operands)
+        hb = torch.zeros(N, 128, dtype=torch.bfloat16, device=h.device)
+        hb[:, :H] = h
+        hb[:, H] = 1.0                                       # (ones column: the bias gradients = column sums of Gd)
+        Wg = gemm_tn(G, hb, cols=H + 1)                      # [2 Wx + 2 Wm, H + 1] = G^T [h | 1]
+        for g_w1, o, W, cd in ((g_w1x, 0, Wx, cd_x), (g_w1m, 2 * Wx, Wm, cd_m)):
+            g_w1[:, :H] = Wg[o:o + W, :H]
+            g_w1[:, H:2 * H] = Wg[o + W:o + 2 * W, :H]
+            g_w1[:, 2 * H] = cd.sum(0)
+            g_w1[:, 2 * H + 1] = Wg[o:o + W, H]
+        # dL/dh += Gd W1[:, :H] + Gs W1[:, H:2H] for both MLPs: one row-streaming product over [Gd | Gs] (K = 2 W each)
+        wcat = [pack_rows_weights(torch.cat([lin.weight.detach()[:, :H], lin.weight.detach()[:, H:2 * H]], 0).float().contiguous(), H)
+                for lin in (lin_x0, lin_m0)]
+        gh_add = torch.empty(N, 128, **f32)
+        gemm_rows(G[:, :2 * Wx], wcat[0], G[:, 2 * Wx:], wcat[1], out=gh_add)
+        g_h += gh_add[:, :H]
+    elif first:   # ("reduce": the reference form, fp32 library products)
         hf = h.float()
         for g_w1, Gd, Gs, cd, lin in ((g_w1x, Gd_x, Gs_x, cd_x, lin_x0), (g_w1m, Gd_m, Gs_m, cd_m, lin_m0)):
             g_w1[:, :H] = Gd.t() @ hf

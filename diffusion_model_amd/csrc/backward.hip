@@ -499,16 +499,15 @@ int egcl_backward_dgrad(egnn_ctx* c, void* stream, int layer, const float* x, in
 }
 
 int egcl_backward_dgrad_reduce(egnn_ctx* c, void* stream, int layer, const float* x, int e_first, int n_edges, const void* g_a2x,
-                               const void* g_a2m, float* Gd_x, float* Gs_x, float* Gd_m, float* Gs_m, float* cd_x, float* cd_m,
-                               float* gd2_part) {
+                               const void* g_a2m, void* G, float* cd_x, float* cd_m, float* gd2_part) {
   if (!c || c->L == 0 || c->N == 0 || layer < 0 || layer >= c->L) { set_error("bad egcl_backward_dgrad_reduce context/layer"); return EGNN_EINVAL; }
   if (e_first < 0 || n_edges < 0 || e_first + n_edges > c->E) { set_error("edge range [%d, %d) outside the graph", e_first, e_first + n_edges); return EGNN_EINVAL; }
   if (n_edges == 0) return EGNN_OK;
-  if (!x || !g_a2x || !g_a2m || !Gd_x || !Gs_x || !Gd_m || !Gs_m || !cd_x || !cd_m || !gd2_part) { set_error("bad egcl_backward_dgrad_reduce arguments"); return EGNN_EINVAL; }
+  if (!x || !g_a2x || !g_a2m || !G || !cd_x || !cd_m || !gd2_part) { set_error("bad egcl_backward_dgrad_reduce arguments"); return EGNN_EINVAL; }
   if (!backward_recompute_supported(c)) { set_error("fused backward is not available for these widths"); return EGNN_EINVAL; }
   if (!c->graph_ptr || !c->row_ptr || c->B < 1) { set_error("egcl_backward_dgrad_reduce needs the graph ranges (egnn_set_graph)"); return EGNN_ESTATE; }
-  return backward_dgrad_graph(c, reinterpret_cast<hipStream_t>(stream), layer, x, e_first, n_edges, g_a2x, g_a2m, Gd_x, Gs_x, Gd_m,
-                              Gs_m, cd_x, cd_m, gd2_part);
+  return backward_dgrad_graph(c, reinterpret_cast<hipStream_t>(stream), layer, x, e_first, n_edges, g_a2x, g_a2m, G, cd_x, cd_m,
+                              gd2_part);
 }
 
 static int bwd_l1(void* stream, int prec, int grad, int n_edges, int C, const int32_t* dst, const int32_t* src,

@@ -7,10 +7,9 @@ namespace egnn {
 int init_edge_dgrad_graph_attributes();
 int launch_edge_dgrad_graph(int N, int B, const int* graph_ptr, const int* row_ptr, const int* dst, const int* src, int e_first,
                             int n_edges, const float* x, const void* table, int TC, int offP, int offQ, const float* wd,
-                            const void* g_a2, int Kd, const void* w2t, int KP, float* Gd, float* Gs, float* cd, float* gd2_part,
-                            hipStream_t st);
+                            const void* g_a2, int Kd, const void* w2t, int KP, void* Gd, void* Gs, int ldg, float* cd,
+                            float* gd2_part, hipStream_t st);
 // both edge MLPs of `layer` over the chunk [e_first, e_first + n_edges) (whole graphs of <= 64 nodes)
 int backward_dgrad_graph(egnn_ctx* c, hipStream_t st, int layer, const float* x, int e_first, int n_edges, const void* g_a2x,
-                         const void* g_a2m, float* Gd_x, float* Gs_x, float* Gd_m, float* Gs_m, float* cd_x, float* cd_m,
-                         float* gd2_part);
+                         const void* g_a2m, void* G, float* cd_x, float* cd_m, float* gd2_part);
 }  // namespace egnn

@@ -10,12 +10,13 @@
 //               _NO_BUILD / _NO_EPI / _NO_MFMA / _W_ONCE of the 32x32x16 kernels were removed with round 4: results in
 //               profiles/r02i_x_decomposition.txt, code in the history before commit "diag.h")
 //               EGNN_EXP_DG_NOK / _NOG / _NOW / _L2G / _NOTAB / _NOEPI               (dgrad kernel)
+//               EGNN_EXP_DGG_NOSILU / _NOHOT / _NOROW (+ _DG_NOK / _DG_NOEPI)        (per-graph dgrad kernel)
 #pragma once
 
 #if !defined(EGNN_DIAG) && (defined(EGNN_EXP_STAMP) || defined(EGNN_EXP_STAMP2) || defined(EGNN_EXP_WGSTAMP) || defined(EGNN_EXP_DGSTAMP) || \
     defined(EGNN_EXP_NO_S1) || defined(EGNN_EXP_NO_T2) || defined(EGNN_EXP_DG_NOK) || defined(EGNN_EXP_DG_NOG) || defined(EGNN_EXP_DG_NOW) || \
     defined(EGNN_EXP_DG_L2G) || defined(EGNN_EXP_DG_NOTAB) || defined(EGNN_EXP_DG_NOEPI) || defined(EGNN_EXP_NP_NONORM) ||                    \
-    defined(EGNN_EXP_NP_NOMLP))
+    defined(EGNN_EXP_NP_NOMLP) || defined(EGNN_EXP_DGG_NOSILU) || defined(EGNN_EXP_DGG_NOHOT) || defined(EGNN_EXP_DGG_NOROW))
 #error "EGNN_EXP_* switches are diagnostic builds: add -DEGNN_DIAG (tools/exp_build.sh)"
 #endif
 
@@ -61,6 +62,23 @@ EGNN_DIAG_FLAG(kDgNoTab, false);
 EGNN_DIAG_FLAG(kDgNoEpi, true);
 #else
 EGNN_DIAG_FLAG(kDgNoEpi, false);
+#endif
+// per-graph dgrad (edge_bwd_dgrad_graph.hip; it also honours _DG_NOK and _DG_NOEPI): without SiLU', without the one-hot products,
+// without the row sums
+#ifdef EGNN_EXP_DGG_NOSILU
+EGNN_DIAG_FLAG(kDggNoSilu, true);
+#else
+EGNN_DIAG_FLAG(kDggNoSilu, false);
+#endif
+#ifdef EGNN_EXP_DGG_NOHOT
+EGNN_DIAG_FLAG(kDggNoHot, true);
+#else
+EGNN_DIAG_FLAG(kDggNoHot, false);
+#endif
+#ifdef EGNN_EXP_DGG_NOROW
+EGNN_DIAG_FLAG(kDggNoRow, true);
+#else
+EGNN_DIAG_FLAG(kDggNoRow, false);
 #endif
 #ifdef EGNN_EXP_NP_NONORM   // node_post timing builds (tools/lat_ab.sh): without the normaliser / coordinate update, without the MLP
 EGNN_DIAG_FLAG(kNpNoNorm, true);

@@ -3,7 +3,8 @@
 // (edge_bwd_first.hip: the backward of the forward's first-layer factorisation),
 //
 //     g1[e][k]  = ( sum_n dL/da2[e][n] W2[n][k] ) SiLU'(a1[e][k])          a1 = P[dst e] + Q[src e] + wd d2_e      (never stored)
-//     Gd[n][k]  = sum over the edges n receives of g1          Gs[n][k] = sum over the edges n sends of g1
+//     Gd[n][k]  = sum over the edges n receives of g1          Gs[n][k] = sum over the edges n sends of g1      (fp32 sums, stored bf16:
+//                                                                           the operands of the node-level products)
 //     cd[k]     = sum_e g1[e][k] d2_e                           gd2[e]   = sum_k g1[e][k] wd[k]
 //
 // for one edge MLP (mlp_x: n, k < Wx; mlp_m: n < M, k < Wm; EquivariantGraphNeuralNetwork.py:13-25 under autograd).  Round 3 wrote
@@ -24,6 +25,7 @@
 // Graphs of more than 64 nodes, or edge chunks that cut through graphs, take the round-3 chain.
 #include <stdlib.h>
 
+#include "diag.h"
 #include "kernels.h"
 
 namespace egnn {
@@ -63,7 +65,8 @@ struct DgradGraphParams {
   int Kd;
   const void* w2t;                 // bf16 fragments, transposed pack [KP/32][Kd/16][64][8]
   int KP;
-  float *Gd, *Gs;                  // [N][KP] fp32 (assigned: every (node, column) by exactly one workgroup)
+  __bf16 *Gd, *Gs;                 // [N][ldg] bf16 (assigned: every (node, column) by exactly one workgroup)
+  int ldg;
   float* cd;                       // [B][KP]
   float* gd2_part;                 // [KP / 256][n_edges] shares of dL/d(d2_e) (already in unscaled units)
 };
@@ -107,10 +110,10 @@ __global__ __launch_bounds__(kTG, 2) void edge_dgrad_graph_kernel(const DgradGra
       u32x4 v = {0u, 0u, 0u, 0u};
       if (node < nn)
         v = *reinterpret_cast<const u32x4*>(tab + ((size_t)(n0 + node) * p.TC + (which ? p.offQ : p.offP) + slice * kColsG + piece * 8) * 2);
-      *reinterpret_cast<u32x4*>(smem + (which ? kGOffQ : kGOffP) + (size_t)node * kTabStride + piece * 16) = v;
+      *reinterpret_cast<u32x4*>(smem + ((which ? (int)kGOffQ : (int)kGOffP) + node * kTabStride + piece * 16)) = v;
     }
     // P row 64 = "no edge": -log2(e) a1 = +60000 gives exp2 = inf, sigmoid = 0, SiLU' = 0 exactly
-    if (tid < kColsG) reinterpret_cast<_Float16*>(smem + kGOffP + (size_t)kNodesG * kTabStride)[tid] = (_Float16)60000.0f;
+    if (tid < kColsG) reinterpret_cast<_Float16*>(smem + ((int)kGOffP + kNodesG * kTabStride))[tid] = (_Float16)60000.0f;
     for (int i = tid; i < 2 * kNodesG * kHotStride / 16; i += kTG) reinterpret_cast<u32x4*>(smem + kGOffHd)[i] = u32x4{0u, 0u, 0u, 0u};
     for (int i = tid; i < nn * 3; i += kTG) s_x[i] = p.x[(size_t)3 * n0 + i];
     if (tid < kColsG) s_wd[tid] = p.wd[slice * kColsG + tid];
@@ -124,19 +127,19 @@ __global__ __launch_bounds__(kTG, 2) void edge_dgrad_graph_kernel(const DgradGra
   f32x2 cd2 = {0.f, 0.f};
   const int col = 32 * wave + r;                      // this lane's column inside the slice
   const unsigned colb = 2u * (unsigned)col;
-  const int NC = p.Kd / kKCG, KS = p.Kd / 16;
+  const int NC = diag::kDgNoK ? 2 : p.Kd / kKCG, KS = p.Kd / 16;   // (diag: two chunks only = prologue + epilogue time)
   const int brow = tid >> 3, kg = tid & 7;
   const rsrc_t rs_g = make_rsrc(p.g_a2, (unsigned)((size_t)p.n_edges * p.Kd * 2));   // rows past the chunk read as zero
   const rsrc_t rs_w = make_rsrc(p.w2t, (unsigned)((size_t)p.KP * p.Kd * 2));
   const unsigned vstep = (unsigned)(8 * NW) * (unsigned)p.Kd * 2u;
-  char* const slot0 = s_a1 + ((size_t)kg * kRPADG + brow) * 16;
+  char* const slot0 = s_a1 + (kg * kRPADG + brow) * 16;
   constexpr unsigned kSlotStep = 8 * NW * 16;
   const unsigned lane16 = lane * 16u;
-  const unsigned lds_a1_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(s_a1 + ((size_t)hh * kRPADG + r) * 16);
+  const unsigned lds_a1_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(s_a1 + (hh * kRPADG + r) * 16);
   const int colblk0 = slice * NW + wave;
   const unsigned w0off = (unsigned)colblk0 * KS * 1024u;
   float* const part_out = p.gd2_part + (size_t)slice * p.n_edges;
-  const char* const hot_rd = smem + kGOffHd + (size_t)r * kHotStride + 16 * hh;   // this lane's A-operand pieces of the one-hot images
+  const char* const hot_rd = smem + ((int)kGOffHd + r * kHotStride + 16 * hh);   // this lane's A-operand pieces of the one-hot images
 
   const int ntiles = (e_hi - e_lo + kRG - 1) / kRG;
   for (int tile = 0; tile < ntiles; ++tile) {
@@ -153,8 +156,8 @@ __global__ __launch_bounds__(kTG, 2) void edge_dgrad_graph_kernel(const DgradGra
         const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);   // norm(...)**2 as in the forward (:56)
         dd = nrm * nrm;
         const int pos = hot_pos(tid);
-        *reinterpret_cast<unsigned short*>(smem + kGOffHd + (size_t)dl * kHotStride + 2 * pos) = 0x3F80;   // bf16 1.0
-        *reinterpret_cast<unsigned short*>(smem + kGOffHs + (size_t)sl * kHotStride + 2 * pos) = 0x3F80;
+        *reinterpret_cast<unsigned short*>(smem + ((int)kGOffHd + dl * kHotStride + 2 * pos)) = 0x3F80;   // bf16 1.0
+        *reinterpret_cast<unsigned short*>(smem + ((int)kGOffHs + sl * kHotStride + 2 * pos)) = 0x3F80;
       }
       s_po[tid] = (int)kGOffP + dl * kTabStride;
       s_qo[tid] = (int)kGOffQ + sl * kTabStride;
@@ -240,6 +243,14 @@ __global__ __launch_bounds__(kTG, 2) void edge_dgrad_graph_kernel(const DgradGra
 #undef LDS_RD
 
     // ---- epilogue in accumulator layout: row = 32 rb + acc_row(i, lane), column = col ----
+    if constexpr (diag::kDgNoEpi) {   // timing build: K loop only
+#pragma unroll
+      for (int rb = 0; rb < kRBG; ++rb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) cd2.x += acc[rb][i];
+      __syncthreads();
+      continue;
+    }
     const float wdc = s_wd[col];
     const f32x2 one2 = {1.0f, 1.0f}, k2 = {kNegInvLog2e, kNegInvLog2e}, wd2 = {wdc, wdc};
     float rowdot[32];
@@ -268,7 +279,7 @@ __global__ __launch_bounds__(kTG, 2) void edge_dgrad_graph_kernel(const DgradGra
           const f32x2 sv = (t2 * k2) * sg;                                    // SiLU(a1)
           const f32x2 ds = __builtin_elementwise_fma(sv, one2 - sg, sg);      // SiLU'(a1) = sig + s (1 - sig)
           const f32x2 gg = {acc[rb][4 * q + jj], acc[rb][4 * q + jj + 1]};
-          const f32x2 g1 = gg * ds;
+          const f32x2 g1 = diag::kDggNoSilu ? gg : gg * ds;
           acc[rb][4 * q + jj] = g1.x;
           acc[rb][4 * q + jj + 1] = g1.y;
           cd2 = __builtin_elementwise_fma(g1, dd, cd2);
@@ -283,16 +294,16 @@ __global__ __launch_bounds__(kTG, 2) void edge_dgrad_graph_kernel(const DgradGra
 #pragma unroll
       for (int i = 0; i < 16; ++i) hf[i >> 3][i & 7] = (__bf16)acc[rb][i];
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
+      for (int s = 0; s < (diag::kDggNoHot ? 0 : 2); ++s)
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
-          const bf16x8 od = *reinterpret_cast<const bf16x8*>(hot_rd + (size_t)(32 * mb) * kHotStride + (32 * rb + 16 * s) * 2);
-          const bf16x8 os = *reinterpret_cast<const bf16x8*>(hot_rd + (kGOffHs - kGOffHd) + (size_t)(32 * mb) * kHotStride + (32 * rb + 16 * s) * 2);
+          const bf16x8 od = *reinterpret_cast<const bf16x8*>(hot_rd + ((32 * mb) * kHotStride + (32 * rb + 16 * s) * 2));
+          const bf16x8 os = *reinterpret_cast<const bf16x8*>(hot_rd + ((int)(kGOffHs - kGOffHd) + (32 * mb) * kHotStride + (32 * rb + 16 * s) * 2));
           gd[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(od, hf[s], gd[mb], 0, 0, 0);
           gs[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(os, hf[s], gs[mb], 0, 0, 0);
         }
       // dL/d(d2_e) share of this slice: row sums over the 32 lanes of a half-wave (every second row block: 32 values per lane)
-      if (rb & 1) {
+      if ((rb & 1) && !diag::kDggNoRow) {
         const float t = butterfly32(rowdot, lane);
         const int row = 32 * (r >> 4) + acc_row(r & 15, lane);   // row of value index q = lane & 31
         s_part[wave * kRG + 32 * (rb - 1) + row] = t;
@@ -307,8 +318,8 @@ __global__ __launch_bounds__(kTG, 2) void edge_dgrad_graph_kernel(const DgradGra
       // clear this tile's one-hot entries
       const int pos = hot_pos(tid);
       const int dl = (s_po[tid] - (int)kGOffP) / kTabStride, sl = (s_qo[tid] - (int)kGOffQ) / kTabStride;
-      *reinterpret_cast<unsigned short*>(smem + kGOffHd + (size_t)dl * kHotStride + 2 * pos) = 0;
-      *reinterpret_cast<unsigned short*>(smem + kGOffHs + (size_t)sl * kHotStride + 2 * pos) = 0;
+      *reinterpret_cast<unsigned short*>(smem + ((int)kGOffHd + dl * kHotStride + 2 * pos)) = 0;
+      *reinterpret_cast<unsigned short*>(smem + ((int)kGOffHs + sl * kHotStride + 2 * pos)) = 0;
     }
   }
   // ---- the graph's sums: node = 32 mb + acc_row(i, lane), column on the lane ----
@@ -318,9 +329,9 @@ __global__ __launch_bounds__(kTG, 2) void edge_dgrad_graph_kernel(const DgradGra
     for (int i = 0; i < 16; ++i) {
       const int node = 32 * mb + acc_row(i, lane);
       if (node < nn) {
-        const size_t o = (size_t)(n0 + node) * p.KP + slice * kColsG + col;
-        p.Gd[o] = gd[mb][i];
-        p.Gs[o] = gs[mb][i];
+        const size_t o = (size_t)(n0 + node) * p.ldg + slice * kColsG + col;
+        p.Gd[o] = (__bf16)gd[mb][i];
+        p.Gs[o] = (__bf16)gs[mb][i];
       }
     }
   float cdv = cd2.x + cd2.y;
@@ -339,14 +350,14 @@ int init_edge_dgrad_graph_attributes() {
 // workgroup whose graph is not inside the chunk leaves without writing).  Gd / Gs / cd rows of graphs without edges are not written.
 int launch_edge_dgrad_graph(int N, int B, const int* graph_ptr, const int* row_ptr, const int* dst, const int* src, int e_first,
                             int n_edges, const float* x, const void* table, int TC, int offP, int offQ, const float* wd,
-                            const void* g_a2, int Kd, const void* w2t, int KP, float* Gd, float* Gs, float* cd, float* gd2_part,
-                            hipStream_t st) {
+                            const void* g_a2, int Kd, const void* w2t, int KP, void* Gd, void* Gs, int ldg, float* cd,
+                            float* gd2_part, hipStream_t st) {
   if (Kd % 64 != 0 || Kd < 256 || KP % kColsG != 0) { set_error("edge dgrad (graph form): unsupported widths Kd=%d KP=%d", Kd, KP); return EGNN_EINVAL; }
   if (((size_t)n_edges + kRG) * Kd * 2 >= ((size_t)1 << 32)) { set_error("edge dgrad (graph form): chunk too large"); return EGNN_EINVAL; }
   DgradGraphParams p;
   p.N = N; p.B = B; p.graph_ptr = graph_ptr; p.row_ptr = row_ptr; p.edge_dst = dst; p.edge_src = src; p.e_base = e_first;
   p.n_edges = n_edges; p.x = x; p.table = table; p.TC = TC; p.offP = offP; p.offQ = offQ; p.wd = wd; p.g_a2 = g_a2; p.Kd = Kd;
-  p.w2t = w2t; p.KP = KP; p.Gd = Gd; p.Gs = Gs; p.cd = cd; p.gd2_part = gd2_part;
+  p.w2t = w2t; p.KP = KP; p.Gd = static_cast<__bf16*>(Gd); p.Gs = static_cast<__bf16*>(Gs); p.ldg = ldg; p.cd = cd; p.gd2_part = gd2_part;
   hipLaunchKernelGGL(edge_dgrad_graph_kernel, dim3(B * (KP / kColsG)), dim3(kTG), kSmemG, st, p);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;

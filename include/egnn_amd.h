@@ -220,15 +220,17 @@ int egcl_backward_dgrad(egnn_ctx* ctx, void* stream, int layer, const float* d_x
 
 /* The same dgrad WITHOUT dL/da1 in memory (csrc/edge_bwd_dgrad_graph.hip; replaces egcl_backward_dgrad +
  * egcl_backward_first_reduce for batches of graphs of at most 64 nodes): one workgroup per (graph, 256 hidden units) multiplies
- * g_a2 . W2, applies SiLU'(a1) on the accumulator tile and reduces it there for the first Linear layers -- Gd[n] / Gs[n] =
- * sums of g1 over the edges node n receives / sends ([N, W] fp32), cd[graph] = sum_e g1[e] d2_e ([B, W]) and the
- * (Wx + Wm) / 256 shares of dL/d(d2_e) (d_gd2_part [(Wx + Wm) / 256, n_edges]); all ASSIGNED for the graphs of the chunk (rows
- * of graphs without edges are left as they are: zero them once).  The chunk [e_first, e_first + n_edges) must consist of WHOLE
- * graphs (egnn_set_graph's graph ranges); d_g_a2x / d_g_a2m are the chunk's rows.  Follow with the node-level products and
- * egcl_backward_scatter_geom as after egcl_backward_first_reduce. */
+ * g_a2 . W2, applies SiLU'(a1) on the accumulator tile and reduces it there for the first Linear layers:
+ *   d_G  bf16 [N, 2 Wx + 2 Wm] = [Gd_x | Gs_x | Gd_m | Gs_m], Gd[n] / Gs[n] = fp32 sums of g1 over the edges node n receives /
+ *        sends, stored as the bf16 operands of the node-level products (dW1 = G^T [h | 1], dL/dh += G W1);
+ *   d_cd_x / d_cd_m [B, W] fp32: cd[graph] = sum_e g1[e] d2_e;
+ *   d_gd2_part [(Wx + Wm) / 256, n_edges]: the column-slice shares of dL/d(d2_e) for egcl_backward_scatter_geom.
+ * All ASSIGNED for the graphs of the chunk (rows of graphs without edges are left as they are: zero them once).  The chunk
+ * [e_first, e_first + n_edges) must consist of WHOLE graphs (egnn_set_graph's graph ranges); d_g_a2x / d_g_a2m are the chunk's
+ * rows. */
 int egcl_backward_dgrad_reduce(egnn_ctx* ctx, void* stream, int layer, const float* d_x, int e_first, int n_edges,
-                               const void* d_g_a2x, const void* d_g_a2m, float* d_Gd_x, float* d_Gs_x, float* d_Gd_m,
-                               float* d_Gs_m, float* d_cd_x, float* d_cd_m, float* d_gd2_part);
+                               const void* d_g_a2x, const void* d_g_a2m, void* d_G, float* d_cd_x, float* d_cd_m,
+                               float* d_gd2_part);
 
 /* Weight gradients of the backward (loss.backward() of parts/train_per_iretation.py:172 through the Linear layers of
  * EquivariantGraphNeuralNetwork.py:13-30): a reduction over ALL edges (or nodes) on the matrix cores,
