@@ -54,6 +54,7 @@ SIGNATURES = {
     "egcl_backward_gather_in": (_i, [_vp, _i, _i, _i, _i] + [_vp] * 6),
     "egcl_backward_scatter": (_i, [_vp, _i, _i, _i, _i] + [_vp] * 9),
     "egcl_backward_first_reduce": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i] + [_vp] * 9),
+    "egcl_backward_node_act": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp]),
     "egcl_backward_scatter_geom": (_i, [_vp, _i, _i] + [_vp] * 8),
     "egcl_backward_fused_supported": (_i, [_vp]),
     "egcl_backward_table": (_i, [_vp, _vp, _i, _vp]),
@@ -65,7 +66,7 @@ SIGNATURES = {
     "egnn_gemm_tn_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
     "egnn_gemm_tn_bf16": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _f, _vp, _i, _i, _i, _i, _vp, C.c_size_t]),
     "egnn_gemm_rows_pack": (_i, [_vp, _i, _i, _vp, _i, _vp]),
-    "egnn_gemm_rows_bf16": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i]),
+    "egnn_gemm_rows_bf16": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i]),
     "egnn_gamma_tilde": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "egnn_dense_rows": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "egnn_eps": (_i, [_vp, _i, _i, _i, _vp, _i] + [_vp] * 5),

@@ -309,18 +309,19 @@ def _node_backward_hip(layer, h_l, sum_m, gh, grads):
     hcat = torch.zeros(N, max(K1k, K1n), **bf)
     hcat[:, :H] = h_l
     hcat[:, H:K1] = sum_m
-    z1 = linear_rows(hcat, lin1.weight, k=K1k) + lin1.bias.detach()
-    sg = torch.sigmoid(z1)
-    s_act = z1 * sg
+    z1 = linear_rows(hcat, lin1.weight, k=K1k)                    # (without the bias: the activation stage adds it)
     ghb = torch.zeros(N, 128, **bf)                               # gh as a GEMM operand: H <= 64 real columns
     ghb[:, :H] = gh
     g_s = linear_rows(ghb, lin2.weight.detach().t(), k=64)        # [N, Wh] = gh @ W2
-    g_z1 = g_s * (sg * (1.0 + z1 * (1.0 - sg)))
-    g_z1b, s_b = g_z1.to(torch.bfloat16), s_act.to(torch.bfloat16)
     Wh = lin1.weight.shape[0]
+    # s = SiLU(z1 + b1), dL/dz1 = dL/ds * SiLU'(z1 + b1) as bf16 operands and the bias gradient, in one pass (backward.hip)
+    g_z1b, s_b = torch.empty(N, Wh, **bf), torch.empty(N, Wh, **bf)
+    g_b1 = torch.zeros(Wh, dtype=torch.float32, device=h_l.device)
+    _lib.check(_lib.lib().egcl_backward_node_act(_lib.stream_ptr(), N, Wh, _lib.ptr(z1), z1.stride(0), _lib.ptr(lin1.bias.detach()),
+                                                 _lib.ptr(g_s), g_s.stride(0), _lib.ptr(g_z1b), _lib.ptr(s_b), Wh, _lib.ptr(g_b1)))
     acc = lambda p_, g_: grads.__setitem__(p_, grads.get(p_, 0) + g_)
     acc(lin2.bias, gh.sum(0))
-    acc(lin1.bias, g_z1.sum(0))
+    acc(lin1.bias, g_b1)
     acc(lin2.weight, gemm_tn(s_b, ghb, rows=Wh, cols=H).t())                     # [Wh, H]^T
     acc(lin1.weight, gemm_tn(g_z1b, hcat, rows=Wh, cols=K1))                     # [Wh, H + M]
     g_cat = linear_rows(g_z1b, lin1.weight.detach().t())                         # [N, H + M] = dL/dz1 @ W1

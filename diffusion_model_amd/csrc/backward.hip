@@ -322,6 +322,46 @@ __global__ __launch_bounds__(kThreads) void bwd_gather_rows_kernel(int n_edges, 
 // once per run; the src side is one atomic add per edge.  One workgroup = kScatRows consecutive edges, one thread
 // per column of [g_h (dst) | g_h (src) | g_x].
 constexpr int kScatRows = 64;
+// ---- node MLP backward, activation stage (mlp_h: Linear -> SiLU -> Linear, EquivariantGraphNeuralNetwork.py:26-30 under autograd):
+//     s = SiLU(z + b1) and dL/dz = dL/ds * SiLU'(z + b1) as the bf16 operands of the weight-gradient / dgrad products, and the
+//     bias gradient (column sums of dL/dz) -- one pass instead of a dozen element-wise launches over [N, W] fp32.
+// block = 256 threads = 4 row lanes x 64 column quads (256 columns), 64 rows per block
+__global__ __launch_bounds__(256) void node_act_bwd_kernel(int N, int W, const float* __restrict__ z, int ldz, const float* __restrict__ b1,
+                                                           const float* __restrict__ gs, int ldg, __bf16* __restrict__ gz_out,
+                                                           __bf16* __restrict__ s_out, int ldo, float* __restrict__ g_b1) {
+  __shared__ float red[4][256];
+  const int cq = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = 256 * blockIdx.y + 4 * cq;
+  const int r0 = 64 * blockIdx.x;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < W) {
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(b1 + c);
+    for (int i = 0; i < 16; ++i) {
+      const int row = r0 + rl + 4 * i;
+      if (row >= N) break;
+      const f32x4 zv = *reinterpret_cast<const f32x4*>(z + (size_t)row * ldz + c);
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(gs + (size_t)row * ldg + c);
+      __bf16 go[4], so[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float a = zv[k] + bb[k];
+        const float sg = 1.0f / (1.0f + __expf(-a));
+        const float g = gv[k] * (sg * (1.0f + a * (1.0f - sg)));
+        cs[k] += g;
+        go[k] = (__bf16)g;
+        so[k] = (__bf16)(a * sg);
+      }
+      *reinterpret_cast<uint2*>(gz_out + (size_t)row * ldo + c) = *reinterpret_cast<const uint2*>(go);
+      *reinterpret_cast<uint2*>(s_out + (size_t)row * ldo + c) = *reinterpret_cast<const uint2*>(so);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) red[rl][4 * cq + k] = cs[k];
+  __syncthreads();
+  const int cc = 256 * blockIdx.y + threadIdx.x;
+  if (cc < W) atomicAdd(g_b1 + cc, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 template <typename T>
 __global__ __launch_bounds__(kThreads) void bwd_scatter_kernel(int n_edges, int H, int K1P, const int* __restrict__ dst,
                                                                 const int* __restrict__ src, const float* __restrict__ x,
@@ -596,6 +636,19 @@ int egcl_backward_gather_in(void* stream, int prec, int n_edges, int H, int K1P,
     hipLaunchKernelGGL(bwd_gather_kernel<__bf16>, grid, block, 0, st, n_edges, H, K1P, dst, src, h, x, static_cast<__bf16*>(in_out), d2_out);
   else
     hipLaunchKernelGGL(bwd_gather_kernel<float>, grid, block, 0, st, n_edges, H, K1P, dst, src, h, x, static_cast<float*>(in_out), d2_out);
+  EGNN_HIP(hipGetLastError());
+  return EGNN_OK;
+}
+
+int egcl_backward_node_act(void* stream, int N, int W, const float* z, int ldz, const float* b1, const float* g_s, int ldg,
+                           void* g_z_out, void* s_out, int ldo, float* g_b1) {
+  if (N < 1 || W < 4 || W % 4 != 0 || ldz < W || ldg < W || ldo < W || ldz % 4 != 0 || ldg % 4 != 0 || ldo % 4 != 0 || !z || !b1 || !g_s ||
+      !g_z_out || !s_out || !g_b1) {
+    set_error("bad egcl_backward_node_act arguments (W and the row strides multiples of 4)");
+    return EGNN_EINVAL;
+  }
+  hipLaunchKernelGGL(node_act_bwd_kernel, dim3((N + 63) / 64, (W + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), N, W, z,
+                     ldz, b1, g_s, ldg, static_cast<__bf16*>(g_z_out), static_cast<__bf16*>(s_out), ldo, g_b1);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }

@@ -20,8 +20,8 @@ struct GemmRowsParams {
   int lda[2], K[2];     // K % 64 == 0 (K[1] = 0: one operand)
   const void* W[2];     // bf16 fragments [K / 64][4 k-steps][4 column blocks][64][8]: B[k = c][n]
   int E;
-  void* out;            // bf16 (or fp32) [E][ldo], 128 columns written
-  int ldo;
+  void* out;            // bf16 (or fp32) [E][ldo], 128 columns written per column chunk (blockIdx.y): chunk j -> columns 128 j ..
+  int ldo;              // (the W packs of chunk j follow those of chunk j - 1: K * 128 elements each)
   int out_f32;          // 1: fp32 output (node MLP products, where the result feeds a nonlinearity's derivative)
 };
 
@@ -40,12 +40,13 @@ __global__ __launch_bounds__(kTR, 2) void gemm_rows_kernel(const GemmRowsParams 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, hh = lane >> 5;
-  const int e0 = blockIdx.x * kRows;
+  const int e0 = blockIdx.x * kRows, chunk = blockIdx.y;
   const int steps0 = p.K[0] / kKS, nsteps = steps0 + p.K[1] / kKS;
   const rsrc_t rs_a0 = make_rsrc(p.A[0], (unsigned)min((size_t)p.E * p.lda[0] * 2, (size_t)0xFFFFFFFFu));
   const rsrc_t rs_a1 = make_rsrc(p.A[1] ? p.A[1] : p.A[0], p.A[1] ? (unsigned)min((size_t)p.E * p.lda[1] * 2, (size_t)0xFFFFFFFFu) : 0u);
-  const rsrc_t rs_w0 = make_rsrc(p.W[0], (unsigned)((size_t)128 * p.K[0] * 2));
-  const rsrc_t rs_w1 = make_rsrc(p.W[1] ? p.W[1] : p.W[0], (unsigned)((size_t)128 * (p.W[1] ? p.K[1] : p.K[0]) * 2));
+  const rsrc_t rs_w0 = make_rsrc(static_cast<const char*>(p.W[0]) + (size_t)chunk * 128 * p.K[0] * 2, (unsigned)((size_t)128 * p.K[0] * 2));
+  const rsrc_t rs_w1 = make_rsrc(p.W[1] ? static_cast<const char*>(p.W[1]) + (size_t)chunk * 128 * p.K[1] * 2 : static_cast<const char*>(p.W[0]),
+                                 (unsigned)((size_t)128 * (p.W[1] ? p.K[1] : p.K[0]) * 2));
   // staging: wave instruction i = wave + 8 k (k = 0..3) covers rows 8 i .. 8 i + 7 of the tile; lane -> (row, LDS piece)
   unsigned vrow[4], vpiece[4];
 #pragma unroll
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(kTR, 2) void gemm_rows_kernel(const GemmRowsParams 
   __builtin_amdgcn_s_barrier();                // the ring is free: reused as store staging
 #undef VM_WAIT
   if (p.out_f32) {   // accumulator layout straight to memory: 128 contiguous bytes per half-wave and row
-    float* out = static_cast<float*>(p.out) + (size_t)(e0 + 32 * wave) * p.ldo;
+    float* out = static_cast<float*>(p.out) + (size_t)(e0 + 32 * wave) * p.ldo + 128 * chunk;
     const int nrows = p.E - (e0 + 32 * wave);
 #pragma unroll
     for (int nb = 0; nb < kNB; ++nb)
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(kTR, 2) void gemm_rows_kernel(const GemmRowsParams 
   }
   // ---- store: 32 rows x 128 columns per wave as row-major bf16 (two 64-column halves through the per-wave staging tile) ----
   __bf16* stg = reinterpret_cast<__bf16*>(smem) + (size_t)wave * 32 * 72;
-  __bf16* out = static_cast<__bf16*>(p.out) + (size_t)(e0 + 32 * wave) * p.ldo;
+  __bf16* out = static_cast<__bf16*>(p.out) + (size_t)(e0 + 32 * wave) * p.ldo + 128 * chunk;
   const int nrows = p.E - (e0 + 32 * wave);
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
@@ -126,21 +127,25 @@ __global__ __launch_bounds__(kTR, 2) void gemm_rows_kernel(const GemmRowsParams 
 
 }  // namespace
 
-int launch_gemm_rows(const GemmRowsParams& p, hipStream_t st) {
+int launch_gemm_rows(const GemmRowsParams& p, int nchunks, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
     EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL(gemm_rows_kernel, dim3((p.E + kRows - 1) / kRows), dim3(kTR), kSmemR, st, p);
+  hipLaunchKernelGGL(gemm_rows_kernel, dim3((p.E + kRows - 1) / kRows, nchunks), dim3(kTR), kSmemR, st, p);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }
 
-// W [K][ldw] row-major fp32 (first `ncols` columns used, the rest of the 128 zero) -> bf16 B fragments
-// [K / 64 steps][4 k-steps][4 column blocks][64 lanes][8]: lane l holds B[k = 64 step + 16 ks + 8 (l >> 5) + j][n = 32 nb + (l & 31)]
+// W [K][ldw] row-major fp32 (first `ncols` columns used, the rest of the last 128-column chunk zero) -> bf16 B fragments, per
+// chunk (blockIdx.y) [K / 64 steps][4 k-steps][4 column blocks][64 lanes][8]: lane l holds
+// B[k = 64 step + 16 ks + 8 (l >> 5) + j][n = 128 chunk + 32 nb + (l & 31)]
 __global__ void pack_rows_weights_kernel(const float* __restrict__ W, int K, int ldw, int ncols, __bf16* __restrict__ out) {
   const size_t total = (size_t)K * 128;
+  W += 128 * blockIdx.y;
+  ncols -= 128 * blockIdx.y;
+  out += total * blockIdx.y;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int j = i & 7, lane = (i >> 3) & 63;
     const size_t f = i >> 9;                 // fragment index = (step * 4 + ks) * 4 + nb
@@ -150,7 +155,7 @@ __global__ void pack_rows_weights_kernel(const float* __restrict__ W, int K, int
   }
 }
 int launch_pack_rows_weights(const float* W, int K, int ldw, int ncols, void* out, hipStream_t st) {
-  hipLaunchKernelGGL(pack_rows_weights_kernel, dim3(128), dim3(256), 0, st, W, K, ldw, ncols, static_cast<__bf16*>(out));
+  hipLaunchKernelGGL(pack_rows_weights_kernel, dim3(128, (ncols + 127) / 128), dim3(256), 0, st, W, K, ldw, ncols, static_cast<__bf16*>(out));
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }
@@ -162,24 +167,25 @@ using namespace egnn;
 extern "C" {
 
 int egnn_gemm_rows_pack(void* stream, int K, int ncols, const float* d_W, int ldw, void* d_frags_out) {
-  if (K < 64 || K % 64 != 0 || ncols < 1 || ncols > 128 || ldw < ncols || !d_W || !d_frags_out) {
-    set_error("egnn_gemm_rows_pack: need K %% 64 == 0, 1 <= ncols <= 128");
+  if (K < 64 || K % 64 != 0 || ncols < 1 || ncols > 128 * 65535 || ldw < ncols || !d_W || !d_frags_out) {
+    set_error("egnn_gemm_rows_pack: need K %% 64 == 0, ncols >= 1");
     return EGNN_EINVAL;
   }
   return launch_pack_rows_weights(d_W, K, ldw, ncols, d_frags_out, reinterpret_cast<hipStream_t>(stream));
 }
 
 int egnn_gemm_rows_bf16(void* stream, int E, const void* d_A0, int lda0, int K0, const void* d_W0, const void* d_A1, int lda1, int K1,
-                        const void* d_W1, void* d_out, int ldo, int out_f32) {
+                        const void* d_W1, void* d_out, int ldo, int out_f32, int n_chunks) {
   {
     const int rc = gemm_rows_args_check(E, d_A0, lda0, K0, d_W0, d_A1, lda1, K1, d_W1, d_out, ldo);   // host_logic.cpp
     if (rc) return rc;
+    if (n_chunks < 1 || n_chunks > 65535 || ldo < 128 * n_chunks) { set_error("egnn_gemm_rows_bf16: %d column chunks need ldo >= %d", n_chunks, 128 * n_chunks); return EGNN_EINVAL; }
   }
   GemmRowsParams p;
   p.A[0] = d_A0; p.lda[0] = lda0; p.K[0] = K0; p.W[0] = d_W0;
   p.A[1] = d_A1; p.lda[1] = d_A1 ? lda1 : 0; p.K[1] = d_A1 ? K1 : 0; p.W[1] = d_A1 ? d_W1 : nullptr;
   p.E = E; p.out = d_out; p.ldo = ldo; p.out_f32 = out_f32 ? 1 : 0;
-  return launch_gemm_rows(p, reinterpret_cast<hipStream_t>(stream));
+  return launch_gemm_rows(p, n_chunks, reinterpret_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

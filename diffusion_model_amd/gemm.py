@@ -48,32 +48,33 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, rows: int | None = None, cols: int
 
 
 def pack_rows_weights(w: torch.Tensor, ncols: int | None = None) -> torch.Tensor:
-    """fragment pack of an fp32 [K, >= ncols] matrix for ``gemm_rows`` (K % 64 == 0, ncols <= 128)"""
+    """fragment pack of an fp32 [K, >= ncols] matrix for ``gemm_rows`` (K % 64 == 0): K * 128 bf16 per chunk of 128 columns"""
     if not w.is_cuda or w.dtype != torch.float32 or w.dim() != 2 or w.stride(1) != 1:
         raise ValueError("pack_rows_weights: fp32 CUDA(ROCm) [K, n] matrix with unit column stride")
     K = w.shape[0]
     ncols = w.shape[1] if ncols is None else ncols
-    out = torch.empty(K * 128, dtype=torch.bfloat16, device=w.device)
+    out = torch.empty((ncols + 127) // 128 * K * 128, dtype=torch.bfloat16, device=w.device)
     _lib.check(_lib.lib().egnn_gemm_rows_pack(_lib.stream_ptr(), K, ncols, _lib.ptr(w), w.stride(0), _lib.ptr(out)))
     return out
 
 
 def gemm_rows(a0: torch.Tensor, w0: torch.Tensor, a1: torch.Tensor | None = None, w1: torch.Tensor | None = None,
-              out: torch.Tensor | None = None, k0: int | None = None) -> torch.Tensor:
-    """out[e, :128] = a0[e, :k0] @ W0 (+ a1[e] @ W1), bf16 operands, fp32 accumulate, W as packed by ``pack_rows_weights``;
-    ``out`` bf16 (default) or fp32, any row stride >= 128 (a 128-column slice of a wider matrix is fine)
-    (egnn_gemm_rows_bf16: every operand row is streamed once)."""
+              out: torch.Tensor | None = None, k0: int | None = None, chunks: int = 1) -> torch.Tensor:
+    """out[e, :128 chunks] = a0[e, :k0] @ W0 (+ a1[e] @ W1), bf16 operands, fp32 accumulate, W as packed by
+    ``pack_rows_weights`` (``chunks`` column chunks of 128 in one launch); ``out`` bf16 (default) or fp32, any row stride
+    >= 128 chunks (a slice of a wider matrix is fine)  (egnn_gemm_rows_bf16: every operand row is streamed once per chunk)."""
     if not a0.is_cuda or a0.dtype != torch.bfloat16 or a0.dim() != 2 or a0.stride(1) != 1:
         raise RuntimeError("gemm_rows needs bf16 CUDA(ROCm) row-major operands; there is no CPU fallback")
     E = a0.shape[0]
     k0 = a0.shape[1] if k0 is None else k0
     if out is None:
-        out = torch.empty(E, 128, dtype=torch.bfloat16, device=a0.device)
-    if out.dtype not in (torch.bfloat16, torch.float32) or out.shape[0] < E or out.stride(1) != 1 or out.stride(0) < 128:
-        raise ValueError("gemm_rows: out must be bf16 / fp32 [>= E rows] with a row stride >= 128")
+        out = torch.empty(E, 128 * chunks, dtype=torch.bfloat16, device=a0.device)
+    if out.dtype not in (torch.bfloat16, torch.float32) or out.shape[0] < E or out.stride(1) != 1 or out.stride(0) < 128 * chunks:
+        raise ValueError("gemm_rows: out must be bf16 / fp32 [>= E rows] with a row stride >= 128 per column chunk")
     _lib.check(_lib.lib().egnn_gemm_rows_bf16(_lib.stream_ptr(), E, _lib.ptr(a0), a0.stride(0), k0, _lib.ptr(w0),
                                               _lib.ptr(a1), 0 if a1 is None else a1.stride(0), 0 if a1 is None else a1.shape[1],
-                                              _lib.ptr(w1), _lib.ptr(out), out.stride(0), 1 if out.dtype == torch.float32 else 0))
+                                              _lib.ptr(w1), _lib.ptr(out), out.stride(0), 1 if out.dtype == torch.float32 else 0,
+                                              int(chunks)))
     return out
 
 
@@ -84,8 +85,7 @@ def linear_rows(a: torch.Tensor, weight: torch.Tensor, k: int | None = None) -> 
     k = a.shape[1] if k is None else k
     wt = torch.zeros(k, n_out, dtype=torch.float32, device=a.device)
     wt[:n_in] = weight.detach().float().t()
-    out = torch.empty(a.shape[0], (n_out + 127) // 128 * 128, dtype=torch.float32, device=a.device)
-    for j in range(0, n_out, 128):
-        nc = min(128, n_out - j)
-        gemm_rows(a, pack_rows_weights(wt[:, j:j + nc].contiguous(), nc), out=out[:, j:], k0=k)
+    chunks = (n_out + 127) // 128
+    out = torch.empty(a.shape[0], chunks * 128, dtype=torch.float32, device=a.device)
+    gemm_rows(a, pack_rows_weights(wt, n_out), out=out, k0=k, chunks=chunks)   # all column chunks in one launch
     return out[:, :n_out]

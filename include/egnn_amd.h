@@ -157,6 +157,13 @@ int egcl_backward_scatter(void* stream, int prec, int n_edges, int H, int K1P, c
                           const int32_t* d_src, const float* d_x, const void* d_g_in, const float* d_g_diff,
                           const float* d_g_sq_sums, const int32_t* d_node_segment, float* d_g_h, float* d_g_x);
 
+/* Node MLP backward, activation stage (mlp_h = Linear -> SiLU -> Linear, :26-30 under autograd): from the recomputed first-layer
+ * product z [N, ldz] fp32 (WITHOUT its bias b1 [W]) and dL/ds [N, ldg] fp32, one pass writes s = SiLU(z + b1) and
+ * dL/dz = dL/ds * SiLU'(z + b1) as bf16 [N, ldo] (the operands of the weight-gradient / dgrad products) and ADDS the bias
+ * gradient (column sums of dL/dz) to d_g_b1 [W] (fp32 atomics: zero it first).  W and the row strides multiples of 4. */
+int egcl_backward_node_act(void* stream, int N, int W, const float* d_z, int ldz, const float* d_b1, const float* d_g_s, int ldg,
+                           void* d_g_z_out, void* d_s_out, int ldo, float* d_g_b1);
+
 /* First Linear layers of both edge MLPs, factorised as the forward factorises them (csrc/edge_bwd_first.hip): ONE pass over
  * dL/da1 (d_g1x [n_edges, Wx], d_g1m [n_edges, Wm], bf16; the outputs of egcl_backward_dgrad for the edges
  * [e_first, e_first + n_edges) of the plan) produces, for batches of graphs of at most 64 nodes, the per-node sums
@@ -247,11 +254,13 @@ int egnn_gemm_tn_bf16(void* stream, int E, int M, int N, const void* d_A, int ld
 /* First-layer dgrad of the backward (autograd through the first Linear of mlp_x / mlp_m, :13, :19): a row-streaming product
  *     out[e][n] = sum_c A0[e][c] W0[c][n] + sum_c A1[e][c] W1[c][n],   n < 128,
  * A0 / A1 row-major bf16 [E, lda] (dL/da1 of the two MLPs; A1 may be NULL), out bf16 [E, ldo] (128 columns written);
- * W0 / W1 are fragment packs made by egnn_gemm_rows_pack from fp32 [K, ldw] matrices whose first ncols (<= 128) columns are
- * used (K * 128 bf16 each).  K % 64 == 0.  Replaces torch.mm + addmm_ (round 2). */
+ * W0 / W1 are fragment packs made by egnn_gemm_rows_pack from fp32 [K, ldw] matrices whose first ncols columns are used:
+ * K * 128 bf16 per chunk of 128 columns, chunk after chunk (ceil(ncols / 128) chunks).  K % 64 == 0.  n_chunks column chunks
+ * run in ONE launch (out columns 128 j .. 128 j + 127 from chunk j of both packs; ldo >= 128 n_chunks): the node MLP's
+ * backward products are 8 chunks wide over only N / 256 row blocks.  Replaces torch.mm + addmm_ (round 2). */
 int egnn_gemm_rows_pack(void* stream, int K, int ncols, const float* d_W, int ldw, void* d_frags_out);
 int egnn_gemm_rows_bf16(void* stream, int E, const void* d_A0, int lda0, int K0, const void* d_W0, const void* d_A1, int lda1,
-                        int K1, const void* d_W1, void* d_out, int ldo, int out_f32);   /* out_f32: fp32 [E, ldo] output */
+                        int K1, const void* d_W1, void* d_out, int ldo, int out_f32 /* fp32 [E, ldo] output */, int n_chunks);
 
 /* EquivariantGNN.forward(edge_index, h, x) -> (h_L, x_L) (:85-88): all L layers. */
 int egnn_forward(egnn_ctx* ctx, void* stream, int prec, int norm_scope,

@@ -327,10 +327,10 @@ def test_gemm_tn_matches_fp64_reference(E, M, N, lda, ldb):
     assert torch.equal(gemm_tn(a, b, rows=M, cols=N), got)          # slices are added in a fixed order: bitwise repeatable
 
 
-@pytest.mark.parametrize("E,K0,K1,ncols", [(1000, 256, 0, 74), (70001, 1024, 1024, 74), (5000, 64, 192, 128)])
+@pytest.mark.parametrize("E,K0,K1,ncols", [(1000, 256, 0, 74), (70001, 1024, 1024, 74), (5000, 64, 192, 128), (3000, 320, 64, 300)])
 def test_gemm_rows_matches_fp64_reference(E, K0, K1, ncols):
     """egnn_gemm_rows_bf16 (row-streaming product, LDS-DMA staged operands) against a float64 product of the same bf16
-    values; the output is rounded to bf16 once (2^-9 relative)."""
+    values; the output is rounded to bf16 once (2^-9 relative).  ncols > 128: several 128-column chunks in one launch."""
     from diffusion_model_amd.gemm import gemm_rows, pack_rows_weights
     g = torch.Generator().manual_seed(E)
     a0 = torch.randn(E, K0, generator=g).to(torch.bfloat16).to(DEV)
@@ -341,12 +341,14 @@ def test_gemm_rows_matches_fp64_reference(E, K0, K1, ncols):
         a1 = torch.randn(E, K1, generator=g).to(torch.bfloat16).to(DEV)
         w1 = torch.randn(K1, ncols, generator=g).to(DEV)
         want = want + a1.double().cpu() @ w1.to(torch.bfloat16).double().cpu()
-    out = gemm_rows(a0, pack_rows_weights(w0), a1, None if w1 is None else pack_rows_weights(w1))
+    chunks = (ncols + 127) // 128
+    out = gemm_rows(a0, pack_rows_weights(w0), a1, None if w1 is None else pack_rows_weights(w1), chunks=chunks)
+    assert out.shape[1] == 128 * chunks
     got = out[:, :ncols].double().cpu()
     err = float((got - want).abs().max() / want.abs().max())
     print(f"gemm_rows E={E} K={K0}+{K1} n={ncols}: max err / max |out| = {err:.2e}")
     assert err <= 6e-3                                     # bf16 output rounding
-    assert float(out[:, ncols:].abs().max()) == 0.0 if ncols < 128 else True
+    assert float(out[:, ncols:].abs().max()) == 0.0 if ncols < 128 * chunks else True
 
 
 def test_gamma_network_and_compressor_device_kernels_match_reference_golden():
