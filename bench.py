@@ -259,9 +259,17 @@ def train_leg(args, rk, steps, warmup, batch):
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_train.json")))
         if args.precision == "bf16" and batch == 256 and n == 64 and L == 4:
-            train_traffic = tj["bytes_per_step"]
-            train_traffic_src = (f"profiles/traffic_train.json (rocprofv3 --pmc, separate passes of `bench.py --mode train` at git head "
-                                 f"{tj.get('git_head', '?')}: sum over the step's dispatches of FETCH_SIZE x 2 + WRITE_SIZE)")
+            from diffusion_model_amd import _lib as _l
+            # (valid for the kernels AND the launch sequence it was measured on: fingerprint of csrc/, the flags, autograd.py, gemm.py)
+            if tj.get("training_sources_sha256") == _l.training_sources_sha256():
+                train_traffic = tj["bytes_per_step"]
+                train_traffic_src = (f"profiles/traffic_train.json (rocprofv3 --pmc, separate passes of `bench.py --mode train` at git head "
+                                     f"{tj.get('git_head', '?')}, source fingerprint {tj['training_sources_sha256'][:16]} == this tree's: "
+                                     f"sum over the step's dispatches of FETCH_SIZE x 2 + WRITE_SIZE)")
+            else:
+                train_traffic_src = ("profiles/traffic_train.json was measured on other sources (fingerprint " +
+                                     str(tj.get("training_sources_sha256"))[:12] + " vs " + _l.training_sources_sha256()[:12] +
+                                     "): re-run tools/profile_train_pmc.sh")
     except Exception:
         pass
     out["roofline"] = {"bound": "mfma", "achieved": 3 * fwd_flop / (el / steps) / 1e12, "peak": PEAK_TFLOPS["bf16"],

@@ -30,6 +30,24 @@ def edge_kernel_sources_sha256() -> str:
     return h.hexdigest()
 
 
+def training_sources_sha256() -> str:
+    """Fingerprint of everything the HBM traffic of ONE training step depends on: every kernel source and header of the
+    library, the compiler flags and the launch sequence (autograd.py, gemm.py): what profiles/traffic_train.json is valid for."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(_HERE, "csrc")
+    names = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.cpp")))
+    names += [os.path.join(_HERE, "autograd.py"), os.path.join(_HERE, "gemm.py")]
+    for path in names:
+        with open(path, "rb") as f:
+            h.update(os.path.basename(path).encode() + b"\0" + f.read())
+    with open(os.path.join(os.path.dirname(_HERE), "Makefile"), "rb") as f:
+        flags = [l for l in f.read().splitlines() if l.startswith(b"FLAGS")]
+    h.update(b"\n".join(flags))
+    return h.hexdigest()
+
+
 _vp, _i, _f, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_uint64
 _fp = C.POINTER(C.c_float)
 

@@ -11,6 +11,8 @@ python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/$tag/smoke.log 2
 if [ "$2" = "profile" ]; then
   GIT_HEAD=${GIT_HEAD:-unknown} bash tools/profile.sh $tag > gpurun_out/$tag/profile.log 2>&1; echo "profile rc=$?"
   cp gpurun_out/prof_$tag/traffic.json profiles/traffic.json 2>/dev/null   # the bench lines below quote it (fingerprint of the edge-kernel sources)
+  GIT_HEAD=${GIT_HEAD:-unknown} bash tools/profile_train_pmc.sh ${tag}_train > gpurun_out/$tag/profile_train.log 2>&1; echo "profile_train rc=$?"
+  cp gpurun_out/prof_${tag}_train/traffic_train.json profiles/traffic_train.json 2>/dev/null   # (fingerprint of csrc/ + autograd.py + gemm.py)
 fi
 python bench.py > gpurun_out/$tag/bench_c2.json 2> gpurun_out/$tag/bench_c2.err; echo "c2 rc=$?"
 python bench.py --atoms 512 --batch 32 --steps 5 --warmup 2 --reps 3 --no-cpu-baseline > gpurun_out/$tag/bench_c3.json 2> gpurun_out/$tag/bench_c3.err; echo "c3 rc=$?"

@@ -29,7 +29,10 @@ def total(sub, counter):
 
 fetch, write = total("pmc_fetch", "FETCH_SIZE"), total("pmc_write", "WRITE_SIZE")
 by_kernel = {k: (2 * fetch.get(k, 0.0) + write.get(k, 0.0)) * 1024 / nsteps for k in set(fetch) | set(write)}
-doc = {"comment": __doc__.split("usage")[0].strip(), "git_head": head, "source": os.path.basename(out.rstrip("/")),
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from diffusion_model_amd import _lib  # noqa: E402  (no GPU call: only the source fingerprint)
+
+doc = {"comment": __doc__.split("usage")[0].strip(), "git_head": head, "training_sources_sha256": _lib.training_sources_sha256(), "source": os.path.basename(out.rstrip("/")),
        "workload": "bench.py --mode train: 256 graphs x 64 atoms per rank, bf16, kept activations",
        "bytes_per_step": sum(by_kernel.values()),
        "largest": {k: v for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1])[:14]}}
