@@ -214,8 +214,11 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_
                                              P(g_b3), P(g_b2m), P(g_wa), P(g_ba)))
         # a2x / a2m now hold dL/da2: wgrad and dgrad of the second Linear layers
         if hip:   # reductions over the chunk's edges on the library's own split-K kernel (gemm_tn.hip), fp32 accumulate
-            gemm_tn(a2x, s1x, out=g_w2x, accumulate=True)
-            gemm_tn(a2m, s1m, out=g_w2m, accumulate=True)
+            # (the recompute / keeping kernels store s1 as the MFMA consumed it, -log2(e) * SiLU(a1): undone by the scale.
+            # Measured and dropped: the message head on a second stream beside the coordinate MLP's product -- HBM-bound
+            # beside MFMA-bound -- made the step 1.0 ms LONGER, 51.8 vs 50.8 ms on one box)
+            gemm_tn(a2x, s1x, out=g_w2x, accumulate=True, scale=-math.log(2.0))
+            gemm_tn(a2m, s1m, out=g_w2m, accumulate=True, scale=-math.log(2.0))
         else:
             g_w2x += _wgrad(A2X, S1X, n_pad, 16)
             g_w2m += _wgrad(A2M, S1M, n_pad, 32)
@@ -252,7 +255,7 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_
         _lib.check(L.egcl_backward_scatter(st, prec, n, H, K1P, P(d32), P(s32), P(x), P(g_in), P(g_diff), P(g_S),
                                            P(node_seg), P(g_h), P(g_x)))
 
-    if fused is not None:   # the recompute kernels store s1 as the MFMA consumed it: -log2(e) * SiLU(a1)
+    if fused is not None and not hip:   # the recompute kernels store s1 as the MFMA consumed it: -log2(e) * SiLU(a1)
         g_w2x *= -math.log(2.0)
         g_w2m *= -math.log(2.0)
     if first == "graph":   # node-level products of the factorised first layers on the library's own GEMMs (N rows, bf16 operands)

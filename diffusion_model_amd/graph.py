@@ -139,6 +139,7 @@ def fully_connected_plan(sizes: Sequence[int], device="cuda") -> "GraphPlan":
                                               _lib.ptr(plan.edge_dst) if plan.E else None,
                                               _lib.ptr(plan.edge_src) if plan.E else None))
     plan._keep = base_d
+    plan.graph_edge_ptr = [0] + torch.cumsum(per, 0).tolist()   # host copy of every graph's edge range (known without a sync)
     return plan
 
 
@@ -162,6 +163,7 @@ def radius_plan(x: torch.Tensor, sizes: Sequence[int], radius: float) -> "GraphP
         _lib.check(_lib.lib().egnn_radius_graph_fill(_lib.stream_ptr(), plan.N, _lib.ptr(xc), _lib.ptr(plan.graph_ptr),
                                                      _lib.ptr(plan.node_graph), float(radius), _lib.ptr(plan.row_ptr),
                                                      _lib.ptr(plan.edge_dst), _lib.ptr(plan.edge_src)))
+    plan.graph_edge_ptr = plan.row_ptr[plan.graph_ptr.long()].tolist()   # (the edge count above synchronised already)
     return plan
 
 

@@ -442,6 +442,104 @@ def test_saved_activation_backward_matches_recompute(monkeypatch):
         assert rel_err(out["1"][1][k].cpu(), out["0"][1][k].cpu()) <= 3e-2, k
 
 
+def test_backward_chunks_are_cut_at_graph_boundaries():
+    """host logic of the graph-form backward: chunks of WHOLE graphs with at most `rows` edges; None when one graph alone has
+    more (the caller then takes the chain that may cut anywhere)"""
+    from types import SimpleNamespace
+    from diffusion_model_amd.autograd import _graph_chunks
+    plan = SimpleNamespace(graph_edge_ptr=[0, 12, 12, 42, 48, 104])      # five graphs, the second without edges
+    assert _graph_chunks(plan, 1000) == [(0, 104)]
+    assert _graph_chunks(plan, 60) == [(0, 48), (48, 56)]
+    assert _graph_chunks(plan, 56) == [(0, 48), (48, 56)]
+    assert _graph_chunks(plan, 42) is None                                              # the last graph alone has 56
+    assert _graph_chunks(plan, 12) is None
+    assert _graph_chunks(SimpleNamespace(), 100) is None                                # a plan without the host copy
+    got = _graph_chunks(SimpleNamespace(graph_edge_ptr=[0, 30, 60, 90, 120]), 64)
+    assert got == [(0, 60), (60, 60)] and sum(n for _, n in got) == 120
+    cpu_plan = dma.GraphPlan(fully_connected_edge_index([3, 1, 4]), 8, sizes=[3, 1, 4])
+    assert cpu_plan.graph_edge_ptr == [0, 6, 6, 18] and cpu_plan.max_graph_nodes == 4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graphs", ["fully_connected", "radius"])
+def test_graph_form_backward_against_the_chain_and_fp32_incl_input_gradients(graphs, monkeypatch):
+    """the per-graph fused dgrad (csrc/edge_bwd_dgrad_graph.hip: dL/da1 never stored, per-node sums on the matrix cores, node-level
+    products) against the round-3 chain (dL/da1 stored, gather / GEMMs over all edges / scatter) on the SAME kept activations and
+    against the fp32 backward: every parameter gradient AND the gradients with respect to the inputs h and x, ragged graphs (one
+    without edges, one of 64 nodes), chunks of one or two graphs.  "radius": sparse graphs of uneven degree (atoms without any
+    edge inside a graph, tiles with dozens of receivers) from the device radius-graph builder.  The bar: the graph form is as
+    close to the fp32 gradients as the chain is (it is closer where the chain rounds dL/d(d^2) to bf16: input x, layer 0's
+    coordinate MLP -- measured 7.5e-3 against 2.6e-2 on the radius graphs), and within 5e-2 of the chain."""
+    from diffusion_model_amd import autograd as _ag
+    H = 36
+    d = dims_for(H, 256, 1024, 1024, 1024)
+    sizes = (33, 64, 1, 17, 50)
+    n = sum(sizes)
+    dev = "cuda"
+    g = torch.Generator().manual_seed(12)
+    h0, x0 = torch.randn(n, H, generator=g), torch.randn(n, 3, generator=g) * 1.5
+    wh, wx = torch.randn(n, H, generator=g), torch.randn(n, 3, generator=g)
+    plan_sizes = list(sizes)
+    monkeypatch.setattr(_ag, "EDGE_CHUNK", 4300)          # 64 x 63 = 4032 edges: the big graph alone; the others in pairs
+    out = {}
+    for form, prec in (("1", "bf16"), ("0", "bf16"), ("0", "fp32")):
+        monkeypatch.setenv("EGNN_BWD_GRAPH", form)
+        torch.manual_seed(9)
+        m = dma.EquivariantGNN(2, **d).to(dev).train()
+        m.precision, m.norm_scope = prec, "graph"
+        h = h0.to(dev).requires_grad_(True)
+        x = x0.to(dev).requires_grad_(True)
+        if graphs == "radius":
+            plan = dma.radius_plan(x0.to(dev), plan_sizes, 1.6)
+            deg = (plan.row_ptr[1:] - plan.row_ptr[:-1]).cpu()
+            assert int(deg.min()) == 0 and int(deg.max()) >= 8 and plan.E > 300       # uneven degrees, some isolated atoms
+        else:
+            plan = dma.fully_connected_plan(plan_sizes, torch.device(dev))
+        assert plan.graph_edge_ptr == plan.row_ptr[plan.graph_ptr.long()].tolist()
+        ho, xo = m(plan, h, x)
+        ((ho * wh.to(dev)).sum() + (xo * wx.to(dev)).sum()).backward()
+        assert _ag.LAST_FIRST_LAYER_FORM == ("graph" if form == "1" else None)
+        grads = {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
+        grads["input.h"], grads["input.x"] = h.grad.detach().cpu(), x.grad.detach().cpu()
+        out[(form, prec)] = (ho.detach().cpu(), grads)
+    assert torch.equal(out[("1", "bf16")][0], out[("0", "bf16")][0])         # same forward
+    gg, gc, gf = out[("1", "bf16")][1], out[("0", "bf16")][1], out[("0", "fp32")][1]
+    worst = (0.0, None)
+    for k in gg:
+        assert torch.isfinite(gg[k]).all(), k
+        e_g, e_c, e_gc = rel_err(gg[k], gf[k]), rel_err(gc[k], gf[k]), rel_err(gg[k], gc[k])
+        worst = max(worst, (e_g, k))
+        assert e_g <= e_c + 5e-3, (k, e_g, e_c)
+        assert e_gc <= 5e-2, (k, e_gc)
+    print(f"{graphs}: graph form vs fp32 worst {worst[0]:.2e} ({worst[1]}); input x: graph {rel_err(gg['input.x'], gf['input.x']):.2e}, "
+          f"chain {rel_err(gc['input.x'], gf['input.x']):.2e}")
+
+
+@pytest.mark.gpu
+def test_node_activation_stage_matches_torch():
+    """egcl_backward_node_act: s = SiLU(z + b1), dL/dz = dL/ds * SiLU'(z + b1) as bf16 and the bias gradient, against float64
+    torch on the same inputs (row strides wider than W, N not a multiple of the 64-row block, W not a multiple of 256)"""
+    from diffusion_model_amd import _lib
+    N, W, ld = 1000, 320, 384
+    g = torch.Generator().manual_seed(2)
+    z = (torch.randn(N, ld, generator=g) * 3).cuda()
+    gs = torch.randn(N, ld, generator=g).cuda()
+    b1 = torch.randn(W, generator=g).cuda()
+    gz = torch.full((N, ld), 7.0, dtype=torch.bfloat16, device="cuda")
+    so = torch.full((N, ld), 7.0, dtype=torch.bfloat16, device="cuda")
+    gb = torch.zeros(W, device="cuda")
+    _lib.check(_lib.lib().egcl_backward_node_act(_lib.stream_ptr(), N, W, _lib.ptr(z), ld, _lib.ptr(b1), _lib.ptr(gs), ld, _lib.ptr(gz),
+                                                 _lib.ptr(so), ld, _lib.ptr(gb)))
+    a = (z[:, :W] + b1).double()
+    sg = torch.sigmoid(a)
+    want_s, want_g = a * sg, gs[:, :W].double() * (sg * (1 + a * (1 - sg)))
+    assert rel_err(so[:, :W].double().cpu(), want_s.cpu()) <= 4e-3 and rel_err(gz[:, :W].double().cpu(), want_g.cpu()) <= 4e-3   # bf16
+    assert rel_err(gb.double().cpu(), want_g.sum(0).cpu()) <= 1e-5
+    assert float(gz[:, W:].float().min()) == 7.0 and float(so[:, W:].float().min()) == 7.0      # columns past W untouched
+    assert _lib.lib().egcl_backward_node_act(_lib.stream_ptr(), N, 322, _lib.ptr(z), ld, _lib.ptr(b1), _lib.ptr(gs), ld, _lib.ptr(gz),
+                                             _lib.ptr(so), ld, _lib.ptr(gb)) != 0            # W % 4 != 0 is refused
+
+
 # ---------------- data-parallel training step on RCCL (needs >= 2 GPUs: skipped on a one-GPU box) ----------------
 def _nccl_worker(rank, world, port, out, force_active=False):
     """one rank per GPU, backend nccl (= RCCL on ROCm): each rank runs the real forward + backward on its shard of the
