@@ -372,6 +372,9 @@ class _EGNNFunction(torch.autograd.Function):
                 bf = dict(dtype=torch.bfloat16, device=hc.device)
                 bufs = [torch.empty(Epad, Wx, **bf), torch.empty(Epad, Wm, **bf), torch.empty(Epad, Wx, **bf),
                         torch.empty(Epad, M, **bf), torch.empty(max(Wx // 512, 1), E, device=hc.device)]
+                if os.environ.get("EGNN_DEBUG_POISON_KEPT", "0") == "1":   # (tests: an element the forward leaves unwritten and
+                    for t in bufs:                                            # the backward reads shows up as NaN)
+                        t.fill_(float("nan"))
                 if Epad > E:
                     for t in bufs[:4]:
                         t[E:].zero_()

@@ -292,6 +292,11 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
 #pragma unroll
     for (int w = 0; w < 8; ++w) v += L.part[w * kR + tid];
     L.val[tid] = v;
+    // training forward: this column share of s_e for the backward's dL/d(x_i - x_j) = dL/d(sum_x[i]) * s_e.  (Rounds 3 / 4 up to
+    // r04m never stored it -- the comment above promised it, the statement was missing: egcl_backward_heads_saved then read
+    // whatever the buffer held, zeros in a fresh process, i.e. the term was silently dropped; found by running the graph-form
+    // gradient test after another training test, fixed with tests/test_training.py::test_kept_buffers_are_fully_written.)
+    if constexpr (SAVE) { if (tid < nvalid && p.s_half_out) p.s_half_out[(size_t)half * p.E + e0 + tid] = v; }
   }
   __syncthreads();
   WG_STAMP(8);   // s_e per row ready

@@ -442,6 +442,88 @@ def test_saved_activation_backward_matches_recompute(monkeypatch):
         assert rel_err(out["1"][1][k].cpu(), out["0"][1][k].cpu()) <= 3e-2, k
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["graph", "chain"])
+def test_kept_buffers_are_fully_written(form, monkeypatch):
+    """Every element of the kept-activation buffers (s1, t2 of both edge MLPs, the column shares of s_e) that the backward reads
+    must have been written by egcl_forward_save: with the buffers filled with NaN before the forward (EGNN_DEBUG_POISON_KEPT=1)
+    all gradients stay finite and equal those of the plain run (up to the order of the fp32 atomics of the column sums).
+    Regression test: up to r04m the 16x16x32 coordinate kernel's training mode never stored its share of s_e -- the backward's
+    dL/d(x_i - x_j) = dL/d(sum_x[i]) * s_e read zeros in a fresh process (the term silently dropped) and stale values after
+    another training step.  Ragged graphs: E is not a multiple of the 64-row padding, several chunks."""
+    from diffusion_model_amd import autograd as _ag
+    H = 36
+    d = dims_for(H, 256, 1024, 1024, 1024)
+    sizes = [33, 64, 1, 17, 50]
+    n = sum(sizes)
+    dev = "cuda"
+    g = torch.Generator().manual_seed(12)
+    h0, x0 = torch.randn(n, H, generator=g), torch.randn(n, 3, generator=g) * 1.5
+    wh, wx = torch.randn(n, H, generator=g), torch.randn(n, 3, generator=g)
+    monkeypatch.setattr(_ag, "EDGE_CHUNK", 4300)
+    monkeypatch.setenv("EGNN_BWD_GRAPH", "1" if form == "graph" else "0")
+    out = {}
+    for poison in ("0", "1"):
+        monkeypatch.setenv("EGNN_DEBUG_POISON_KEPT", poison)
+        torch.manual_seed(9)
+        m = dma.EquivariantGNN(2, **d).to(dev).train()
+        m.precision, m.norm_scope = "bf16", "graph"
+        h = h0.to(dev).requires_grad_(True)
+        x = x0.to(dev).requires_grad_(True)
+        ho, xo = m(dma.fully_connected_plan(sizes, torch.device(dev)), h, x)
+        ((ho * wh.to(dev)).sum() + (xo * wx.to(dev)).sum()).backward()
+        assert m._ctx.last_backward_path == "kept activations"
+        out[poison] = {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
+        out[poison]["input.h"], out[poison]["input.x"] = h.grad.detach().cpu(), x.grad.detach().cpu()
+    for k in out["0"]:
+        assert torch.isfinite(out["1"][k]).all(), k
+        assert rel_err(out["1"][k], out["0"][k]) <= 1e-4, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,env", [("bf16", {}), ("bf16", {"EGNN_BWD_GRAPH": "0"}), ("bf16", {"EGNN_BWD_SAVE": "0"}),
+                                      ("bf16", {"EGNN_BWD_FIRST": "1"}), ("fp16", {}), ("fp32", {}), ("bf16x3", {})],
+                         ids=["bf16-graph", "bf16-chain", "bf16-recompute", "bf16-reduce", "fp16", "fp32", "bf16x3"])
+def test_no_backward_reads_uninitialised_memory(prec, env, monkeypatch):
+    """Every workspace the host side hands to the library comes from torch.empty: with torch's debug fill of uninitialised
+    memory (NaN in every fresh tensor: torch.utils.deterministic.fill_uninitialized_memory under use_deterministic_algorithms)
+    a forward + backward must give the gradients of the plain run -- an element read before it is written would turn them NaN.
+    All backward forms of every precision, ragged graphs, several chunks."""
+    from diffusion_model_amd import autograd as _ag
+    H = 36
+    d = dims_for(H, 256, 1024, 1024, 1024)
+    sizes = [33, 64, 1, 17, 50]
+    n = sum(sizes)
+    dev = "cuda"
+    g = torch.Generator().manual_seed(13)
+    h0, x0 = torch.randn(n, H, generator=g), torch.randn(n, 3, generator=g) * 1.5
+    wh, wx = torch.randn(n, H, generator=g), torch.randn(n, 3, generator=g)
+    monkeypatch.setattr(_ag, "EDGE_CHUNK", 4300)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    out = {}
+    old_fill = torch.utils.deterministic.fill_uninitialized_memory
+    try:
+        for fill in (False, True):
+            torch.use_deterministic_algorithms(fill, warn_only=True)
+            torch.utils.deterministic.fill_uninitialized_memory = fill
+            torch.manual_seed(9)
+            m = dma.EquivariantGNN(2, **d).to(dev).train()
+            m.precision, m.norm_scope = prec, "graph"
+            h = h0.to(dev).requires_grad_(True)
+            x = x0.to(dev).requires_grad_(True)
+            ho, xo = m(dma.fully_connected_plan(sizes, torch.device(dev)), h, x)
+            ((ho * wh.to(dev)).sum() + (xo * wx.to(dev)).sum()).backward()
+            out[fill] = {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
+            out[fill]["input.h"], out[fill]["input.x"], out[fill]["out.h"] = h.grad.detach().cpu(), x.grad.detach().cpu(), ho.detach().cpu()
+    finally:
+        torch.use_deterministic_algorithms(False)
+        torch.utils.deterministic.fill_uninitialized_memory = old_fill
+    for k in out[False]:
+        assert torch.isfinite(out[True][k]).all(), k
+        assert rel_err(out[True][k], out[False][k]) <= 1e-4, k
+
+
 def test_backward_chunks_are_cut_at_graph_boundaries():
     """host logic of the graph-form backward: chunks of WHOLE graphs with at most `rows` edges; None when one graph alone has
     more (the caller then takes the chain that may cut anywhere)"""
