@@ -6,6 +6,8 @@
 // derivative, the scalar heads (mlp_x.4, the attention gate), row reductions and the column-sum gradients of
 // biases / w3 / wa -- is fused into the three kernels below, one HBM pass each, in place on the GEMM buffers.
 // Storage type of the [edges, W] buffers follows the precision (float or bf16); all arithmetic is fp32.
+#include <stdlib.h>
+
 #include "bwd_graph.h"
 #include "kernels.h"
 
@@ -498,6 +500,8 @@ int egcl_backward_edge_recompute(egnn_ctx* c, void* stream, int layer, const flo
     if (c->bwd_s) { (void)hipFree(c->bwd_s); c->bwd_s = nullptr; c->cap_bwd_s = 0; }
     EGNN_HIP(hipMalloc(reinterpret_cast<void**>(&c->bwd_s), (size_t)nsplit * n_edges * sizeof(float)));
     c->cap_bwd_s = (size_t)nsplit * n_edges;
+    const char* poison = getenv("EGNN_DEBUG_POISON");   // (tests: see dev_alloc in egnn_forward.hip)
+    if (poison && poison[0] == '1') EGNN_HIP(hipMemset(c->bwd_s, 0xFF, c->cap_bwd_s * sizeof(float)));
   }
   int rc = backward_recompute(c, st, layer, x, g_sum_x, g_sum_m, e_first, n_edges, s1x, s1m, g_a2x, g_a2m, c->bwd_s, g_b2x,
                               g_w3, g_b3, g_b2m, g_wa, g_ba);

@@ -917,6 +917,14 @@ static int dev_alloc(T** p, size_t count) {
     *p = nullptr;
     return EGNN_ENOMEM;
   }
+  // EGNN_DEBUG_POISON=1 (tests): every scratch / pack buffer starts as 0xFF bytes -- NaN as fp32, fp16 and bf16, -1 as an index --
+  // so that an element a kernel reads before any kernel wrote it cannot pass for a plausible value (hipMalloc hands out zeros
+  // in a fresh process and whatever the previous owner left afterwards: tests/test_gpu_parity.py::test_no_scratch_read_before_write)
+  const char* poison = getenv("EGNN_DEBUG_POISON");
+  if (poison && poison[0] == '1' && hipMemset(*p, 0xFF, count * sizeof(T)) != hipSuccess) {
+    set_error("hipMemset (EGNN_DEBUG_POISON) failed");
+    return EGNN_EHIP;
+  }
   return EGNN_OK;
 }
 

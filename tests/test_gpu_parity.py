@@ -535,6 +535,53 @@ def test_sampler_graph_replay_equals_eager_and_is_seed_deterministic():
     assert not torch.equal(smp2.sample()[0], pos)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16", "fp16"])
+def test_no_scratch_read_before_write(precision, monkeypatch):
+    """The library's own device buffers (context scratch, weight packs, sampler state) come from hipMalloc, which hands out zeros
+    in a fresh process and the previous owner's bytes afterwards.  With EGNN_DEBUG_POISON=1 every such buffer starts as 0xFF
+    bytes (NaN as fp32 / fp16 / bf16, -1 as an index): the forward of every precision on every graph-size regime (2-atom toys,
+    20- and 64-atom single graphs on the small-graph kernels, a batch on the 128-row tiles, ragged graphs incl. a single atom)
+    and a device sampler run must reproduce the unpoisoned results BITWISE -- and torch's own fill of uninitialised tensors
+    (NaN in every torch.empty) covers the host side's workspaces."""
+    H, A = 36, 2
+    d = dims_for(H, 256, 1024, 1024, 1024)
+    cases = {"toys": [2, 2, 2, 2], "one20": [20], "one64": [64], "batch": [64] * 6, "ragged": [33, 64, 1, 17, 50]}
+    res = {}
+    old_fill = torch.utils.deterministic.fill_uninitialized_memory
+    try:
+        for poison in ("0", "1"):
+            monkeypatch.setenv("EGNN_DEBUG_POISON", poison)
+            torch.use_deterministic_algorithms(poison == "1", warn_only=True)
+            torch.utils.deterministic.fill_uninitialized_memory = poison == "1"
+            for name, sizes in cases.items():
+                n = sum(sizes)
+                g = torch.Generator().manual_seed(5)
+                h, x = torch.randn(n, H, generator=g), torch.randn(n, 3, generator=g) * 1.5
+                torch.manual_seed(11)
+                net = _tame(dma.EquivariantGNN(3, **d)).to(DEV).eval()       # (a new context, new packs per case)
+                net.precision, net.norm_scope = precision, "graph"
+                with torch.no_grad():
+                    ho, xo = net(dma.fully_connected_plan(sizes, torch.device(DEV)), h.to(DEV), x.to(DEV))
+                    ho2, xo2 = net(dma.fully_connected_edge_index(sizes, device=DEV), h.to(DEV), x.to(DEV),
+                                   batch=torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes)).to(DEV))
+                assert torch.equal(ho, ho2) and torch.equal(xo, xo2)
+                res[(poison, name)] = (ho.cpu(), xo.cpu())
+            T, na = 12, 16
+            torch.manual_seed(3)
+            snet = _tame(dma.EquivariantGNN(2, **dims_for(H, 128, 256, 256, 256))).to(DEV).eval()
+            snet.precision = precision
+            cond = torch.randn(3 * na, H - A - 1, generator=torch.Generator().manual_seed(1))
+            smp = dma.DeviceSampler(snet, dma.E3DiffusionProcess(0.2, 2.0, T), [na] * 3, cond, atom_type_size=A, seed=77)
+            res[(poison, "sampler")] = tuple(t.cpu() for t in smp.sample(use_graph=True))
+    finally:
+        torch.use_deterministic_algorithms(False)
+        torch.utils.deterministic.fill_uninitialized_memory = old_fill
+    for name in list(cases) + ["sampler"]:
+        for a, b in zip(res[("0", name)], res[("1", name)]):
+            assert torch.isfinite(b.float()).all(), (precision, name)
+            assert torch.equal(a, b), (precision, name)
+
+
 def test_device_noise_statistics():
     """Philox / Box-Muller draws used by the sampler: mean 0, variance 1, no cross-step correlation."""
     T, n, A, H = 4, 4096, 2, 3

@@ -505,6 +505,7 @@ def test_no_backward_reads_uninitialised_memory(prec, env, monkeypatch):
     old_fill = torch.utils.deterministic.fill_uninitialized_memory
     try:
         for fill in (False, True):
+            monkeypatch.setenv("EGNN_DEBUG_POISON", "1" if fill else "0")   # the library's own hipMalloc'ed buffers as 0xFF bytes
             torch.use_deterministic_algorithms(fill, warn_only=True)
             torch.utils.deterministic.fill_uninitialized_memory = fill
             torch.manual_seed(9)
