@@ -160,16 +160,24 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_
     w3, b3 = lin_x4.weight.detach().reshape(-1).contiguous(), lin_x4.bias.detach().contiguous()
     wa, ba = att.weight.detach().reshape(-1).contiguous(), att.bias.detach().contiguous()
     # fp32 accumulators; the first Linear layers carry their bias gradient in column 2H+1 (ones column of `in`)
-    g_w1x, g_w1m = torch.zeros(Wx, K1P, **f32), torch.zeros(Wm, K1P, **f32)
-    g_w2x, g_w2m = torch.zeros(Wx, Wx, **f32), torch.zeros(M, Wm, **f32)
-    g_b2x, g_w3, g_b3 = torch.zeros(Wx, **f32), torch.zeros(Wx, **f32), torch.zeros(1, **f32)
-    g_b2m, g_wa, g_ba = torch.zeros(M, **f32), torch.zeros(M, **f32), torch.zeros(1, **f32)
+    # (one zero fill for all of them: a dozen 5-us launches per layer otherwise; every piece starts at a multiple of 4 floats)
+    shapes = [(Wx, K1P), (Wm, K1P), (Wx, Wx), (M, Wm), (Wx,), (Wx,), (4,), (M,), (M,), (4,)]
+    if plan is not None:
+        shapes += [(plan.B, Wx), (plan.B, Wm)]
+    sizes_ = [_round_up(math.prod(sh), 4) for sh in shapes]
+    flat = torch.zeros(sum(sizes_), **f32)
+    pieces, o = [], 0
+    for sh, sz in zip(shapes, sizes_):
+        pieces.append(flat[o:o + math.prod(sh)].view(*sh))
+        o += sz
+    g_w1x, g_w1m, g_w2x, g_w2m, g_b2x, g_w3, g_b3, g_b2m, g_wa, g_ba = pieces[:10]
+    g_b3, g_ba = g_b3[:1], g_ba[:1]
     g_am, g_ax = g_am.contiguous(), g_ax.contiguous()
     global LAST_FIRST_LAYER_FORM
     LAST_FIRST_LAYER_FORM = first
     if first:
         N, nparts = h.shape[0], (Wx + Wm) // 256
-        cd_x, cd_m = torch.zeros(plan.B, Wx, **f32), torch.zeros(plan.B, Wm, **f32)
+        cd_x, cd_m = pieces[10], pieces[11]
         gd2_part = torch.empty(nparts * min(rows, E), **f32)
     if first == "graph":     # the kernel leaves the sums as the bf16 operands of the node-level products: [Gd_x | Gs_x | Gd_m | Gs_m]
         G = torch.zeros(N, 2 * Wx + 2 * Wm, dtype=torch.bfloat16, device=h.device)
@@ -286,7 +294,8 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_
             g_h.addmm_(Gs, w1[:, H:2 * H])
 
     def acc(p, g):
-        grads[p] = grads.get(p, 0) + g.reshape(p.shape)
+        g = g.reshape(p.shape).contiguous()
+        grads[p] = g if p not in grads else grads[p] + g        # (no `0 + g` launch for the first contribution)
 
     acc(lin_x0.weight, g_w1x[:, :2 * H + 1]); acc(lin_x0.bias, g_w1x[:, 2 * H + 1])
     acc(lin_m0.weight, g_w1m[:, :2 * H + 1]); acc(lin_m0.bias, g_w1m[:, 2 * H + 1])
@@ -322,7 +331,7 @@ def _node_backward_hip(layer, h_l, sum_m, gh, grads):
     g_b1 = torch.zeros(Wh, dtype=torch.float32, device=h_l.device)
     _lib.check(_lib.lib().egcl_backward_node_act(_lib.stream_ptr(), N, Wh, _lib.ptr(z1), z1.stride(0), _lib.ptr(lin1.bias.detach()),
                                                  _lib.ptr(g_s), g_s.stride(0), _lib.ptr(g_z1b), _lib.ptr(s_b), Wh, _lib.ptr(g_b1)))
-    acc = lambda p_, g_: grads.__setitem__(p_, grads.get(p_, 0) + g_)
+    acc = lambda p_, g_: grads.__setitem__(p_, g_ if p_ not in grads else grads[p_] + g_)
     acc(lin2.bias, gh.sum(0))
     acc(lin1.bias, g_b1)
     acc(lin2.weight, gemm_tn(s_b, ghb, rows=Wh, cols=H).t())                     # [Wh, H]^T
@@ -462,7 +471,7 @@ class _EGNNFunction(torch.autograd.Function):
                 g_am, g_ax, g_S = zero(outs[2], sum_m), zero(outs[3], sum_x), zero(outs[4], S)
                 for p, g in zip(node_params, outs[5:]):
                     if g is not None:
-                        grads[p] = grads.get(p, 0) + g
+                        grads[p] = g if p not in grads else grads[p] + g
             # edge part
             if E > 0:
                 _edge_backward(layer, prec, ws, h_l, x_l, dst32, src32, node_seg, g_am, g_ax, g_S.contiguous(), g_h, g_x, grads,
