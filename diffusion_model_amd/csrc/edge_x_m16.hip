@@ -233,21 +233,41 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[rb][cb][i] = fmaf(acc[rb][cb][i], kNegLog2e, bb);
     }
-    // per-wave staging tile [16 rows][72 bf16] (64 columns + pad); 16-byte row-major stores, 128 contiguous bytes per row
-    __bf16* stg = reinterpret_cast<__bf16*>(s_a1) + (size_t)wave * 16 * 72;
+    // Row-major bf16 through a per-wave LDS tile kept TRANSPOSED, T[64 columns][16 rows] (32 bytes per column): a lane's four
+    // values of a column block are rows 4 q4 .. 4 q4 + 3 of ONE column = one 8-byte write (16-byte tile rows before: sixteen
+    // 2-byte writes per row block), and ds_read_b64_tr_b16 hands lane j of a 16-lane group row j of four neighbouring columns
+    // (the group addresses 4 tile rows x 16 elements; gemm_tn.hip reads its operands the same way).  Two such reads = 8 columns =
+    // one 16-byte store; a store instruction covers 64 contiguous bytes of each of 16 rows.
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2s;
+    char* tile = s_a1 + (size_t)wave * (64 * 32);
+    const unsigned tile_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)tile;
+    const int g16 = lane >> 4, j16 = lane & 15;
+    const unsigned rd_addr = tile_lds + (unsigned)((8 * g16 + (j16 >> 2)) * 32 + (j16 & 3) * 8);   // column 8 g16 + (j >> 2), rows 4 (j & 3) ..
     __bf16* tout = static_cast<__bf16*>(p.g_a2_out) + (size_t)e0 * p.WxP + 16 * cb0;
 #pragma unroll
     for (int rb = 0; rb < 8; ++rb) {
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) stg[(4 * q4 + i) * 72 + 16 * cb + r15] = (__bf16)acc[rb][cb][i];
+      for (int cb = 0; cb < 4; ++cb) {
+        u32x2s w;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w.x) : "v"(acc[rb][cb][0]), "v"(acc[rb][cb][1]));
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w.y) : "v"(acc[rb][cb][2]), "v"(acc[rb][cb][3]));
+        *reinterpret_cast<u32x2s*>(tile + (16 * cb + r15) * 32 + q4 * 8) = w;
+      }
       __builtin_amdgcn_wave_barrier();
+      u32x2s t[2][2];   // [half of the 64 columns][4-column piece]
+      asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                   "ds_read_b64_tr_b16 %0, %4 offset:0\n\t"
+                   "ds_read_b64_tr_b16 %1, %4 offset:128\n\t"
+                   "ds_read_b64_tr_b16 %2, %4 offset:1024\n\t"
+                   "ds_read_b64_tr_b16 %3, %4 offset:1152\n\t"
+                   "s_waitcnt lgkmcnt(0)"
+                   : "=&v"(t[0][0]), "=&v"(t[0][1]), "=&v"(t[1][0]), "=&v"(t[1][1]) : "v"(rd_addr) : "memory");
+      if (16 * rb + j16 < nvalid - (diag::kNoT2 ? 1000 : 0)) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int piece = lane + 64 * t, row = piece >> 3, seg = piece & 7;   // 16 rows x 8 pieces of 16 bytes
-        if (16 * rb + row < nvalid - (diag::kNoT2 ? 1000 : 0))
-          *reinterpret_cast<bf16x8*>(tout + (size_t)(16 * rb + row) * p.WxP + 8 * seg) = *reinterpret_cast<const bf16x8*>(stg + row * 72 + 8 * seg);
+        for (int k = 0; k < 2; ++k) {
+          const u32x4 o = {t[k][0].x, t[k][0].y, t[k][1].x, t[k][1].y};   // row 16 rb + j16, columns 32 k + 8 g16 .. + 7
+          *reinterpret_cast<u32x4*>(tout + (size_t)(16 * rb + j16) * p.WxP + 32 * k + 8 * g16) = o;
+        }
       }
       __builtin_amdgcn_wave_barrier();
     }
