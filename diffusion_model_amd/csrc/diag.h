@@ -14,7 +14,7 @@
 #pragma once
 
 #if !defined(EGNN_DIAG) && (defined(EGNN_EXP_STAMP) || defined(EGNN_EXP_STAMP2) || defined(EGNN_EXP_WGSTAMP) || defined(EGNN_EXP_DGSTAMP) || \
-    defined(EGNN_EXP_NO_S1) || defined(EGNN_EXP_NO_T2) || defined(EGNN_EXP_DG_NOK) || defined(EGNN_EXP_DG_NOG) || defined(EGNN_EXP_DG_NOW) || \
+    defined(EGNN_EXP_NO_S1) || defined(EGNN_EXP_NO_T2) || defined(EGNN_EXP_NO_STAGE) || defined(EGNN_EXP_DG_NOK) || defined(EGNN_EXP_DG_NOG) || defined(EGNN_EXP_DG_NOW) || \
     defined(EGNN_EXP_DG_L2G) || defined(EGNN_EXP_DG_NOTAB) || defined(EGNN_EXP_DG_NOEPI) || defined(EGNN_EXP_NP_NONORM) ||                    \
     defined(EGNN_EXP_NP_NOMLP) || defined(EGNN_EXP_DGG_NOSILU) || defined(EGNN_EXP_DGG_NOHOT) || defined(EGNN_EXP_DGG_NOROW))
 #error "EGNN_EXP_* switches are diagnostic builds: add -DEGNN_DIAG (tools/exp_build.sh)"
@@ -32,6 +32,11 @@ EGNN_DIAG_FLAG(kNoS1, false);
 EGNN_DIAG_FLAG(kNoT2, true);
 #else
 EGNN_DIAG_FLAG(kNoT2, false);
+#endif
+#ifdef EGNN_EXP_NO_STAGE   // training forward: skip the whole pre-activation staging block (scale pass, LDS transpose, stores)
+EGNN_DIAG_FLAG(kNoStage, true);
+#else
+EGNN_DIAG_FLAG(kNoStage, false);
 #endif
 #ifdef EGNN_EXP_DG_NOK
 EGNN_DIAG_FLAG(kDgNoK, true);

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
   float part[32];
 #pragma unroll
   for (int v = 0; v < 32; ++v) part[v] = 0.f;
-  if constexpr (SAVE) {   // the scaled pre-activations go to HBM first (the K-loop buffers are free behind the last barrier);
+  if constexpr (SAVE && !diag::kNoStage) {   // the scaled pre-activations go to HBM first (the K-loop buffers are free behind the last barrier);
                           // the accumulators then hold them for the SiLU below
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
