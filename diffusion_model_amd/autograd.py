@@ -176,8 +176,7 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_
     global LAST_FIRST_LAYER_FORM
     LAST_FIRST_LAYER_FORM = first
     if first:
-        # (shares of dL/d(d2_e): one per 256 hidden units; the second graph form, EGNN_DGRAD_GRAPH2=1, one per 128)
-        N, nparts = h.shape[0], (Wx + Wm) // (128 if first == "graph" and os.environ.get("EGNN_DGRAD_GRAPH2", "0") == "1" else 256)
+        N, nparts = h.shape[0], (Wx + Wm) // 256
         cd_x, cd_m = pieces[10], pieces[11]
         gd2_part = torch.empty(nparts * min(rows, E), **f32)
     if first == "graph":     # the kernel leaves the sums as the bf16 operands of the node-level products: [Gd_x | Gs_x | Gd_m | Gs_m]

@@ -1025,7 +1025,6 @@ int init_kernel_attributes() {
   if ((rc = init_node_bf16_attributes())) return rc;
   if ((rc = init_edge_dgrad_attributes())) return rc;
   if ((rc = init_edge_dgrad_graph_attributes())) return rc;
-  if ((rc = init_edge_dgrad_graph2_attributes())) return rc;
   if ((rc = init_edge_x_m16_attributes())) return rc;
   if ((rc = init_edge_bf16x3_attributes())) return rc;
   done = true;
@@ -1182,10 +1181,6 @@ int backward_dgrad(egnn_ctx* c, hipStream_t st, int layer, const float* x, int e
 
 // the same dgrad WITHOUT dL/da1 in memory: per-graph workgroups that also reduce it for the first Linear layers
 // (edge_bwd_dgrad_graph.hip); G = bf16 [N][2 WxP + 2 WmP] = [Gd_x | Gs_x | Gd_m | Gs_m], gd2_part = [(WxP + WmP) / 256][n_edges]
-int dgrad_graph_share_columns() {
-  const char* e = getenv("EGNN_DGRAD_GRAPH2");
-  return (e && e[0] == '1') ? 128 : 256;
-}
 int backward_dgrad_graph(egnn_ctx* c, hipStream_t st, int layer, const float* x, int e_first, int n_edges, const void* g_a2x,
                          const void* g_a2m, void* G, float* cd_x, float* cd_m, float* gd2_part) {
   const LayerPack& lp = c->layers[layer];
@@ -1193,14 +1188,14 @@ int backward_dgrad_graph(egnn_ctx* c, hipStream_t st, int layer, const float* x,
   const float* wdm_s = wdx_s + c->WxP;
   const int ldg = 2 * c->WxP + 2 * c->WmP;
   __bf16* g = static_cast<__bf16*>(G);
-  const int share = dgrad_graph_share_columns();
-  auto launch = share == 128 ? launch_edge_dgrad_graph2 : launch_edge_dgrad_graph;
-  int rc = launch(c->N, c->B, c->graph_ptr, c->row_ptr, c->edge_dst, c->edge_src, e_first, n_edges, x, c->table, c->TC, 0, c->WxP, wdx_s,
-                  g_a2x, c->WxP, lp.w2xT_bf16, c->WxP, g, g + c->WxP, ldg, cd_x, gd2_part, st);
+  int rc = launch_edge_dgrad_graph(c->N, c->B, c->graph_ptr, c->row_ptr, c->edge_dst, c->edge_src, e_first, n_edges, x, c->table,
+                                   c->TC, 0, c->WxP, wdx_s, g_a2x, c->WxP, lp.w2xT_bf16, c->WxP, g, g + c->WxP, ldg, cd_x,
+                                   gd2_part, st);
   if (rc) return rc;
-  return launch(c->N, c->B, c->graph_ptr, c->row_ptr, c->edge_dst, c->edge_src, e_first, n_edges, x, c->table, c->TC, 2 * c->WxP,
-                2 * c->WxP + c->WmP, wdm_s, g_a2m, c->MP, lp.w2mT_bf16, c->WmP, g + 2 * c->WxP, g + 2 * c->WxP + c->WmP, ldg, cd_m,
-                gd2_part + (size_t)(c->WxP / share) * n_edges, st);
+  return launch_edge_dgrad_graph(c->N, c->B, c->graph_ptr, c->row_ptr, c->edge_dst, c->edge_src, e_first, n_edges, x, c->table,
+                                 c->TC, 2 * c->WxP, 2 * c->WxP + c->WmP, wdm_s, g_a2m, c->MP, lp.w2mT_bf16, c->WmP,
+                                 g + 2 * c->WxP, g + 2 * c->WxP + c->WmP, ldg, cd_m,
+                                 gd2_part + (size_t)(c->WxP / 256) * n_edges, st);
 }
 
 // Stage 1 of a layer: node_pre, squared-distance sums and the fused edge pass.  gsum (c->gscale) then holds the
