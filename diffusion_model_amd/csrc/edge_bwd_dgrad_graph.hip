@@ -129,8 +129,8 @@ __global__ __launch_bounds__(kTG, 2) void edge_dgrad_graph_kernel(const DgradGra
   const unsigned colb = 2u * (unsigned)col;
   const int NC = diag::kDgNoK ? 2 : p.Kd / kKCG, KS = p.Kd / 16;   // (diag: two chunks only = prologue + epilogue time)
   const int brow = tid >> 3, kg = tid & 7;
-  const rsrc_t rs_g = make_rsrc(p.g_a2, (unsigned)((size_t)p.n_edges * p.Kd * 2));   // rows past the chunk read as zero
-  const rsrc_t rs_w = make_rsrc(p.w2t, (unsigned)((size_t)p.KP * p.Kd * 2));
+  const rsrc_t rs_g = make_rsrc(p.g_a2, diag::kDgNoG ? 0u : (unsigned)((size_t)p.n_edges * p.Kd * 2));   // rows past the chunk read as zero
+  const rsrc_t rs_w = make_rsrc(p.w2t, diag::kDgNoW ? 0u : (unsigned)((size_t)p.KP * p.Kd * 2));   // (diag: zero-size descriptors = loads that never leave the CU)
   const unsigned vstep = (unsigned)(8 * NW) * (unsigned)p.Kd * 2u;
   char* const slot0 = s_a1 + (kg * kRPADG + brow) * 16;
   constexpr unsigned kSlotStep = 8 * NW * 16;
