@@ -46,7 +46,7 @@ def node_macs(H, M, Wh):
     return (H + M) * Wh + Wh * H
 
 
-PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "bf16x3": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md (bf16x3 = three bf16
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "bf16x3": 2500.0, "f16c8": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md (bf16x3 = three bf16
 # MFMAs per algorithmic product: its `achieved` counts the ALGORITHMIC flops once, so at best 1/3 of the bf16 peak)
 
 
@@ -406,6 +406,9 @@ def sample_leg(args, rk, precision=None, batch=None, atoms=None, steps=None, war
                                         "(v_mfma_f32_16x16x32_f16) + message kernel edge_kernel_bf16_v4<1,true,..,f16x8>",
                                 "bf16x3": "fused edge pass of one EGCL layer: edge_x3_kernel<false> + edge_x3_kernel<true> "
                                           "(head/remainder operands, 3 bf16 MFMAs per product)",
+                                "f16c8": "fused edge pass of one EGCL layer: edge_c8_kernel<false> + edge_c8_kernel<true> (fp16 heads on "
+                                         "v_mfma_f32_16x16x32_f16 + both remainder products on one v_mfma_scale_f32_16x16x128_f8f6f4 "
+                                         "with e4m3 operands and fixed block scales)",
                                 "fp32": "fused edge pass of one EGCL layer: edge_kernel<F32> (v_mfma_f32_32x32x2_f32)"}[precision],
                      "avg_launch_ms": edge_ms.value, "launches": edge_n.value,
                      "algorithmic_flop_per_launch": flops_per_launch,
@@ -597,7 +600,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="graphs per GPU")
     ap.add_argument("--atoms", type=int, default=64)
     ap.add_argument("--layers", type=int, default=4)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "bf16x3", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "bf16x3", "f16c8", "fp32"])
     ap.add_argument("--mode", default="sample", choices=["sample", "train", "slab"],
                     help="sample = headline metric (default, with the ddp_train sub-record); train = BASELINE configs[3] "
                          "shape only (fwd+bwd+all-reduce+Adam) as the headline of the line; slab = BASELINE configs[4] only")

@@ -6,10 +6,10 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EGNN_LIB", os.path.join(_HERE, "libegnn_amd.so"))   # EGNN_LIB: timing-experiment builds
 
-PREC_F32, PREC_BF16, PREC_BF16X3, PREC_F16 = 0, 1, 2, 3
+PREC_F32, PREC_BF16, PREC_BF16X3, PREC_F16, PREC_F16C8 = 0, 1, 2, 3, 4
 NORM_CALL, NORM_GRAPH = 0, 1
 PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "float32": PREC_F32, "bf16": PREC_BF16, "bfloat16": PREC_BF16,
-              "bf16x3": PREC_BF16X3, "fp16": PREC_F16, "f16": PREC_F16, "float16": PREC_F16}
+              "bf16x3": PREC_BF16X3, "f16c8": PREC_F16C8, "fp16": PREC_F16, "f16": PREC_F16, "float16": PREC_F16}
 NORM_SCOPES = {"call": NORM_CALL, "graph": NORM_GRAPH}
 
 

@@ -407,7 +407,7 @@ class _EGNNFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gh, gx):
         layers, plan, prec = ctx.layers, ctx.plan, ctx.prec
-        if prec == _lib.PREC_BF16X3:   # forward on the split-operand kernels; the backward chain is the fp32 one
+        if prec in (_lib.PREC_BF16X3, _lib.PREC_F16C8):   # forward on the split-operand kernels; the backward chain is the fp32 one
             prec = _lib.PREC_F32
         if prec == _lib.PREC_F16:      # forward on fp16 operands; the backward recomputes on the bf16 kernels
             prec = _lib.PREC_BF16

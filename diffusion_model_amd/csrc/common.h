@@ -67,6 +67,10 @@ struct LayerPack {
   // split-operand node MLP (node_post_bf16_kernel<., f16x8, true>): mlp_h.0 head / remainder with K padded to its ring's two
   // turns, mlp_h.2 remainder (its head is w2h_f16p); null when the shape is outside that kernel
   void *w1h_f16k = nullptr, *w1h_f16k_lo = nullptr, *w2h_f16p_lo = nullptr;
+  // precision f16c8 (edge_f16c8.hip): e4m3 fragments [N/16][K/64][2][64][16 B] of the heads and remainders of the fp16 streams
+  // above (hi | lo K blocks interleaved), and the e8m0 bytes of their block scales {x: hi, lo, m: hi, lo}
+  void *w2x_c8 = nullptr, *w2m_c8 = nullptr;
+  int* c8_exp = nullptr;
 };
 
 constexpr int kGraphSteps = 8;   // reverse steps captured per hipGraph

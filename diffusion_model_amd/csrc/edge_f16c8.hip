@@ -1,0 +1,500 @@
+// Per-edge kernels of precision 'f16c8' (gfx950): fp32-grade accuracy for TWO bf16-equivalents of matrix work per product.
+//
+// north_star asks for eps within 1e-4 of the reference's fp32 path (EquivariantGraphNeuralNetwork.py:55-65 is fp32
+// throughout).  Precision 'bf16x3' meets it with three full-rate products per operand pair (edge_bf16x3.hip).  Here both
+// operands of the two per-edge second-layer products (:15-16 mlp_m.2, :21-22 mlp_x.2) are split into an fp16 head (11
+// significant bits) and a remainder,          a = a_hi + a_lo,      W = W_hi + W_lo,
+//     a . W  ~=  a_hi . W_hi                          v_mfma_f32_16x16x32_f16      (full rate, exact products, fp32 accumulate)
+//              + a_lo . W_hi  +  a_hi . W_lo          v_mfma_scale_f32_16x16x128_f8f6f4 on e4m3 operands (TWICE the f16 rate)
+// and the two remainder products run on OCP e4m3 (4 significant bits): a remainder is 2^-12 of its operand, so the e4m3
+// rounding of the correction's operands is 2^-16 of the product -- what bf16x3's dropped term and remainder rounding
+// cost (2^-17).  Both corrections share ONE block-scaled instruction per 16 x 16 tile and 64 hidden units: its K = 128 is
+// four blocks of 32 with a scale each, laid out as [a_lo8 | a_hi8 | a_lo8 | a_hi8] against [W_hi8 | W_lo8 | W_hi8 | W_lo8]
+// (hidden units 0-31, 0-31, 32-63, 32-63 of the chunk), and the e8m0 block scales carry the FIXED powers of two the
+// operands were multiplied by before rounding (2^12 for a_lo, 2 for a_hi8; per-matrix exponents for the weights, c8_exp),
+// so the instruction adds straight into the main product's accumulators.  No dynamic (per-block) scale is needed: e4m3
+// spans 2^-9 ... 448, and whatever underflows is 2^-21 of the largest activation the scale admits.
+// Measured (tools/micro/mfma_scale_probe.hip, profiles/r05a_mfma_scale_probe.txt): the mix {2 f16 + 1 scaled e4m3} takes
+// 64 SIMD-cycles per tile and chunk against 96.5 for bf16x3's six bf16 MFMAs, at a higher held clock (1.96 vs 1.85 GHz).
+// CPU emulation of every rounding (tools/rounding_budget.py, profiles/r05_rounding_budget.txt): 6e-6 / 1e-5 on h' / eps_x
+// of the full-width goldens (bar 1e-4).
+//
+// Everything else is the fp32 path's arithmetic: fp32 first-layer table (exact f32 MFMA in node_pre), fp32 geometry, SiLU /
+// sigmoid, heads and segment sums; split-operand node MLP (node_bf16.hip).  Tile and K loop are those of edge_x_m16.hip
+// (128 edges, 8 waves, 16x16 MFMA tiles, 64-deep chunks, phase-opposed SIMD partners, XOR-swizzled fp16 image) with
+//   IS_M = false  coordinate branch (:62-65): 512 columns of mlp_x.2 per workgroup (WxP / 512 column shares), 4 column blocks per wave
+//   IS_M = true   message branch (:57-61): all 256 columns of mlp_m.2 + the attention gate, 2 column blocks per wave
+// What differs from that kernel's schedule, because the operands of a second matrix instruction have to fit beside its 128
+// accumulators: request distances are cut to what the now twice as long matrix phase hides -- the e4m3 weight fragments
+// of a chunk are requested after its first f16 k-step (used 500 cycles later), the fp32 table rows of the next build after
+// its second k-step (their 32 registers take the place of the f16 weight fragments, used 1,000 cycles later), the next
+// chunk's f16 fragments at the end of the matrix phase.
+#include "diag.h"
+#include "edge_tile.h"
+#include <type_traits>
+
+namespace egnn {
+
+namespace {
+
+using namespace tile128;
+constexpr int kT = 512;
+constexpr int kKC = 64;                        // activation chunk depth
+constexpr int kCBX = 2;                        // coordinate kernel: 16-column blocks per wave (2: 256 columns per workgroup; see edge_c8_kernel)
+constexpr size_t kA1 = (size_t)8 * kR * 16;    // fp16 image of a chunk: [8 k-groups][128 rows][8 f16], rows XOR-swizzled (edge_x_m16.hip)
+constexpr size_t kBS = (size_t)kR * 32 + 32;   // e4m3 image: one K block = [128 rows][32 B]; + 32 B: the two blocks a store instruction
+                                               // touches (0 / 2 or 1 / 3) land on the two halves of the 128-B store bank row
+constexpr size_t kC8 = 4 * kBS;                // [a_lo8 0-31 | a_hi8 0-31 | a_lo8 32-63 | a_hi8 32-63]
+__host__ __device__ inline size_t c8_smem_bytes(int KP, bool is_m) {
+  (void)is_m;
+  return kOffLoop + 2 * kA1 + 2 * kC8 + (size_t)KP * 4;
+}
+
+typedef __attribute__((ext_vector_type(4))) float f32x4v;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(2))) short i16x2;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+// SiLU + the three operand forms of one build unit (8 hidden units of one row): table, wd pre-scaled by -log2(e).
+//   slot16: 16 B of the fp16 image; slot_lo / slot_hi: 8 B each of the e4m3 image (remainder x 2^12, value x 2)
+__device__ __forceinline__ void unit_finish_c8(const Unit& u, const float* wd, float d2, char* slot16, char* slot_lo, char* slot_hi) {
+  const f32x4 w0 = *reinterpret_cast<const f32x4*>(wd), w1 = *reinterpret_cast<const f32x4*>(wd + 4);
+  float a[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    a[j] = silu_s(fmaf(w0[j], d2, u.p0[j] + u.q0[j]));
+    a[j + 4] = silu_s(fmaf(w1[j], d2, u.p1[j] + u.q1[j]));
+  }
+  const f16x8 h = pack8<f16x8>(a);   // RNE; MODE.FP16_OVFL: saturates instead of inf
+  float lo[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) lo[j] = a[j] - (float)h[j];
+  // v_cvt_scalef32_pk_fp8_f32: e4m3(src / scale), RNE, saturating at +-448 under MODE.FP16_OVFL (tools/micro/mfma_scale_probe.hip)
+  i16x2 l0 = {0, 0}, l1 = {0, 0}, h0 = {0, 0}, h1 = {0, 0};
+  l0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(l0, lo[0], lo[1], 0x1p-12f, false);
+  l0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(l0, lo[2], lo[3], 0x1p-12f, true);
+  l1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(l1, lo[4], lo[5], 0x1p-12f, false);
+  l1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(l1, lo[6], lo[7], 0x1p-12f, true);
+  h0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(h0, a[0], a[1], 0.5f, false);
+  h0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(h0, a[2], a[3], 0.5f, true);
+  h1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(h1, a[4], a[5], 0.5f, false);
+  h1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(h1, a[6], a[7], 0.5f, true);
+  *reinterpret_cast<f16x8*>(slot16) = h;
+  *reinterpret_cast<u32x2*>(slot_lo) = u32x2{__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1)};
+  *reinterpret_cast<u32x2*>(slot_hi) = u32x2{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
+}
+
+// CB = 16-column blocks per wave: the workgroup's 8 waves cover 128 CB columns (message branch: CB = 2 = all 256 columns)
+template <bool IS_M, int CB>
+__global__ __launch_bounds__(kT, 2) void edge_c8_kernel(const EdgeParams p) {
+  static_assert(!IS_M || CB == 2, "the message branch is 256 columns wide");
+  f16_saturate_mode();
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const Lds L(smem);
+  char* s_a1 = smem + kOffLoop;             // [2 buffers] fp16 image
+  char* s_c8 = s_a1 + 2 * kA1;              // [2 buffers] e4m3 image
+  float* s_wd = reinterpret_cast<float*>(s_c8 + 2 * kC8);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r15 = lane & 15, q4 = lane >> 4;
+  const int KP = IS_M ? p.WmP : p.WxP;
+  const int nsplit = IS_M ? 1 : p.WxP / (128 * CB);
+  const int j = xcd_tile(blockIdx.x, gridDim.x);
+  const int tile = j / nsplit, half = j - tile * nsplit;
+  const int e0 = tile * kR;
+  const int nvalid = min(kR, p.E - e0);
+
+  prologue_rows(p, L, e0, nvalid, IS_M ? p.wdm : p.wdx, KP, s_wd, tid);
+
+  // ---- K loop ----
+  const int NC = KP / kKC, KS = KP / 32;
+  const int brow = tid >> 3, kg = tid & 7;   // this thread builds rows brow and brow + 64, hidden units 8 kg .. 8 kg + 7 of a chunk
+  const rsrc_t rs_tab = make_rsrc(p.table, (unsigned)min((size_t)p.N * p.TC * 4, (size_t)0xFFFFFFFFu));
+  const size_t ncols = IS_M ? (size_t)p.MP : (size_t)p.WxP;
+  const rsrc_t rs_w = make_rsrc(IS_M ? p.w2m16 : p.w2x16, (unsigned)(ncols * KP * 2));   // fp16 fragments [N/16][K/32][64][8]
+  const rsrc_t rs_w8 = make_rsrc(IS_M ? p.w2m_c8 : p.w2x_c8, (unsigned)(ncols * KP * 2));  // e4m3 fragments [N/16][K/64][2][64][16 B]
+  const unsigned vdst0 = (unsigned)L.dst[brow] * (unsigned)p.TC * 4u + (unsigned)kg * 32u;
+  const unsigned vsrc0 = (unsigned)L.src[brow] * (unsigned)p.TC * 4u + (unsigned)kg * 32u;
+  const unsigned vdst1 = (unsigned)L.dst[brow + 64] * (unsigned)p.TC * 4u + (unsigned)kg * 32u;
+  const unsigned vsrc1 = (unsigned)L.src[brow + 64] * (unsigned)p.TC * 4u + (unsigned)kg * 32u;
+  const unsigned offP = (IS_M ? 2u * p.WxP : 0u) * 4u, offQ = (IS_M ? 2u * p.WxP + p.WmP : (unsigned)p.WxP) * 4u;   // fp32 table {Px|Qx|Pm|Qm}
+  // fp16 image slots of this thread (rows brow, brow + 64), as edge_x_m16.hip
+  char* slot0 = s_a1 + (size_t)kg * (kR * 16) + (size_t)(brow ^ kg) * 16;
+  // e4m3 image: hidden units 8 kg .. + 7 sit in K block 2 (kg >> 2) (remainder) / + 1 (value), 16-byte piece (kg >> 1) & 1 of the
+  // row's 32 bytes, XORed by the block's parity (an operand read of 16 lanes covers rows of an even and of an odd block: they
+  // then hit the even / the odd 16-byte slots of the 256-B load bank row), 8-byte half kg & 1
+  const unsigned pc = (unsigned)(kg >> 1) & 1u, sub8 = (unsigned)(kg & 1) * 8u;
+  char* slo0 = s_c8 + (size_t)(2 * (kg >> 2)) * kBS + (size_t)brow * 32 + pc * 16u + sub8;
+  const int shi_delta = (int)kBS + 16 - 32 * (int)pc;   // the value slot: next block, other 16-byte piece
+  const unsigned lane16 = lane * 16u;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)s_a1;
+  const unsigned abase0 = lds0 + (unsigned)q4 * (kR * 16) + (unsigned)(r15 ^ q4) * 16u;
+  const unsigned abase1 = lds0 + (unsigned)(4 + q4) * (kR * 16) + (unsigned)(r15 ^ (4 + q4)) * 16u;
+  const unsigned lds8 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)s_c8;
+  const unsigned cbase = lds8 + (unsigned)q4 * (unsigned)kBS + (unsigned)r15 * 32u;   // this lane's 32 operand bytes of row block 0
+  const int cb0 = IS_M ? wave * CB : half * (8 * CB) + wave * CB;   // first 16-column block of this wave
+  const unsigned w0 = (unsigned)cb0 * KS * 1024u;              // fp16 stream: 1 KiB per (column block, k-step)
+  const unsigned w80 = (unsigned)cb0 * NC * 2048u;             // e4m3 stream: 2 KiB per (column block, chunk)
+  // block scales (e8m0, byte 0 of the scale operands): the hardware applies scale_a(row, block) * scale_b(column, block), and the
+  // two kinds of block need the same product -- even blocks a_lo8 x W_hi8: 2^-12 x 2^-s_hi, odd blocks a_hi8 x W_lo8: 2^-1 x
+  // 2^-(s_hi + 11) -- so both operands take ONE wave-uniform scale: a literal and a scalar register, no vector registers
+  constexpr int kScaleA = 127 - 12;
+  const int scale_b = __builtin_amdgcn_readfirstlane((IS_M ? p.c8_exp + 2 : p.c8_exp)[0]);   // 127 - s_hi (c8_exponents_kernel)
+
+  f32x4v acc[8][CB];
+#pragma unroll
+  for (int rb = 0; rb < 8; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) acc[rb][cb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+  Unit ua0, ua1;
+  auto vload = [&](const int cq) {   // fp32 table rows for the activations of chunk cq (clamped: a harmless repeat at the end)
+    const int c = cq < NC ? cq : NC - 1;
+    const unsigned kb = (unsigned)c * kKC * 4u;
+    unit_load(ua0, rs_tab, vdst0, vsrc0, offP + kb, offQ + kb);
+    unit_load(ua1, rs_tab, vdst1, vsrc1, offP + kb, offQ + kb);
+  };
+  f16x8 bq[2][CB];   // fp16 weight fragments of the 2 k-steps of the chunk the next matrix phase multiplies
+  i32x8 b8[CB];      // e4m3 weight fragments of the running chunk
+  auto wload16 = [&](const int cq, const int s) {   // k-step s of chunk cq (clamped)
+    const int c = cq < NC ? cq : NC - 1;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) bq[s][cb] = ldbuf_v8<f16x8>(rs_w, lane16, w0 + ((unsigned)cb * KS + (unsigned)(2 * c + s)) * 1024u);
+  };
+  // SiLU + operand forms of chunk c into LDS buffer PAR = c & 1 (a compile-time parity: the loop below is unrolled by two so
+  // that every LDS address of the K loop is a per-thread base + an immediate).  The two rows are finished ONE AFTER THE OTHER
+  // and the fp16 weight fragments of the next matrix phase are requested as their registers come free (w_mid after the first
+  // row, w_end after the second): with both rows' temporaries and 32 fragment registers live beside the 32 table registers the
+  // build did not fit beside the 128 accumulators.
+  auto vfinish = [&](auto par_c, const int c, const int w_mid_chunk, const int w_mid_s, const int w_end_chunk) {
+    constexpr int PAR = decltype(par_c)::value;
+    __builtin_amdgcn_s_setprio(3);   // vector work wins issue arbitration over the partner wave's MFMAs
+    unit_finish_c8(ua0, s_wd + c * kKC + kg * 8, L.d2[brow], slot0 + PAR * kA1, slo0 + PAR * kC8, slo0 + PAR * kC8 + shi_delta);
+    __builtin_amdgcn_sched_barrier(0);
+    wload16(w_mid_chunk, w_mid_s);
+    __builtin_amdgcn_sched_barrier(0);
+    unit_finish_c8(ua1, s_wd + c * kKC + kg * 8, L.d2[brow + 64], slot0 + PAR * kA1 + 64 * 16, slo0 + PAR * kC8 + 64 * 32,
+                   slo0 + PAR * kC8 + 64 * 32 + shi_delta);
+    __builtin_amdgcn_sched_barrier(0);
+    if (w_end_chunk >= 0) wload16(w_end_chunk, 1);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // chunk 0: table rows and the first weight fragments are requested, then the segment structure is worked out while they fly
+  vload(0);
+  const int S = prologue_segments<false>(p, L, e0, nvalid, tid, lane, wave);
+  vfinish(std::integral_constant<int, 0>(), 0, 0, 0, wave < 4 ? 0 : -1);   // + the fragments of chunk 0 (waves 4-7: k-step 0 only)
+  if (wave >= 4) vload(1);   // waves 4-7 build chunk 1 first thing in the loop
+  __syncthreads();
+
+  // matrix phase of chunk c (LDS buffer PAR):  2 fp16 k-steps x (8 row blocks x CB), then the correction: 8 row blocks x CB
+  // scaled e4m3 MFMAs.  Operand pipelines as in edge_x_m16.hip (inline-asm ds_read_b128, counted lgkmcnt): a ring of 3 fp16
+  // pieces, then a ring of 2 x 32-byte e4m3 operands (a lane's 32 bytes are contiguous in the image).
+  // tab_chunk: the chunk whose table rows are requested behind the second k-step (the next build of THIS wave).
+  auto mphase = [&](auto par_c, const int c, const int tab_chunk, const bool last, const int w_next) {
+    constexpr int PAR = decltype(par_c)::value;
+    constexpr int kO16 = PAR * (int)kA1, kO8 = PAR * (int)kC8;
+    f16x8 a[3];
+#define LDS_RD(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(off))
+#define LDS_WAIT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
+    LDS_RD(a[0], abase0, kO16 + 0); LDS_RD(a[1], abase0, kO16 + 256); LDS_RD(a[2], abase0, kO16 + 512);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int rb = 0; rb < 8; ++rb) {
+        const int u = 8 * s + rb;
+        if (u <= 13) LDS_WAIT(2);
+        else if (u == 14) LDS_WAIT(1);
+        else LDS_WAIT(0);
+        asm volatile("" : "+v"(a[u % 3]));   // uses of the piece stay below the wait
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+          acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u % 3], bq[s][cb], acc[rb][cb], 0, 0, 0);
+        if (u == 0) LDS_RD(a[0], abase0, kO16 + 768); if (u == 1) LDS_RD(a[1], abase0, kO16 + 1024); if (u == 2) LDS_RD(a[2], abase0, kO16 + 1280);
+        if (u == 3) LDS_RD(a[0], abase0, kO16 + 1536); if (u == 4) LDS_RD(a[1], abase0, kO16 + 1792); if (u == 5) LDS_RD(a[2], abase1, kO16 + 0);
+        if (u == 6) LDS_RD(a[0], abase1, kO16 + 256); if (u == 7) LDS_RD(a[1], abase1, kO16 + 512); if (u == 8) LDS_RD(a[2], abase1, kO16 + 768);
+        if (u == 9) LDS_RD(a[0], abase1, kO16 + 1024); if (u == 10) LDS_RD(a[1], abase1, kO16 + 1280); if (u == 11) LDS_RD(a[2], abase1, kO16 + 1536);
+        if (u == 12) LDS_RD(a[0], abase1, kO16 + 1792);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (s == 0) {   // the chunk's e4m3 fragments: used behind the second k-step
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+          const unsigned o = w80 + ((unsigned)cb * NC + (unsigned)c) * 2048u;
+          const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rs_w8, lane16, __builtin_amdgcn_readfirstlane(o), 0);
+          const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rs_w8, lane16, __builtin_amdgcn_readfirstlane(o + 1024u), 0);
+          b8[cb] = i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+        }
+      } else if (!last) {
+        vload(tab_chunk);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // correction
+    u32x4 c0[2], c1[2];   // ring of 2 operands: 16-byte halves
+    LDS_RD(c0[0], cbase, kO8 + 0); LDS_RD(c1[0], cbase, kO8 + 16); LDS_RD(c0[1], cbase, kO8 + 512); LDS_RD(c1[1], cbase, kO8 + 528);
+#pragma unroll
+    for (int rb = 0; rb < 8; ++rb) {
+      if (rb < 7) LDS_WAIT(2); else LDS_WAIT(0);
+      asm volatile("" : "+v"(c0[rb & 1]), "+v"(c1[rb & 1]));
+      const u32x4 x0 = c0[rb & 1], x1 = c1[rb & 1];
+      const i32x8 a8 = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+        acc[rb][cb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8[cb], acc[rb][cb], 0, 0, 0, kScaleA, 0, scale_b);
+      if (rb == 0) { LDS_RD(c0[0], cbase, kO8 + 1024); LDS_RD(c1[0], cbase, kO8 + 1040); }
+      if (rb == 1) { LDS_RD(c0[1], cbase, kO8 + 1536); LDS_RD(c1[1], cbase, kO8 + 1552); }
+      if (rb == 2) { LDS_RD(c0[0], cbase, kO8 + 2048); LDS_RD(c1[0], cbase, kO8 + 2064); }
+      if (rb == 3) { LDS_RD(c0[1], cbase, kO8 + 2560); LDS_RD(c1[1], cbase, kO8 + 2576); }
+      if (rb == 4) { LDS_RD(c0[0], cbase, kO8 + 3072); LDS_RD(c1[0], cbase, kO8 + 3088); }
+      if (rb == 5) { LDS_RD(c0[1], cbase, kO8 + 3584); LDS_RD(c1[1], cbase, kO8 + 3600); }
+    }
+#undef LDS_WAIT
+#undef LDS_RD
+    __builtin_amdgcn_sched_barrier(0);
+    if (w_next >= 0) wload16(w_next, 0);   // waves 4-7: k-step 0 of their next matrix phase (the barrier and the build hide it)
+  };
+
+  // SIMD partners (waves w and w + 4) in opposite phase, one barrier per chunk (edge_x_m16.hip); two chunks per loop iteration
+  // (NC is even: edge_f16c8_supported)
+  const std::integral_constant<int, 0> P0;
+  const std::integral_constant<int, 1> P1;
+  if (wave < 4) {   // multiply chunk i, then build chunk i + 1 and request the fragments of chunk i + 1
+    const int my_mode = tid < S ? segment_mode(p, L, e0, tid) : 0;   // row_ptr loads of the segment modes: under the first matrix phase
+    mphase(P0, 0, 1, false, -1);
+    if (tid < S) L.seg_mode[tid] = my_mode;
+    vfinish(P1, 1, 1, 0, 1);
+    __syncthreads();
+    for (int i = 1; i + 1 < NC - 1; i += 2) {
+      mphase(P1, i, i + 1, false, -1); vfinish(P0, i + 1, i + 1, 0, i + 1); __syncthreads();
+      mphase(P0, i + 1, i + 2, false, -1); vfinish(P1, i + 2, i + 2, 0, i + 2); __syncthreads();
+    }
+  } else {          // build chunk i + 1 (requesting k-step 1 of chunk i half way), multiply chunk i, request k-step 0 of chunk i + 1
+    vfinish(P1, 1, 0, 1, -1);
+    __builtin_amdgcn_sched_barrier(0);
+    mphase(P0, 0, 2, false, 1);
+    __syncthreads();
+    for (int i = 1; i + 1 < NC - 1; i += 2) {
+      vfinish(P0, i + 1, i, 1, -1); __builtin_amdgcn_sched_barrier(0); mphase(P1, i, i + 2, false, i + 1); __syncthreads();
+      vfinish(P1, i + 2, i + 1, 1, -1); __builtin_amdgcn_sched_barrier(0); mphase(P0, i + 1, i + 3, false, i + 2); __syncthreads();
+    }
+    wload16(NC - 1, 1);   // the last matrix phase has no build in front of it
+  }
+  mphase(P1, NC - 1, NC - 1, true, -1);
+  __syncthreads();
+
+  // ---- epilogue ---- accumulator layout of a 16x16 tile: column = lane & 15, row = 4 (lane >> 4) + register
+  constexpr float kAcc = kNegLog2e / kF16WScale;   // the weight fragments carry 2^8
+  if constexpr (!IS_M) {
+    // s[row] = [b3] + sum_n w3[n] * SiLU(a2[row][n] + b2[n]) over this workgroup's 512 columns (edge_x_m16.hip)
+    float part[32];
+#pragma unroll
+    for (int v = 0; v < 32; ++v) part[v] = 0.f;
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+      const int n = 16 * (cb0 + cb) + r15;
+      const float bb = p.b2x[n], w = p.w3x[n];
+      const f32x2 bb2 = {bb, bb}, w2 = {w, w}, k2 = {kAcc, kAcc}, one2 = {1.0f, 1.0f};
+#pragma unroll
+      for (int rb = 0; rb < 8; ++rb)
+#pragma unroll
+        for (int i = 0; i < 4; i += 2) {
+          const f32x2 a2 = {acc[rb][cb][i], acc[rb][cb][i + 1]};
+          const f32x2 t = __builtin_elementwise_fma(a2, k2, bb2);
+          const f32x2 e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+          const f32x2 d = e + one2;
+          const f32x2 rr = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+          const f32x2 sv = t * rr;
+          f32x2 pp = {part[rb * 4 + i], part[rb * 4 + i + 1]};
+          pp = __builtin_elementwise_fma(w2, sv, pp);
+          part[rb * 4 + i] = pp.x;
+          part[rb * 4 + i + 1] = pp.y;
+        }
+    }
+    {
+      float t0, t1;
+      butterfly16(part, lane, t0, t1);   // value indices 2 m, 2 m + 1 (m = lane & 15): row block m >> 1, register 2 (m & 1) + {0, 1}
+      const int row = 16 * (r15 >> 1) + 4 * q4 + 2 * (r15 & 1);
+      L.part[wave * kR + row] = t0;
+      L.part[wave * kR + row + 1] = t1;
+    }
+    __syncthreads();
+    if (tid < kR) {
+      float v = half == 0 ? p.scal[0] : 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v += L.part[w * kR + tid];
+      L.val[tid] = v;
+    }
+    __syncthreads();
+    coordinate_segment_sums(p, L, S, tile, half, tid, lane, wave);
+  } else {
+    // m = SiLU(a2 + b2), gate = sigmoid(wa . m + ba), messages m * gate summed per receiving node (:57-61); the form of
+    // tile128::message_epilogue on 16x16 accumulator tiles: 2 column blocks per wave, 64 message values per lane
+    float mval[8][CB][4];
+    {
+      float zp[32];
+#pragma unroll
+      for (int v = 0; v < 32; ++v) zp[v] = 0.f;
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        const int n = 16 * (cb0 + cb) + r15;
+        const float bb = p.b2m[n], wa = p.wa[n];
+#pragma unroll
+        for (int rb = 0; rb < 8; ++rb)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float m = silu_s(fmaf(acc[rb][cb][i], kAcc, bb));   // = -log2(e) * m
+            mval[rb][cb][i] = m;
+            zp[rb * 4 + i] = fmaf(wa, m, zp[rb * 4 + i]);
+          }
+      }
+      float t0, t1;
+      butterfly16(zp, lane, t0, t1);
+      const int row = 16 * (r15 >> 1) + 4 * q4 + 2 * (r15 & 1);
+      L.part[wave * kR + row] = t0;
+      L.part[wave * kR + row + 1] = t1;
+    }
+    __syncthreads();
+    if (tid < kR) {
+      float g = p.scal[1];
+#pragma unroll
+      for (int w = 0; w < 8; ++w) g += L.part[w * kR + tid];
+      L.val[tid] = sigmoid_f(g) * kNegInvLog2e;   // also undoes the scale of mval
+    }
+    __syncthreads();
+    for (int base = 0; base < S; base += kSegFast) {
+      const int ns = min(kSegFast, S - base);
+      if (base > 0) __syncthreads();   // the previous pass has been read
+      for (int t = tid; t < ns * kR; t += kT) {
+        const int seg = base + (t >> 7), row = t & 127;
+        L.gseg[t] = (L.seg_of_row[row] == seg) ? L.val[row] : 0.f;
+      }
+      __syncthreads();
+      for (int sg = 0; sg < ns; ++sg) {
+        const int seg = base + sg;
+        const float* gw = L.gseg + sg * kR + 4 * q4;
+        float v[CB];
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) v[cb] = 0.f;
+#pragma unroll
+        for (int rb = 0; rb < 8; ++rb) {
+          const f32x4 g4 = *reinterpret_cast<const f32x4*>(gw + 16 * rb);   // rows 16 rb + 4 q4 + {0..3}
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[cb] = fmaf(mval[rb][cb][i], g4[i], v[cb]);
+        }
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+          v[cb] += __shfl_xor(v[cb], 16);
+          v[cb] += __shfl_xor(v[cb], 32);
+        }
+        if (q4 == 0) {
+          const int mode = L.seg_mode[seg];
+          float* dstp = mode == 2 ? p.agg_m + (size_t)L.seg_node[seg] * p.MP : p.part_m + ((size_t)tile * 2 + mode) * p.MP;
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb) dstp[16 * (cb0 + cb) + r15] = v[cb];
+        }
+      }
+    }
+  }
+}
+
+// e4m3 B fragments of the correction product for v_mfma_scale_f32_16x16x128_f8f6f4, one instruction per 64-deep chunk:
+//   out[((nb * NC + c) * 2 + piece) * 1024 + lane * 16 + j],  lane l: column 16 nb + (l & 15), K block q = l >> 4
+//   block q covers hidden units 64 c + 32 (q >> 1) + [0, 32): even q holds e4m3(2^s_hi W_hi), odd q e4m3(2^s_lo W_lo) with
+//   v = W * scale (what the fp16 stream holds), W_hi = fp16(v), W_lo = v - W_hi;
+//   register piece `piece` of the lane holds k-piece piece ^ (q & 1) (16 hidden units each): the A operand's LDS image swaps
+//   the two 16-byte halves of a row in odd blocks (bank spreading), and a lane reads its 32 bytes in address order.
+// exps[0..1] = {127 - s_hi, 127 - s_lo} (e8m0 bytes of the block scales), from c8_exponents_kernel.
+__global__ void pack_frags_c8(const float* __restrict__ W, int Nout, int K, int ldw, int NP, int KP, unsigned char* __restrict__ out,
+                              float scale, const int* __restrict__ exps) {
+  __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);   // MODE.FP16_OVFL: the conversions saturate
+  const int NC = KP / 64;
+  const float inv_hi = __builtin_ldexpf(1.0f, exps[0] - 127), inv_lo = __builtin_ldexpf(1.0f, exps[1] - 127);   // 2^-s: the cvt divides
+  const size_t total = (size_t)(NP / 16) * NC * 2 * 64 * 8;   // byte PAIRS
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int jp = i & 7, lane = (i >> 3) & 63, piece = (i >> 9) & 1;
+    const size_t f = i >> 10;
+    const int c = f % NC, nb = f / NC;
+    const int q = lane >> 4, n = 16 * nb + (lane & 15);
+    const int k = 64 * c + 32 * (q >> 1) + 16 * (piece ^ (q & 1)) + 2 * jp;
+    float v[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float w = (n < Nout && k + t < K) ? W[(size_t)n * ldw + k + t] * scale : 0.f;
+      w = fminf(fmaxf(w, -65504.f), 65504.f);
+      const float hi = (float)(_Float16)w;
+      v[t] = (q & 1) ? w - hi : hi;
+    }
+    typedef __attribute__((ext_vector_type(2))) short i16x2_;
+    i16x2_ r = {0, 0};
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, v[0], v[1], (q & 1) ? inv_lo : inv_hi, false);
+    reinterpret_cast<unsigned short*>(out)[i] = (unsigned short)r.x;
+  }
+}
+// exps[0] = 127 - s_hi with 2^s_hi max|fp16(W scale)| in [112, 224] (e4m3 tops out at 448); exps[1] = exps[0] - 11 (a remainder
+// is at most 2^-11 of its head).  One workgroup.
+__global__ void c8_exponents_kernel(const float* __restrict__ W, int Nout, int K, int ldw, float scale, int* __restrict__ exps) {
+  __shared__ float red[256];
+  float m = 0.f;
+  for (size_t i = threadIdx.x; i < (size_t)Nout * K; i += blockDim.x) m = fmaxf(m, fabsf(W[(i / K) * ldw + (i % K)] * scale));
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s >= 1; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float mx = fminf(red[0], 65504.f);
+    int s_hi = 0;
+    if (mx > 0.f && mx == mx) s_hi = (int)floorf(log2f(224.0f / mx));
+    s_hi = s_hi > 40 ? 40 : (s_hi < -40 ? -40 : s_hi);
+    exps[0] = 127 - s_hi;
+    exps[1] = 127 - s_hi - 11;
+  }
+}
+
+}  // namespace
+
+int edge_f16c8_x_split(int WxP) { return WxP / (128 * kCBX); }   // column shares of the coordinate sums node_post adds
+
+int init_edge_f16c8_attributes() {
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_c8_kernel<false, kCBX>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_c8_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  return EGNN_OK;
+}
+
+// the shapes of edge_x_m16.hip (hidden width 512 / 1024, 256 message columns); fp16 16-column streams, e4m3 streams and their
+// scale exponents packed; fp32 table rows addressed by a 32-bit buffer offset
+bool edge_f16c8_supported(const EdgeParams& p) {
+  return (p.WxP == 512 || p.WxP == 1024) && p.MP == 256 && p.WmP % 64 == 0 && p.WmP >= 128 && p.w2x16 && p.w2m16 && p.w2x_c8 && p.w2m_c8 &&
+         p.c8_exp && c8_smem_bytes(p.WxP, false) <= 160 * 1024 && c8_smem_bytes(p.WmP, true) <= 160 * 1024 &&
+         (size_t)p.N * p.TC * 4 < ((size_t)1 << 32);
+}
+
+// coordinate kernel (WxP / 512 column shares per tile), then the message kernel (on `side` when the caller forks)
+int launch_edge_f16c8_x(const EdgeParams& p, hipStream_t st) {
+  const int tiles = (p.E + kR - 1) / kR;
+  hipLaunchKernelGGL((edge_c8_kernel<false, kCBX>), dim3(tiles * (p.WxP / (128 * kCBX))), dim3(kT), c8_smem_bytes(p.WxP, false), st, p);
+  EGNN_HIP(hipGetLastError());
+  return EGNN_OK;
+}
+int launch_edge_f16c8_m(const EdgeParams& p, hipStream_t st) {
+  const int tiles = (p.E + kR - 1) / kR;
+  hipLaunchKernelGGL((edge_c8_kernel<true, 2>), dim3(tiles), dim3(kT), c8_smem_bytes(p.WmP, true), st, p);
+  EGNN_HIP(hipGetLastError());
+  return EGNN_OK;
+}
+
+// out: e4m3 fragment stream of NP x KP bytes x 2; exps: int[2]
+int pack_c8_stream(const float* W, int Nout, int K, int ldw, int NP, int KP, void* out, float scale, int* exps, hipStream_t st) {
+  hipLaunchKernelGGL(c8_exponents_kernel, dim3(1), dim3(256), 0, st, W, Nout, K, ldw, scale, exps);
+  hipLaunchKernelGGL(pack_frags_c8, dim3(256), dim3(256), 0, st, W, Nout, K, ldw, NP, KP, static_cast<unsigned char*>(out), scale, exps);
+  EGNN_HIP(hipGetLastError());
+  return EGNN_OK;
+}
+
+}  // namespace egnn

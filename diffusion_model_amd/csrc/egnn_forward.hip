@@ -1027,6 +1027,7 @@ int init_kernel_attributes() {
   if ((rc = init_edge_dgrad_graph_attributes())) return rc;
   if ((rc = init_edge_x_m16_attributes())) return rc;
   if ((rc = init_edge_bf16x3_attributes())) return rc;
+  if ((rc = init_edge_f16c8_attributes())) return rc;
   done = true;
   return EGNN_OK;
 }
@@ -1087,6 +1088,7 @@ static void use_scaled_pack(egnn_ctx* c, int layer, EdgeParams& p, const float*&
   p.w2x = lp.w2x_bf16s; p.w2m = lp.w2m_bf16s;
   p.w2x16 = lp.w2x_bf16s16; p.w2m16 = lp.w2m_bf16s16;
   p.w2x_lo = lp.w2x_bf16s_lo; p.w2m_lo = lp.w2m_bf16s_lo;
+  p.w2x_c8 = lp.w2x_c8; p.w2m_c8 = lp.w2m_c8; p.c8_exp = lp.c8_exp;
 }
 // first-layer table of the v3 / v4 kernels (fp16, pre-scaled) for node features h
 static int launch_node_pre_f16(egnn_ctx* c, hipStream_t st, int layer, const float* h, const float* w1catT,
@@ -1226,6 +1228,15 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
     else prec = EGNN_PREC_F32;
     fill_edge_params(c, layer, prec, x, p);
   }
+  if (prec == EGNN_PREC_F16C8) {   // fp16 heads + e4m3 corrections where the 128-edge tiling applies, else the exact fp32 path
+    EdgeParams q = p;
+    const float *w1c, *b1c;
+    use_scaled_pack(c, layer, q, w1c, b1c);
+    q.w2x16 = lp.w2x_f16s16; q.w2m16 = lp.w2m_f16s16;
+    if (edge_sel >= 4 && edge_f16c8_supported(q) && !c->save_s1x) path = 7;
+    else prec = EGNN_PREC_F32;
+    fill_edge_params(c, layer, prec, x, p);
+  }
   if (prec == EGNN_PREC_F16) {   // fp16 operands on the bf16 path's kernels (hidden width 512 / 1024), else the exact fp32 path
     EdgeParams q = p;
     const float *w1c, *b1c;
@@ -1248,7 +1259,7 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
   }
   prof_begin(c, st, 1);
   {
-    if (path == 5) {   // bf16x3: exact fp32 table of the scaled first layers
+    if (path == 5 || path == 7) {   // bf16x3 / f16c8: exact fp32 table of the scaled first layers
       dim3 grid((N + kPre2Nodes - 1) / kPre2Nodes, (c->TC + kPre2Cols - 1) / kPre2Cols);
       const size_t sm = (size_t)((c->H + 1) & ~1) * 33 * sizeof(float);
       if (c->H <= 64)
@@ -1289,6 +1300,22 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
       R = 128;
       nsplit_x = p.WxP / 256;
       rc = launch_edge_bf16x3(p, st);
+    } else if (path == 7) {   // precision f16c8 (edge_f16c8.hip): fp16 16-column streams + e4m3 correction streams
+      R = 128;
+      nsplit_x = edge_f16c8_x_split(p.WxP);
+      p.w2x16 = lp.w2x_f16s16; p.w2m16 = lp.w2m_f16s16;
+      const bool fork = !c->prof && st != nullptr && c->side != nullptr && c->ev_fork != nullptr && fork_candidate(E, p.WxP);
+      if (fork) {
+        EGNN_HIP(hipEventRecord(c->ev_fork, st));
+        EGNN_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+        rc = launch_edge_f16c8_x(p, st);
+        if (!rc) rc = launch_edge_f16c8_m(p, c->side);
+        EGNN_HIP(hipEventRecord(c->ev_join, c->side));
+        EGNN_HIP(hipStreamWaitEvent(st, c->ev_join, 0));
+      } else {
+        rc = launch_edge_f16c8_x(p, st);
+        if (!rc) rc = launch_edge_f16c8_m(p, st);
+      }
     } else if ((path == 6 || path == 4) && !c->save_s1x && small_tiles(c, p) != 0) {
       // small graphs (the reference's per-call workload): 32-edge tiles, weight-stream-bound workgroups (edge_small.hip);
       // coordinate and message kernel side by side when the caller gave a side stream
@@ -1397,7 +1424,8 @@ int launch_layer_end(egnn_ctx* c, hipStream_t st, int layer, int prec, int norm_
     static const int f16_node = getenv("EGNN_F16_NODE") ? atoi(getenv("EGNN_F16_NODE")) : 2;
     PostParams qs = q;
     qs.w1h_bf16 = lp.w1h_f16k; qs.w2h_bf16p = lp.w2h_f16p; qs.w1h_lo = lp.w1h_f16k_lo; qs.w2h_lo = lp.w2h_f16p_lo;
-    const bool half_path = (prec == EGNN_PREC_F16 && c->last_path == 6) || (prec == EGNN_PREC_BF16X3 && c->last_path == 5);
+    const bool half_path = (prec == EGNN_PREC_F16 && c->last_path == 6) || (prec == EGNN_PREC_BF16X3 && c->last_path == 5) ||
+                           (prec == EGNN_PREC_F16C8 && c->last_path == 7);
     int hs_used = 1;
     if (half_path && f16_node == 2 && node_post_split_supported(qs)) {
       int rc = launch_node_post_bf16(qs, st, true, true, defer_finish, &hs_used);
@@ -1470,7 +1498,7 @@ static void free_layer(LayerPack& lp) {
                   lp.w2m_bf16, lp.b2m, lp.wa, lp.scal, lp.w1h_f32, lp.b1h, lp.w2h_f32, lp.b2h, lp.sc, lp.w2x_bf16s, lp.w2m_bf16s, lp.w1h_bf16, lp.w2h_bf16p,
                   lp.w2xT_bf16, lp.w2mT_bf16, lp.w1hl_bf16, lp.w2x_bf16s16, lp.w2x_bf16s_lo, lp.w2m_bf16s_lo,
                   lp.w2x_f16s16, lp.w2m_f16s, lp.w1h_f16, lp.w2h_f16p, lp.w1h_f16k, lp.w1h_f16k_lo, lp.w2h_f16p_lo,
-                  lp.w2m_bf16s16, lp.w2m_f16s16};
+                  lp.w2m_bf16s16, lp.w2m_f16s16, lp.w2x_c8, lp.w2m_c8, lp.c8_exp};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   lp = LayerPack();
@@ -1594,6 +1622,13 @@ int egnn_pack_layer(egnn_ctx* c, void* stream, int l, const float* m0_w, const f
       if ((rc = dev_alloc(&tmp, (size_t)HP * WhP))) return rc;
       lp.w2h_f16p_lo = tmp;
     }
+    // precision f16c8: e4m3 fragments of heads + remainders (2 bytes per weight) and the block-scale exponents
+    tmp = nullptr;
+    if ((rc = dev_alloc(&tmp, (size_t)WxP * WxP))) return rc;
+    lp.w2x_c8 = tmp; tmp = nullptr;
+    if ((rc = dev_alloc(&tmp, (size_t)MP * WmP))) return rc;
+    lp.w2m_c8 = tmp; tmp = nullptr;
+    if ((rc = dev_alloc(&lp.c8_exp, (size_t)4))) return rc;
   }
   const dim3 g(256), b(256);
   hipLaunchKernelGGL(pack_first, g, b, 0, st, x0_w, x0_b, m0_w, m0_b, H, Wx, Wm, WxP, WmP, lp.w1catT, lp.b1cat);
@@ -1641,6 +1676,9 @@ int egnn_pack_layer(egnn_ctx* c, void* stream, int l, const float* m0_w, const f
       hipLaunchKernelGGL((pack_frags_bf16<_Float16, true>), g, b, 0, st, h0_w, Wh, H + M, H + M, WhP, KS, reinterpret_cast<_Float16*>(lp.w1h_f16k_lo), kF16WScale);
       hipLaunchKernelGGL((pack_frags_bf16_accperm<_Float16, true>), g, b, 0, st, h2_w, H, Wh, Wh, HP, WhP, reinterpret_cast<_Float16*>(lp.w2h_f16p_lo), kF16WScale);
     }
+    // precision f16c8: the same scaled weights as e4m3 head / remainder fragments for the block-scaled correction product
+    if ((rc = pack_c8_stream(x2_w, Wx, Wx, Wx, WxP, WxP, lp.w2x_c8, s2 * kF16WScale, lp.c8_exp, st))) return rc;
+    if ((rc = pack_c8_stream(m2_w, M, Wm, Wm, MP, WmP, lp.w2m_c8, s2 * kF16WScale, lp.c8_exp + 2, st))) return rc;
     hipLaunchKernelGGL(pack_frags_bf16_lo, g, b, 0, st, x2_w, Wx, Wx, Wx, WxP, WxP, reinterpret_cast<__bf16*>(lp.w2x_bf16s_lo), s2);
     hipLaunchKernelGGL(pack_frags_bf16_lo, g, b, 0, st, m2_w, M, Wm, Wm, MP, WmP, reinterpret_cast<__bf16*>(lp.w2m_bf16s_lo), s2);
     hipLaunchKernelGGL(pack_frags_bf16<__bf16>, g, b, 0, st, h0_w, Wh, H + M, H + M, WhP, c->K1Q, reinterpret_cast<__bf16*>(lp.w1h_bf16), 1.0f);

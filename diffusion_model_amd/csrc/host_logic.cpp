@@ -52,7 +52,7 @@ int graph_args_check(bool have_model, int N, int E, int B, const void* edge_dst,
 
 int precision_scope_check(bool ready, int prec, int norm_scope) {
   if (!ready) { set_error("model/graph not set"); return EGNN_ESTATE; }
-  if (prec != EGNN_PREC_F32 && prec != EGNN_PREC_BF16 && prec != EGNN_PREC_BF16X3 && prec != EGNN_PREC_F16) {
+  if (prec != EGNN_PREC_F32 && prec != EGNN_PREC_BF16 && prec != EGNN_PREC_BF16X3 && prec != EGNN_PREC_F16 && prec != EGNN_PREC_F16C8) {
     set_error("bad precision %d", prec);
     return EGNN_EINVAL;
   }

@@ -43,6 +43,8 @@ struct EdgeParams {
   const void *w2x_lo, *w2m_lo;   // bf16 remainders W - bf16(W) of the scaled second-layer weights, same fragment layout (bf16x3)
   const void* w2x16;   // mlp_x.2 as 16x16x32 B fragments (edge_x_m16.hip), scaled; null when not packed
   const void* w2m16;   // mlp_m.2 as 16x16x32 B fragments (edge_small.hip), scaled; null when not packed
+  const void *w2x_c8, *w2m_c8;   // precision f16c8: e4m3 fragments of the correction product (edge_f16c8.hip: pack_frags_c8)
+  const int* c8_exp;             // device int[4]: e8m0 bytes of the weight block scales {x: hi, lo, m: hi, lo}
   float *agg_m, *agg_x, *part_m, *part_x;
   size_t agg_x_stride, part_x_stride;  // elements between the column-split copies of agg_x / part_x
   unsigned long long* stamps;  // diagnostic builds only (EGNN_EXP_STAMP): s_memtime stamps of one workgroup
@@ -341,5 +343,12 @@ bool edge_small_supported(const EdgeParams& p);
 int launch_edge_bf16x3(const EdgeParams& p, hipStream_t st);    // precision 'bf16x3': head / remainder split operands
 bool edge_bf16x3_supported(const EdgeParams& p);
 int init_edge_bf16x3_attributes();
+// precision 'f16c8': fp16 main product + block-scaled e4m3 correction (edge_f16c8.hip); p.w2x16 / p.w2m16 = the fp16 16-column streams
+int launch_edge_f16c8_x(const EdgeParams& p, hipStream_t st);
+int launch_edge_f16c8_m(const EdgeParams& p, hipStream_t st);
+bool edge_f16c8_supported(const EdgeParams& p);
+int edge_f16c8_x_split(int WxP);
+int init_edge_f16c8_attributes();
+int pack_c8_stream(const float* W, int Nout, int K, int ldw, int NP, int KP, void* out, float scale, int* exps, hipStream_t st);
 
 }  // namespace egnn

@@ -45,9 +45,14 @@ enum { EGNN_PREC_F32 = 0,   /* v_mfma_f32_32x32x2_f32: exact fp32 (parity mode) 
        EGNN_PREC_BF16X3 = 2,/* fp32-grade accuracy on the bf16 matrix cores: both operands of the per-edge second-layer
                                * products split into bf16 head + bf16 remainder, three MFMAs per tile (2^-17 relative);
                                * fp32 table, heads and node MLP.  Shapes outside the 128-edge-tile kernels run as F32. */
-       EGNN_PREC_F16 = 3 }; /* the BF16 path's kernels on fp16 MFMA operands (v_mfma_f32_16x16x32_f16 / 32x32x16_f16: same
+       EGNN_PREC_F16 = 3,   /* the BF16 path's kernels on fp16 MFMA operands (v_mfma_f32_16x16x32_f16 / 32x32x16_f16: same
                                * rate, 11 significant bits instead of 8; overflow saturates at +-65504); inference only
                                * (egcl_forward_save stays bf16).  Hidden widths other than 512 / 1024 run as F32. */
+       EGNN_PREC_F16C8 = 4 };/* fp32-grade accuracy for TWO bf16-equivalents of matrix work: fp16 heads on
+                               * v_mfma_f32_16x16x32_f16 + both remainder products on ONE block-scaled e4m3 instruction
+                               * (v_mfma_scale_f32_16x16x128_f8f6f4, twice the f16 rate) with fixed power-of-two block scales;
+                               * fp32 table, heads and split-operand node MLP as BF16X3 (csrc/edge_f16c8.hip); inference
+                               * only.  Hidden widths other than 512 / 1024 run as F32. */
 
 /* scope of the coordinate normaliser ||X_i - X_j||_F of EquivariantGraphNeuralNetwork.py:64 */
 enum { EGNN_NORM_CALL = 0,  /* literal reference: one scalar over every edge of the call  */
