@@ -276,20 +276,52 @@ def train_leg(args, rk, steps, warmup, batch):
                        "unit": "TFLOP/s", "frac": 3 * fwd_flop / (el / steps) / 1e12 / PEAK_TFLOPS["bf16"],
                        "algorithmic_flop_per_step": 3 * fwd_flop, "traffic": train_traffic, "traffic_source": train_traffic_src,
                        "backward_path": getattr(getattr(net, "_ctx", None), "last_backward_path", None)}
+    # the world = 1 step of THIS visit: an N = 1 run leaves a small record on the node (host, time, source fingerprint); an N > 1 run
+    # that finds a fresh one from the same host and the same sources takes value(1) from it
+    n1_path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "egnn_bench_ddp_train_n1.json")
+    from diffusion_model_amd import _lib as _l2
+    if world == 1 and rank == 0 and batch == 256 and n == 64:
+        try:
+            json.dump({"value": out["value"], "ms_per_step": out["ms_per_step"], "host": socket.gethostname(), "time": time.time(),
+                       "precision": args.precision, "training_sources_sha256": _l2.training_sources_sha256()}, open(n1_path, "w"))
+        except OSError:
+            pass
     if world > 1:
         el1 = rk.timed(lambda: run(steps, False))
         out["ms_per_step_without_allreduce"] = el1 * 1e3 / steps
+        # cost of the collective alone: the same ranks, all running at once, with the reducer disabled (it cannot see any other
+        # multi-rank loss, and with ranks sharing a device it is not an efficiency at all)
         out["efficiency_vs_no_collective"] = el1 / el
-        # data-parallel efficiency, self-contained: value(N) / (N x value(1)) with value(1) = the SAME step on THIS node with
-        # the reducer disabled (every rank alone on its GPU, timed a moment later in this process; max over ranks) -- boxes
-        # differ by +-4-8 %, so a single-GPU number from another visit is kept only as a second, cross-box figure
-        out["ddp_efficiency"] = el1 / el
-        out["ddp_efficiency_basis"] = "same node, same process: step time without the gradient all-reduce / with it (max over ranks)"
+        import torch.distributed as dist
+        devs = [None] * world
+        dist.all_gather_object(devs, (socket.gethostname(), int(dev.index)))
+        share = len(set(devs)) < world
+        out["ranks_share_device"] = share
+        # data-parallel efficiency = value(N) / (N x value(1)), value(1) from a GENUINE world = 1 run of this visit (same host, same
+        # sources, less than two hours old: `bench.py` / `bench.py --mode train` at N = 1 leaves it); never printed when ranks share
+        # a device (the one-GPU rehearsal), where N steps time-share one GPU
+        out["ddp_efficiency"], out["ddp_efficiency_basis"] = None, None
+        try:
+            r1 = json.load(open(n1_path))
+            fresh = (r1.get("host") == socket.gethostname() and time.time() - r1.get("time", 0) < 7200 and
+                     r1.get("training_sources_sha256") == _l2.training_sources_sha256() and r1.get("precision") == args.precision)
+        except (OSError, ValueError):
+            r1, fresh = None, False
+        if share:
+            out["ddp_efficiency_basis"] = "not reported: ranks share a device (functional rehearsal)"
+        elif fresh:
+            out["ddp_efficiency"] = out["value"] / (world * r1["value"])
+            out["single_gpu_value"] = r1["value"]
+            out["ddp_efficiency_basis"] = (f"value(N) / (N x value(1)); value(1) = {r1['ms_per_step']:.2f} ms per step from the world = 1 run "
+                                           f"of this visit on this host ({n1_path})")
+        else:
+            out["ddp_efficiency_basis"] = ("not reported: no world = 1 record of this visit (run `python bench.py --mode train` at N = 1 "
+                                           "first); see efficiency_vs_no_collective")
         try:
             ref1 = json.load(open(os.path.join(ROOT, "profiles", "ddp_train_n1.json")))
             out["single_gpu_value_other_box"] = ref1["value"]
             out["single_gpu_source"] = f"profiles/ddp_train_n1.json (git head {ref1.get('git_head', '?')})"
-            out["ddp_efficiency_cross_box"] = out["value"] / (world * ref1["value"])
+            out["ddp_efficiency_cross_box"] = None if share else out["value"] / (world * ref1["value"])
         except Exception:
             out["ddp_efficiency_cross_box"] = None
     final = torch.stack(losses[-steps:]).float()
@@ -299,15 +331,22 @@ def train_leg(args, rk, steps, warmup, batch):
 
 
 def golden_error_from_log(precision):
-    """max-relative error of `precision` on the ten reference goldens, read from the committed log of tools/prec_errors.py
-    (the test-suite asserts the same quantity on every run; the bench only quotes the measurement)."""
+    """max-relative error of `precision` on the ten reference goldens, read from the newest committed log of tools/prec_errors.py
+    whose header carries THIS tree's fingerprint of the forward kernels' sources (`forward_sources_sha256`): numbers measured on
+    other kernels are not quoted (the test-suite asserts the same quantity on every run; the bench only quotes the measurement).
+    -> (error, file) or None."""
     import glob
+    from diffusion_model_amd import _lib
+    want = _lib.forward_sources_sha256()
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_prec_errors.log"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_prec_errors*.log"))):
+        ok = False
         for line in open(f):
             w = line.split()
-            if len(w) == 3 and w[0] == "golden_max_rel" and w[1] == precision:
-                best = (float(w[2]), os.path.relpath(f, ROOT))     # the newest log wins (sorted by round tag)
+            if len(w) >= 2 and w[0] == "#" and "forward_sources_sha256" in line:
+                ok = line.strip().split("forward_sources_sha256=")[-1].split()[0] == want
+            if ok and len(w) == 3 and w[0] == "golden_max_rel" and w[1] == precision:
+                best = (float(w[2]), os.path.relpath(f, ROOT))     # the newest matching log wins (sorted by round tag)
     return best
 
 
@@ -382,7 +421,7 @@ def sample_leg(args, rk, precision=None, batch=None, atoms=None, steps=None, war
     except Exception:
         traffic = None
     out = {
-        "metric": "atoms*denoise-steps/sec, 64-atom SiO2 T=1000",
+        "metric": f"atoms*denoise-steps/sec, {n}-atom SiO2 T=1000",
         "value": world * B * n * K / elapsed,
         "unit": "atoms*denoise-steps/s",
         "n_gpus": world, "steps": K, "warmup": Wm,
@@ -445,15 +484,24 @@ def precision_legs(args, rk):
       fp16             the bf16 path's kernels on fp16 operands (11 significant bits; golden error from the same log);
       c3               configs[2] (32 x 512 atoms) on the headline precision, 3 timed steps."""
     out = {}
-    tg, _ = sample_leg(args, rk, precision="bf16x3", steps=10, warmup=3, reps=3)
-    tg3, _ = sample_leg(args, rk, precision="bf16x3", batch=32, atoms=512, steps=3, warmup=1, reps=1)
-    ge = golden_error_from_log("bf16x3")
+    cands = []
+    for prec in ("f16c8", "bf16x3"):
+        ge = golden_error_from_log(prec)
+        rec, _ = sample_leg(args, rk, precision=prec, steps=10, warmup=3, reps=3)
+        cands.append((prec, ge, rec))
+    ok = [c for c in cands if c[1] and c[1][0] <= 1e-4] or [c for c in cands if c[0] == "bf16x3"]
+    prec, ge, tg = min(ok, key=lambda c: c[2]["ms_per_step"])
+    tg3, _ = sample_leg(args, rk, precision=prec, batch=32, atoms=512, steps=3, warmup=1, reps=1)
     out["tolerance_grade"] = _sub(tg, {
-        "precision": "bf16x3", "tolerance": 1e-4,
+        "precision": prec, "tolerance": 1e-4,
         "golden_max_rel_err": ge[0] if ge else None, "golden_err_source": ge[1] if ge else None,
         "meets_tolerance": bool(ge and ge[0] <= 1e-4),
-        "why_this_precision": "fp32 (exact-f32 MFMA, 1/16 of the bf16 rate) also meets 1e-4 and is ~4x slower; fp16 and bf16 do not "
-                              "(profiles/r04_rounding_budget.txt: a two-product fp16 form stops at 1e-4..2.5e-4)",
+        "why_this_precision": "the fastest precision whose measured error on the ten reference goldens is <= 1e-4: f16c8 = fp16 heads + both "
+                              "remainder products on one block-scaled e4m3 MFMA (2 bf16-equivalents per product), bf16x3 = three bf16 "
+                              "products; fp32 (exact-f32 MFMA, 1/16 of the bf16 rate) also qualifies and is ~4x slower; fp16 and bf16 do "
+                              "not (profiles/r05_rounding_budget.txt)",
+        "candidates": {c[0]: {"ms_per_step": c[2]["ms_per_step"], "golden_max_rel_err": c[1][0] if c[1] else None,
+                              "edge_pass_ms": c[2]["roofline"]["avg_launch_ms"]} for c in cands},
         "c3": _sub(tg3)})
     f16, _ = sample_leg(args, rk, precision="fp16", steps=10, warmup=3, reps=3)
     ge = golden_error_from_log("fp16")

@@ -11,7 +11,7 @@ from .optim import RAdamScheduleFree, define_optimizer  # noqa: F401
 from .sampler import DeviceSampler, generate  # noqa: F401
 from .preprocessor import SpectrumCompressor  # noqa: F401
 from .snr import GammaNetwork, PositiveLinear  # noqa: F401
-from .training import GradAllReducer, diffuse_as_batch, eval_epoch, train_epoch, train_step, training_loss  # noqa: F401
+from .training import EarlyStopping, GradAllReducer, diffuse_as_batch, eval_epoch, train_epoch, train_step, training_loss  # noqa: F401
 from .checkpoint import load_model_state, save_model_state  # noqa: F401
 from .data import Batch, GraphData, GraphLoader, collate, load_dataset, make_graph, save_dataset  # noqa: F401
 

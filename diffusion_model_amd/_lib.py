@@ -14,20 +14,43 @@ NORM_SCOPES = {"call": NORM_CALL, "graph": NORM_GRAPH}
 
 
 
-def edge_kernel_sources_sha256() -> str:
-    """Fingerprint of the sources the dominant (edge) kernels are compiled from, plus the compiler flags: what a PMC
-    measurement of those kernels (profiles/traffic.json) is valid for.  A hash of the .so itself would not survive a rebuild
-    in another directory (hipcc derives its per-TU symbol ids from the path)."""
+_FLAGS_FALLBACK = b"FLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -fvisibility=hidden"
+
+
+def _flags_line() -> bytes:
+    """the compiler flags of the library build: the Makefile's FLAGS line where the Makefile travels with the package, else the
+    flags this package's Makefile is known to use (a fingerprint must not fail, or change meaning, because a build file is absent)"""
+    try:
+        with open(os.path.join(os.path.dirname(_HERE), "Makefile"), "rb") as f:
+            flags = [l for l in f.read().splitlines() if l.startswith(b"FLAGS")]
+        return b"\n".join(flags)
+    except OSError:
+        return _FLAGS_FALLBACK
+
+
+def _sources_sha256(names) -> str:
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(_HERE, "csrc")
-    for name in ("edge_x_m16.hip", "edge_bf16_v4.hip", "edge_tile.h", "kernels.h", "common.h"):
+    for name in names:
         with open(os.path.join(csrc, name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read())
-    with open(os.path.join(os.path.dirname(_HERE), "Makefile"), "rb") as f:
-        flags = [l for l in f.read().splitlines() if l.startswith(b"FLAGS")]
-    h.update(b"\n".join(flags))
+    h.update(_flags_line())
     return h.hexdigest()
+
+
+def edge_kernel_sources_sha256() -> str:
+    """Fingerprint of the sources the dominant (edge) kernels are compiled from (every header they include, diag.h among them),
+    plus the compiler flags: what a PMC measurement of those kernels (profiles/traffic.json) is valid for.  A hash of the .so
+    itself would not survive a rebuild in another directory (hipcc derives its per-TU symbol ids from the path)."""
+    return _sources_sha256(("edge_x_m16.hip", "edge_bf16_v4.hip", "edge_tile.h", "kernels.h", "common.h", "diag.h"))
+
+
+def forward_sources_sha256() -> str:
+    """Fingerprint of every source an inference forward of any precision runs through (edge kernels of all precisions, node
+    kernels, packing): what a measured error table (tools/prec_errors.py) is valid for."""
+    return _sources_sha256(("egnn_forward.hip", "edge_x_m16.hip", "edge_bf16_v4.hip", "edge_bf16_v3.hip", "edge_small.hip",
+                            "edge_bf16x3.hip", "edge_f16c8.hip", "node_bf16.hip", "edge_tile.h", "kernels.h", "common.h", "diag.h"))
 
 
 def training_sources_sha256() -> str:
@@ -42,9 +65,7 @@ def training_sources_sha256() -> str:
     for path in names:
         with open(path, "rb") as f:
             h.update(os.path.basename(path).encode() + b"\0" + f.read())
-    with open(os.path.join(os.path.dirname(_HERE), "Makefile"), "rb") as f:
-        flags = [l for l in f.read().splitlines() if l.startswith(b"FLAGS")]
-    h.update(b"\n".join(flags))
+    h.update(_flags_line())
     return h.hexdigest()
 
 

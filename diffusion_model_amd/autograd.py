@@ -64,10 +64,21 @@ class _Workspace:
         if not saved_activations:   # (the saved-activation backward reads s1 / a2 from what the forward kept)
             self.s1x, self.s1m = e(rows, Wx), e(rows, Wm)
             self.a2x, self.a2m = e(rows, Wx), e(rows, M)
-        self.g1x, self.g1m = e(rows, Wx), e(rows, Wm)
-        self.inp, self.g_in = e(rows, self.K1P), e(rows, self.K1P)
+        # dL/da1 and the gathered first-layer inputs / their gradients exist only in the forms that store them: the default
+        # 'graph' form of the first Linear layers never touches them (2 x 2 GiB + 2 x 256 MiB at 2^20 rows, W = 1024), so they
+        # are allocated on first use
+        self._lazy = {"g1x": (rows, Wx), "g1m": (rows, Wm), "inp": (rows, self.K1P), "g_in": (rows, self.K1P)}
+        self._e = e
         self.d2 = e(rows, dt=torch.float32)
         self.g_diff = e(rows, 3, dt=torch.float32)
+
+    def __getattr__(self, name):   # only reached for attributes not set yet
+        lazy = self.__dict__.get("_lazy", {})
+        if name in lazy:
+            t = self._e(*lazy[name])
+            setattr(self, name, t)
+            return t
+        raise AttributeError(name)
 
 
 def _hip_gemm_shapes(H, Wx, Wm, M):
@@ -195,8 +206,12 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_
             S1X, S1M, A2X, A2M = (t[a:a + n_pad] for t in kept[:4])
         else:
             S1X, S1M, A2X, A2M = ws.s1x, ws.s1m, ws.a2x, ws.a2m
-        s1x, s1m, a2x, a2m, g1x, g1m = S1X[:n], S1M[:n], A2X[:n], A2M[:n], ws.g1x[:n], ws.g1m[:n]
-        inp, g_in, d2, g_diff = ws.inp[:n], ws.g_in[:n], ws.d2[:n], ws.g_diff[:n]
+        s1x, s1m, a2x, a2m = S1X[:n], S1M[:n], A2X[:n], A2M[:n]
+        d2, g_diff = ws.d2[:n], ws.g_diff[:n]
+        if first != "graph":   # (the 'graph' form has no dL/da1 in memory)
+            g1x, g1m = ws.g1x[:n], ws.g1m[:n]
+        if not first:
+            inp, g_in = ws.inp[:n], ws.g_in[:n]
         if n_pad > n and not hip:   # rows the split library products read beyond the chunk (the own GEMMs stop at row n)
             for t in ((ws.g1x, ws.g1m, ws.inp) if kept is not None else (ws.s1x, ws.s1m, ws.a2x, ws.a2m, ws.g1x, ws.g1m, ws.inp)):
                 t[n:n_pad].zero_()

@@ -11,12 +11,14 @@
 //               profiles/r02i_x_decomposition.txt, code in the history before commit "diag.h")
 //               EGNN_EXP_DG_NOK / _NOG / _NOW / _L2G / _NOTAB / _NOEPI               (dgrad kernel)
 //               EGNN_EXP_DGG_NOSILU / _NOHOT / _NOROW (+ _DG_NOK / _DG_NOEPI)        (per-graph dgrad kernel)
+//               EGNN_EXP_C8_NOCORR / _NOMAIN / _NOBUILD / _NOCVT8 / _NOEPI           (f16c8 edge kernels, + EGNN_DEBUG bits 0 / 1)
 #pragma once
 
 #if !defined(EGNN_DIAG) && (defined(EGNN_EXP_STAMP) || defined(EGNN_EXP_STAMP2) || defined(EGNN_EXP_WGSTAMP) || defined(EGNN_EXP_DGSTAMP) || \
     defined(EGNN_EXP_NO_S1) || defined(EGNN_EXP_NO_T2) || defined(EGNN_EXP_NO_STAGE) || defined(EGNN_EXP_DG_NOK) || defined(EGNN_EXP_DG_NOG) || defined(EGNN_EXP_DG_NOW) || \
     defined(EGNN_EXP_DG_L2G) || defined(EGNN_EXP_DG_NOTAB) || defined(EGNN_EXP_DG_NOEPI) || defined(EGNN_EXP_NP_NONORM) ||                    \
-    defined(EGNN_EXP_NP_NOMLP) || defined(EGNN_EXP_DGG_NOSILU) || defined(EGNN_EXP_DGG_NOHOT) || defined(EGNN_EXP_DGG_NOROW))
+    defined(EGNN_EXP_NP_NOMLP) || defined(EGNN_EXP_DGG_NOSILU) || defined(EGNN_EXP_DGG_NOHOT) || defined(EGNN_EXP_DGG_NOROW) ||                   \
+    defined(EGNN_EXP_C8_NOCORR) || defined(EGNN_EXP_C8_NOMAIN) || defined(EGNN_EXP_C8_NOBUILD) || defined(EGNN_EXP_C8_NOCVT8) || defined(EGNN_EXP_C8_NOEPI))
 #error "EGNN_EXP_* switches are diagnostic builds: add -DEGNN_DIAG (tools/exp_build.sh)"
 #endif
 
@@ -94,6 +96,34 @@ EGNN_DIAG_FLAG(kNpNoNorm, false);
 EGNN_DIAG_FLAG(kNpNoMlp, true);
 #else
 EGNN_DIAG_FLAG(kNpNoMlp, false);
+#endif
+// f16c8 edge kernels (edge_f16c8.hip, tools/c8_ab.sh): without the correction MFMAs (and their operand reads), without the fp16
+// MFMAs, without the activation build's arithmetic (the LDS images keep their first contents), without the e4m3 conversions and
+// their LDS stores, without the epilogue
+#ifdef EGNN_EXP_C8_NOCORR
+EGNN_DIAG_FLAG(kC8NoCorr, true);
+#else
+EGNN_DIAG_FLAG(kC8NoCorr, false);
+#endif
+#ifdef EGNN_EXP_C8_NOMAIN
+EGNN_DIAG_FLAG(kC8NoMain, true);
+#else
+EGNN_DIAG_FLAG(kC8NoMain, false);
+#endif
+#ifdef EGNN_EXP_C8_NOBUILD
+EGNN_DIAG_FLAG(kC8NoBuild, true);
+#else
+EGNN_DIAG_FLAG(kC8NoBuild, false);
+#endif
+#ifdef EGNN_EXP_C8_NOCVT8
+EGNN_DIAG_FLAG(kC8NoCvt8, true);
+#else
+EGNN_DIAG_FLAG(kC8NoCvt8, false);
+#endif
+#ifdef EGNN_EXP_C8_NOEPI
+EGNN_DIAG_FLAG(kC8NoEpi, true);
+#else
+EGNN_DIAG_FLAG(kC8NoEpi, false);
 #endif
 #undef EGNN_DIAG_FLAG
 // EdgeParams::dbg (environment EGNN_DEBUG, read by a diagnostic build only): bit 0 = zero-size weight descriptor, bit 1 =

@@ -24,11 +24,12 @@
 // (128 edges, 8 waves, 16x16 MFMA tiles, 64-deep chunks, phase-opposed SIMD partners, XOR-swizzled fp16 image) with
 //   IS_M = false  coordinate branch (:62-65): 512 columns of mlp_x.2 per workgroup (WxP / 512 column shares), 4 column blocks per wave
 //   IS_M = true   message branch (:57-61): all 256 columns of mlp_m.2 + the attention gate, 2 column blocks per wave
-// What differs from that kernel's schedule, because the operands of a second matrix instruction have to fit beside its 128
-// accumulators: request distances are cut to what the now twice as long matrix phase hides -- the e4m3 weight fragments
-// of a chunk are requested after its first f16 k-step (used 500 cycles later), the fp32 table rows of the next build after
-// its second k-step (their 32 registers take the place of the f16 weight fragments, used 1,000 cycles later), the next
-// chunk's f16 fragments at the end of the matrix phase.
+// Request distances as in that kernel: the weight fragments (fp16 and e4m3) of chunk c + 1 are requested at the start of the
+// matrix phase of chunk c (two register sets), the fp32 table rows of a build right after the previous build.  That fits beside
+// the accumulators at 2 column blocks per wave (256 columns per workgroup, 64 accumulator registers); at 4 column blocks (512
+// columns: the mlp_x activations built twice per tile instead of four times) the operands of the second matrix instruction do
+// not fit beside 128 accumulators -- hipcc spills inside the K loop in every schedule tried -- so the coordinate
+// branch runs as WxP / 256 column shares (kCBX).
 #include "diag.h"
 #include "edge_tile.h"
 #include <type_traits>
@@ -42,9 +43,14 @@ constexpr int kT = 512;
 constexpr int kKC = 64;                        // activation chunk depth
 constexpr int kCBX = 2;                        // coordinate kernel: 16-column blocks per wave (2: 256 columns per workgroup; see edge_c8_kernel)
 constexpr size_t kA1 = (size_t)8 * kR * 16;    // fp16 image of a chunk: [8 k-groups][128 rows][8 f16], rows XOR-swizzled (edge_x_m16.hip)
-constexpr size_t kBS = (size_t)kR * 32 + 32;   // e4m3 image: one K block = [128 rows][32 B]; + 32 B: the two blocks a store instruction
-                                               // touches (0 / 2 or 1 / 3) land on the two halves of the 128-B store bank row
-constexpr size_t kC8 = 4 * kBS;                // [a_lo8 0-31 | a_hi8 0-31 | a_lo8 32-63 | a_hi8 32-63]
+// e4m3 image of a chunk: four K blocks [a_lo8 0-31 | a_hi8 0-31 | a_lo8 32-63 | a_hi8 32-63] of [128 rows][32 B], block q at
+// q * 4096 + 16 (q & 1) + 64 (q >> 1).  No swizzle: an operand read (ds_read_b128, 16-lane groups = rows 0-3 and 12-15 of block q
+// + rows 4-11 of block q + 1) finds the even block's rows on the even and the odd block's on the odd 16-byte slots of the 256-B
+// load bank row; a store instruction (ds_write_b64, 16 lanes = 2 rows x 8 pieces, blocks q and q + 2) covers the two 64-B
+// halves of the 128-B store bank row.  (The first build shifted whole blocks by 32 B and swapped halves by block parity:
+// SQ_LDS_BANK_CONFLICT = 26 % of the LDS cycles, profiles/r05c_f16c8_profile_summary.txt.)
+__host__ __device__ constexpr size_t c8_block(int q) { return (size_t)q * 4096 + 16 * (q & 1) + 64 * (q >> 1); }
+constexpr size_t kC8 = 4 * 4096 + 128;
 __host__ __device__ inline size_t c8_smem_bytes(int KP, bool is_m) {
   (void)is_m;
   return kOffLoop + 2 * kA1 + 2 * kC8 + (size_t)KP * 4;
@@ -66,6 +72,7 @@ __device__ __forceinline__ void unit_finish_c8(const Unit& u, const float* wd, f
     a[j + 4] = silu_s(fmaf(w1[j], d2, u.p1[j] + u.q1[j]));
   }
   const f16x8 h = pack8<f16x8>(a);   // RNE; MODE.FP16_OVFL: saturates instead of inf
+  if constexpr (diag::kC8NoCvt8) { *reinterpret_cast<f16x8*>(slot16) = h; return; }
   float lo[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) lo[j] = a[j] - (float)h[j];
@@ -105,15 +112,19 @@ __global__ __launch_bounds__(kT, 2) void edge_c8_kernel(const EdgeParams p) {
   const int e0 = tile * kR;
   const int nvalid = min(kR, p.E - e0);
 
+  DIAG_STAMP_SETUP(p.stamps + ((size_t)(IS_M ? 1 : 0) * 8 + wave) * 32 * 4);   // tools/stamps.py (diagnostic build only)
+  DIAG_STAMP(30, 0);   // kernel entry
   prologue_rows(p, L, e0, nvalid, IS_M ? p.wdm : p.wdx, KP, s_wd, tid);
+  DIAG_STAMP(30, 1);   // edge rows and geometry ready
 
   // ---- K loop ----
   const int NC = KP / kKC, KS = KP / 32;
   const int brow = tid >> 3, kg = tid & 7;   // this thread builds rows brow and brow + 64, hidden units 8 kg .. 8 kg + 7 of a chunk
-  const rsrc_t rs_tab = make_rsrc(p.table, (unsigned)min((size_t)p.N * p.TC * 4, (size_t)0xFFFFFFFFu));
+  const rsrc_t rs_tab = make_rsrc(p.table, diag::drop_table_loads(p.dbg) ? 0u : (unsigned)min((size_t)p.N * p.TC * 4, (size_t)0xFFFFFFFFu));
   const size_t ncols = IS_M ? (size_t)p.MP : (size_t)p.WxP;
-  const rsrc_t rs_w = make_rsrc(IS_M ? p.w2m16 : p.w2x16, (unsigned)(ncols * KP * 2));   // fp16 fragments [N/16][K/32][64][8]
-  const rsrc_t rs_w8 = make_rsrc(IS_M ? p.w2m_c8 : p.w2x_c8, (unsigned)(ncols * KP * 2));  // e4m3 fragments [N/16][K/64][2][64][16 B]
+  const unsigned wbytes = diag::drop_weight_loads(p.dbg) ? 0u : (unsigned)(ncols * KP * 2);
+  const rsrc_t rs_w = make_rsrc(IS_M ? p.w2m16 : p.w2x16, wbytes);    // fp16 fragments [N/16][K/32][64][8]
+  const rsrc_t rs_w8 = make_rsrc(IS_M ? p.w2m_c8 : p.w2x_c8, wbytes);   // e4m3 fragments [N/16][K/64][2][64][16 B]
   const unsigned vdst0 = (unsigned)L.dst[brow] * (unsigned)p.TC * 4u + (unsigned)kg * 32u;
   const unsigned vsrc0 = (unsigned)L.src[brow] * (unsigned)p.TC * 4u + (unsigned)kg * 32u;
   const unsigned vdst1 = (unsigned)L.dst[brow + 64] * (unsigned)p.TC * 4u + (unsigned)kg * 32u;
@@ -121,18 +132,15 @@ __global__ __launch_bounds__(kT, 2) void edge_c8_kernel(const EdgeParams p) {
   const unsigned offP = (IS_M ? 2u * p.WxP : 0u) * 4u, offQ = (IS_M ? 2u * p.WxP + p.WmP : (unsigned)p.WxP) * 4u;   // fp32 table {Px|Qx|Pm|Qm}
   // fp16 image slots of this thread (rows brow, brow + 64), as edge_x_m16.hip
   char* slot0 = s_a1 + (size_t)kg * (kR * 16) + (size_t)(brow ^ kg) * 16;
-  // e4m3 image: hidden units 8 kg .. + 7 sit in K block 2 (kg >> 2) (remainder) / + 1 (value), 16-byte piece (kg >> 1) & 1 of the
-  // row's 32 bytes, XORed by the block's parity (an operand read of 16 lanes covers rows of an even and of an odd block: they
-  // then hit the even / the odd 16-byte slots of the 256-B load bank row), 8-byte half kg & 1
-  const unsigned pc = (unsigned)(kg >> 1) & 1u, sub8 = (unsigned)(kg & 1) * 8u;
-  char* slo0 = s_c8 + (size_t)(2 * (kg >> 2)) * kBS + (size_t)brow * 32 + pc * 16u + sub8;
-  const int shi_delta = (int)kBS + 16 - 32 * (int)pc;   // the value slot: next block, other 16-byte piece
+  // e4m3 image: hidden units 8 kg .. + 7 sit in K block 2 (kg >> 2) (remainder) / + 1 (value), bytes 8 (kg & 3) .. + 7 of the row
+  char* slo0 = s_c8 + (size_t)(kg >> 2) * (c8_block(2) - c8_block(0)) + (size_t)brow * 32 + (size_t)(kg & 3) * 8;
+  constexpr int shi_delta = (int)(c8_block(1) - c8_block(0));   // the value slot: same place in the next block
   const unsigned lane16 = lane * 16u;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)s_a1;
   const unsigned abase0 = lds0 + (unsigned)q4 * (kR * 16) + (unsigned)(r15 ^ q4) * 16u;
   const unsigned abase1 = lds0 + (unsigned)(4 + q4) * (kR * 16) + (unsigned)(r15 ^ (4 + q4)) * 16u;
   const unsigned lds8 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)s_c8;
-  const unsigned cbase = lds8 + (unsigned)q4 * (unsigned)kBS + (unsigned)r15 * 32u;   // this lane's 32 operand bytes of row block 0
+  const unsigned cbase = lds8 + (unsigned)q4 * 4096u + 16u * (unsigned)(q4 & 1) + 64u * (unsigned)(q4 >> 1) + (unsigned)r15 * 32u;   // c8_block(q4): this lane's 32 operand bytes of row block 0
   const int cb0 = IS_M ? wave * CB : half * (8 * CB) + wave * CB;   // first 16-column block of this wave
   const unsigned w0 = (unsigned)cb0 * KS * 1024u;              // fp16 stream: 1 KiB per (column block, k-step)
   const unsigned w80 = (unsigned)cb0 * NC * 2048u;             // e4m3 stream: 2 KiB per (column block, chunk)
@@ -155,137 +163,333 @@ __global__ __launch_bounds__(kT, 2) void edge_c8_kernel(const EdgeParams p) {
     unit_load(ua0, rs_tab, vdst0, vsrc0, offP + kb, offQ + kb);
     unit_load(ua1, rs_tab, vdst1, vsrc1, offP + kb, offQ + kb);
   };
-  f16x8 bq[2][CB];   // fp16 weight fragments of the 2 k-steps of the chunk the next matrix phase multiplies
-  i32x8 b8[CB];      // e4m3 weight fragments of the running chunk
-  auto wload16 = [&](const int cq, const int s) {   // k-step s of chunk cq (clamped)
-    const int c = cq < NC ? cq : NC - 1;
+  // weight fragments: two register sets each, set c & 1 for chunk c; the sets of chunk c + 1 are requested at the start of the
+  // matrix phase of chunk c (a whole chunk of distance, as edge_x_m16.hip)
+  f16x8 bq[2][2][CB];   // [set][k-step][column block] fp16
+  i32x8 b8[2][CB];      // [set][column block] e4m3 (32 bytes per lane)
+  auto wload = [&](auto par_c, const int cq) {
+    constexpr int PAR = decltype(par_c)::value;
+    const int c = cq < NC ? cq : NC - 1;   // past the end: a harmless repeat
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb) bq[s][cb] = ldbuf_v8<f16x8>(rs_w, lane16, w0 + ((unsigned)cb * KS + (unsigned)(2 * c + s)) * 1024u);
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) bq[PAR][s][cb] = ldbuf_v8<f16x8>(rs_w, lane16, w0 + ((unsigned)cb * KS + (unsigned)(2 * c + s)) * 1024u);
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+      const unsigned o = w80 + ((unsigned)cb * NC + (unsigned)c) * 2048u;
+      const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rs_w8, lane16, __builtin_amdgcn_readfirstlane(o), 0);
+      const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rs_w8, lane16, __builtin_amdgcn_readfirstlane(o + 1024u), 0);
+      b8[PAR][cb] = i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+    }
   };
   // SiLU + operand forms of chunk c into LDS buffer PAR = c & 1 (a compile-time parity: the loop below is unrolled by two so
-  // that every LDS address of the K loop is a per-thread base + an immediate).  The two rows are finished ONE AFTER THE OTHER
-  // and the fp16 weight fragments of the next matrix phase are requested as their registers come free (w_mid after the first
-  // row, w_end after the second): with both rows' temporaries and 32 fragment registers live beside the 32 table registers the
-  // build did not fit beside the 128 accumulators.
-  auto vfinish = [&](auto par_c, const int c, const int w_mid_chunk, const int w_mid_s, const int w_end_chunk) {
+  // that every LDS address of the K loop is a per-thread base + an immediate)
+  auto vfinish = [&](auto par_c, const int c) {
     constexpr int PAR = decltype(par_c)::value;
+    if constexpr (diag::kC8NoBuild) { if (c > 1) { asm volatile("" :: "v"(ua0.p0), "v"(ua0.p1), "v"(ua0.q0), "v"(ua0.q1), "v"(ua1.p0), "v"(ua1.p1), "v"(ua1.q0), "v"(ua1.q1)); return; } }
     __builtin_amdgcn_s_setprio(3);   // vector work wins issue arbitration over the partner wave's MFMAs
     unit_finish_c8(ua0, s_wd + c * kKC + kg * 8, L.d2[brow], slot0 + PAR * kA1, slo0 + PAR * kC8, slo0 + PAR * kC8 + shi_delta);
-    __builtin_amdgcn_sched_barrier(0);
-    wload16(w_mid_chunk, w_mid_s);
-    __builtin_amdgcn_sched_barrier(0);
     unit_finish_c8(ua1, s_wd + c * kKC + kg * 8, L.d2[brow + 64], slot0 + PAR * kA1 + 64 * 16, slo0 + PAR * kC8 + 64 * 32,
                    slo0 + PAR * kC8 + 64 * 32 + shi_delta);
-    __builtin_amdgcn_sched_barrier(0);
-    if (w_end_chunk >= 0) wload16(w_end_chunk, 1);
     __builtin_amdgcn_s_setprio(0);
   };
+  const std::integral_constant<int, 0> P0;
+  const std::integral_constant<int, 1> P1;
 
   // chunk 0: table rows and the first weight fragments are requested, then the segment structure is worked out while they fly
   vload(0);
+  wload(P0, 0);
   const int S = prologue_segments<false>(p, L, e0, nvalid, tid, lane, wave);
-  vfinish(std::integral_constant<int, 0>(), 0, 0, 0, wave < 4 ? 0 : -1);   // + the fragments of chunk 0 (waves 4-7: k-step 0 only)
-  if (wave >= 4) vload(1);   // waves 4-7 build chunk 1 first thing in the loop
+  vfinish(P0, 0);
+  vload(1);
   __syncthreads();
+  DIAG_STAMP(30, 2);   // chunk 0 built, first weights requested
+  DIAG_RSTAMP(31, 1);
 
-  // matrix phase of chunk c (LDS buffer PAR):  2 fp16 k-steps x (8 row blocks x CB), then the correction: 8 row blocks x CB
-  // scaled e4m3 MFMAs.  Operand pipelines as in edge_x_m16.hip (inline-asm ds_read_b128, counted lgkmcnt): a ring of 3 fp16
-  // pieces, then a ring of 2 x 32-byte e4m3 operands (a lane's 32 bytes are contiguous in the image).
-  // tab_chunk: the chunk whose table rows are requested behind the second k-step (the next build of THIS wave).
-  auto mphase = [&](auto par_c, const int c, const int tab_chunk, const bool last, const int w_next) {
+  // matrix phase of chunk c (LDS buffer and weight set PAR):  the weights of chunk c + 1 are requested first, then 2 fp16
+  // k-steps x (8 row blocks x CB), then the correction: 8 row blocks x CB scaled e4m3 MFMAs.  Operand pipelines as in
+  // edge_x_m16.hip (inline-asm ds_read_b128, counted lgkmcnt): a ring of 3 fp16 pieces, then a ring of 2 x 32-byte e4m3 operands
+  // (a lane's 32 bytes are contiguous in the image).
+  auto mphase = [&](auto par_c, auto npar_c, const int c, const bool last) {
     constexpr int PAR = decltype(par_c)::value;
     constexpr int kO16 = PAR * (int)kA1, kO8 = PAR * (int)kC8;
-    f16x8 a[3];
+    // One operand pipeline through both parts of the phase (LDS returns in order; every wait below counts the reads issued AFTER
+    // the one it needs).  At 2 column blocks per wave an fp16 piece feeds 32 cycles of MFMAs and an e4m3 operand 64, so the reads
+    // (a scheduling barrier behind every group of MFMAs: hipcc otherwise sinks the MFMA builtins past the volatile asm that
+    // follows -- the waits then run back to back and the matrix work behind them, and accumulators get renamed and spilled)
+    // run 8 pieces / 4 operands = 256 cycles ahead of their use (the first build's rings of 3 / 2, copied from the 4-column-block
+    // kernel, left the matrix phase waiting on LDS: 4.0 ms of a 5.0 ms kernel with the whole build compiled out,
+    // profiles/r05e_c8_decomposition.txt); the first e4m3 operands are requested under the last fp16 MFMAs.
+    f16x8 a[8];
+    u32x4 c0[4], c1[4];
 #define LDS_RD(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(off))
 #define LDS_WAIT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
-    LDS_RD(a[0], abase0, kO16 + 0); LDS_RD(a[1], abase0, kO16 + 256); LDS_RD(a[2], abase0, kO16 + 512);
+    LDS_RD(a[0], abase0, kO16 + 0); LDS_RD(a[1], abase0, kO16 + 256); LDS_RD(a[2], abase0, kO16 + 512); LDS_RD(a[3], abase0, kO16 + 768);
+    LDS_RD(a[4], abase0, kO16 + 1024); LDS_RD(a[5], abase0, kO16 + 1280); LDS_RD(a[6], abase0, kO16 + 1536); LDS_RD(a[7], abase0, kO16 + 1792);
+    if (!last) wload(npar_c, c + 1);
+    LDS_WAIT(7);
+    asm volatile("" : "+v"(a[0]));
+    if constexpr (!diag::kC8NoMain) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+      for (int cb = 0; cb < CB; ++cb) acc[0][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], bq[PAR][0][cb], acc[0][cb], 0, 0, 0);
+    } else { asm volatile("" :: "v"(bq[PAR][0][0]), "v"(bq[PAR][0][1])); }
+    __builtin_amdgcn_sched_barrier(0);
+    LDS_RD(a[0], abase1, kO16 + 0);
+    LDS_WAIT(7);
+    asm volatile("" : "+v"(a[1]));
+    if constexpr (!diag::kC8NoMain) {
 #pragma unroll
-      for (int rb = 0; rb < 8; ++rb) {
-        const int u = 8 * s + rb;
-        if (u <= 13) LDS_WAIT(2);
-        else if (u == 14) LDS_WAIT(1);
-        else LDS_WAIT(0);
-        asm volatile("" : "+v"(a[u % 3]));   // uses of the piece stay below the wait
+      for (int cb = 0; cb < CB; ++cb) acc[1][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], bq[PAR][0][cb], acc[1][cb], 0, 0, 0);
+    } else { asm volatile("" :: "v"(bq[PAR][0][0]), "v"(bq[PAR][0][1])); }
+    __builtin_amdgcn_sched_barrier(0);
+    LDS_RD(a[1], abase1, kO16 + 256);
+    LDS_WAIT(7);
+    asm volatile("" : "+v"(a[2]));
+    if constexpr (!diag::kC8NoMain) {
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb)
-          acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u % 3], bq[s][cb], acc[rb][cb], 0, 0, 0);
-        if (u == 0) LDS_RD(a[0], abase0, kO16 + 768); if (u == 1) LDS_RD(a[1], abase0, kO16 + 1024); if (u == 2) LDS_RD(a[2], abase0, kO16 + 1280);
-        if (u == 3) LDS_RD(a[0], abase0, kO16 + 1536); if (u == 4) LDS_RD(a[1], abase0, kO16 + 1792); if (u == 5) LDS_RD(a[2], abase1, kO16 + 0);
-        if (u == 6) LDS_RD(a[0], abase1, kO16 + 256); if (u == 7) LDS_RD(a[1], abase1, kO16 + 512); if (u == 8) LDS_RD(a[2], abase1, kO16 + 768);
-        if (u == 9) LDS_RD(a[0], abase1, kO16 + 1024); if (u == 10) LDS_RD(a[1], abase1, kO16 + 1280); if (u == 11) LDS_RD(a[2], abase1, kO16 + 1536);
-        if (u == 12) LDS_RD(a[0], abase1, kO16 + 1792);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (s == 0) {   // the chunk's e4m3 fragments: used behind the second k-step
+      for (int cb = 0; cb < CB; ++cb) acc[2][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[2], bq[PAR][0][cb], acc[2][cb], 0, 0, 0);
+    } else { asm volatile("" :: "v"(bq[PAR][0][0]), "v"(bq[PAR][0][1])); }
+    __builtin_amdgcn_sched_barrier(0);
+    LDS_RD(a[2], abase1, kO16 + 512);
+    LDS_WAIT(7);
+    asm volatile("" : "+v"(a[3]));
+    if constexpr (!diag::kC8NoMain) {
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb) {
-          const unsigned o = w80 + ((unsigned)cb * NC + (unsigned)c) * 2048u;
-          const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rs_w8, lane16, __builtin_amdgcn_readfirstlane(o), 0);
-          const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rs_w8, lane16, __builtin_amdgcn_readfirstlane(o + 1024u), 0);
-          b8[cb] = i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
-        }
-      } else if (!last) {
-        vload(tab_chunk);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // correction
-    u32x4 c0[2], c1[2];   // ring of 2 operands: 16-byte halves
-    LDS_RD(c0[0], cbase, kO8 + 0); LDS_RD(c1[0], cbase, kO8 + 16); LDS_RD(c0[1], cbase, kO8 + 512); LDS_RD(c1[1], cbase, kO8 + 528);
+      for (int cb = 0; cb < CB; ++cb) acc[3][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[3], bq[PAR][0][cb], acc[3][cb], 0, 0, 0);
+    } else { asm volatile("" :: "v"(bq[PAR][0][0]), "v"(bq[PAR][0][1])); }
+    __builtin_amdgcn_sched_barrier(0);
+    LDS_RD(a[3], abase1, kO16 + 768);
+    LDS_WAIT(7);
+    asm volatile("" : "+v"(a[4]));
+    if constexpr (!diag::kC8NoMain) {
 #pragma unroll
-    for (int rb = 0; rb < 8; ++rb) {
-      if (rb < 7) LDS_WAIT(2); else LDS_WAIT(0);
-      asm volatile("" : "+v"(c0[rb & 1]), "+v"(c1[rb & 1]));
-      const u32x4 x0 = c0[rb & 1], x1 = c1[rb & 1];
+      for (int cb = 0; cb < CB; ++cb) acc[4][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[4], bq[PAR][0][cb], acc[4][cb], 0, 0, 0);
+    } else { asm volatile("" :: "v"(bq[PAR][0][0]), "v"(bq[PAR][0][1])); }
+    __builtin_amdgcn_sched_barrier(0);
+    LDS_RD(a[4], abase1, kO16 + 1024);
+    LDS_WAIT(7);
+    asm volatile("" : "+v"(a[5]));
+    if constexpr (!diag::kC8NoMain) {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) acc[5][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[5], bq[PAR][0][cb], acc[5][cb], 0, 0, 0);
+    } else { asm volatile("" :: "v"(bq[PAR][0][0]), "v"(bq[PAR][0][1])); }
+    __builtin_amdgcn_sched_barrier(0);
+    LDS_RD(a[5], abase1, kO16 + 1280);
+    LDS_WAIT(7);
+    asm volatile("" : "+v"(a[6]));
+    if constexpr (!diag::kC8NoMain) {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) acc[6][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[6], bq[PAR][0][cb], acc[6][cb], 0, 0, 0);
+    } else { asm volatile("" :: "v"(bq[PAR][0][0]), "v"(bq[PAR][0][1])); }
+    __builtin_amdgcn_sched_barrier(0);
+    LDS_RD(a[6], abase1, kO16 + 1536);
+    LDS_WAIT(7);
+    asm volatile("" : "+v"(a[7]));
+    if constexpr (!diag::kC8NoMain) {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) acc[7][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[7], bq[PAR][0][cb], acc[7][cb], 0, 0, 0);
+    } else { asm volatile("" :: "v"(bq[PAR][0][0]), "v"(bq[PAR][0][1])); }
+    __builtin_amdgcn_sched_barrier(0);
+    LDS_RD(a[7], abase1, kO16 + 1792);
+    LDS_WAIT(7);
+    asm volatile("" : "+v"(a[0]));
+    if constexpr (!diag::kC8NoMain) {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) acc[0][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], bq[PAR][1][cb], acc[0][cb], 0, 0, 0);
+    } else { asm volatile("" :: "v"(bq[PAR][1][0]), "v"(bq[PAR][1][1])); }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!diag::kC8NoCorr) { LDS_RD(c0[0], cbase, kO8 + 0); LDS_RD(c1[0], cbase, kO8 + 16); }
+    LDS_WAIT(8);
+    asm volatile("" : "+v"(a[1]));
+    if constexpr (!diag::kC8NoMain) {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) acc[1][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], bq[PAR][1][cb], acc[1][cb], 0, 0, 0);
+    } else { asm volatile("" :: "v"(bq[PAR][1][0]), "v"(bq[PAR][1][1])); }
+    __builtin_amdgcn_sched_barrier(0);
+    LDS_WAIT(7);
+    asm volatile("" : "+v"(a[2]));
+    if constexpr (!diag::kC8NoMain) {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) acc[2][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[2], bq[PAR][1][cb], acc[2][cb], 0, 0, 0);
+    } else { asm volatile("" :: "v"(bq[PAR][1][0]), "v"(bq[PAR][1][1])); }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!diag::kC8NoCorr) { LDS_RD(c0[1], cbase, kO8 + 512); LDS_RD(c1[1], cbase, kO8 + 528); }
+    LDS_WAIT(8);
+    asm volatile("" : "+v"(a[3]));
+    if constexpr (!diag::kC8NoMain) {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) acc[3][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[3], bq[PAR][1][cb], acc[3][cb], 0, 0, 0);
+    } else { asm volatile("" :: "v"(bq[PAR][1][0]), "v"(bq[PAR][1][1])); }
+    __builtin_amdgcn_sched_barrier(0);
+    LDS_WAIT(7);
+    asm volatile("" : "+v"(a[4]));
+    if constexpr (!diag::kC8NoMain) {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) acc[4][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[4], bq[PAR][1][cb], acc[4][cb], 0, 0, 0);
+    } else { asm volatile("" :: "v"(bq[PAR][1][0]), "v"(bq[PAR][1][1])); }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!diag::kC8NoCorr) { LDS_RD(c0[2], cbase, kO8 + 1024); LDS_RD(c1[2], cbase, kO8 + 1040); }
+    LDS_WAIT(8);
+    asm volatile("" : "+v"(a[5]));
+    if constexpr (!diag::kC8NoMain) {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) acc[5][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[5], bq[PAR][1][cb], acc[5][cb], 0, 0, 0);
+    } else { asm volatile("" :: "v"(bq[PAR][1][0]), "v"(bq[PAR][1][1])); }
+    __builtin_amdgcn_sched_barrier(0);
+    LDS_WAIT(7);
+    asm volatile("" : "+v"(a[6]));
+    if constexpr (!diag::kC8NoMain) {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) acc[6][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[6], bq[PAR][1][cb], acc[6][cb], 0, 0, 0);
+    } else { asm volatile("" :: "v"(bq[PAR][1][0]), "v"(bq[PAR][1][1])); }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!diag::kC8NoCorr) { LDS_RD(c0[3], cbase, kO8 + 1536); LDS_RD(c1[3], cbase, kO8 + 1552); }
+    LDS_WAIT(8);
+    asm volatile("" : "+v"(a[7]));
+    if constexpr (!diag::kC8NoMain) {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) acc[7][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[7], bq[PAR][1][cb], acc[7][cb], 0, 0, 0);
+    } else { asm volatile("" :: "v"(bq[PAR][1][0]), "v"(bq[PAR][1][1])); }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (diag::kC8NoCorr) { asm volatile("" :: "v"(b8[PAR][0]), "v"(b8[PAR][1])); } else {
+    LDS_WAIT(6);
+    asm volatile("" : "+v"(c0[0]), "+v"(c1[0]));
+    {
+      const u32x4 x0 = c0[0], x1 = c1[0];
       const i32x8 a8 = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb)
-        acc[rb][cb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8[cb], acc[rb][cb], 0, 0, 0, kScaleA, 0, scale_b);
-      if (rb == 0) { LDS_RD(c0[0], cbase, kO8 + 1024); LDS_RD(c1[0], cbase, kO8 + 1040); }
-      if (rb == 1) { LDS_RD(c0[1], cbase, kO8 + 1536); LDS_RD(c1[1], cbase, kO8 + 1552); }
-      if (rb == 2) { LDS_RD(c0[0], cbase, kO8 + 2048); LDS_RD(c1[0], cbase, kO8 + 2064); }
-      if (rb == 3) { LDS_RD(c0[1], cbase, kO8 + 2560); LDS_RD(c1[1], cbase, kO8 + 2576); }
-      if (rb == 4) { LDS_RD(c0[0], cbase, kO8 + 3072); LDS_RD(c1[0], cbase, kO8 + 3088); }
-      if (rb == 5) { LDS_RD(c0[1], cbase, kO8 + 3584); LDS_RD(c1[1], cbase, kO8 + 3600); }
+        acc[0][cb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8[PAR][cb], acc[0][cb], 0, 0, 0, kScaleA, 0, scale_b);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    LDS_RD(c0[0], cbase, kO8 + 2048); LDS_RD(c1[0], cbase, kO8 + 2064);
+    LDS_WAIT(6);
+    asm volatile("" : "+v"(c0[1]), "+v"(c1[1]));
+    {
+      const u32x4 x0 = c0[1], x1 = c1[1];
+      const i32x8 a8 = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+        acc[1][cb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8[PAR][cb], acc[1][cb], 0, 0, 0, kScaleA, 0, scale_b);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    LDS_RD(c0[1], cbase, kO8 + 2560); LDS_RD(c1[1], cbase, kO8 + 2576);
+    LDS_WAIT(6);
+    asm volatile("" : "+v"(c0[2]), "+v"(c1[2]));
+    {
+      const u32x4 x0 = c0[2], x1 = c1[2];
+      const i32x8 a8 = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+        acc[2][cb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8[PAR][cb], acc[2][cb], 0, 0, 0, kScaleA, 0, scale_b);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    LDS_RD(c0[2], cbase, kO8 + 3072); LDS_RD(c1[2], cbase, kO8 + 3088);
+    LDS_WAIT(6);
+    asm volatile("" : "+v"(c0[3]), "+v"(c1[3]));
+    {
+      const u32x4 x0 = c0[3], x1 = c1[3];
+      const i32x8 a8 = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+        acc[3][cb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8[PAR][cb], acc[3][cb], 0, 0, 0, kScaleA, 0, scale_b);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    LDS_RD(c0[3], cbase, kO8 + 3584); LDS_RD(c1[3], cbase, kO8 + 3600);
+    LDS_WAIT(6);
+    asm volatile("" : "+v"(c0[0]), "+v"(c1[0]));
+    {
+      const u32x4 x0 = c0[0], x1 = c1[0];
+      const i32x8 a8 = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+        acc[4][cb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8[PAR][cb], acc[4][cb], 0, 0, 0, kScaleA, 0, scale_b);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    LDS_WAIT(4);
+    asm volatile("" : "+v"(c0[1]), "+v"(c1[1]));
+    {
+      const u32x4 x0 = c0[1], x1 = c1[1];
+      const i32x8 a8 = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+        acc[5][cb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8[PAR][cb], acc[5][cb], 0, 0, 0, kScaleA, 0, scale_b);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    LDS_WAIT(2);
+    asm volatile("" : "+v"(c0[2]), "+v"(c1[2]));
+    {
+      const u32x4 x0 = c0[2], x1 = c1[2];
+      const i32x8 a8 = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+        acc[6][cb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8[PAR][cb], acc[6][cb], 0, 0, 0, kScaleA, 0, scale_b);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    LDS_WAIT(0);
+    asm volatile("" : "+v"(c0[3]), "+v"(c1[3]));
+    {
+      const u32x4 x0 = c0[3], x1 = c1[3];
+      const i32x8 a8 = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+        acc[7][cb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8[PAR][cb], acc[7][cb], 0, 0, 0, kScaleA, 0, scale_b);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     }
 #undef LDS_WAIT
 #undef LDS_RD
-    __builtin_amdgcn_sched_barrier(0);
-    if (w_next >= 0) wload16(w_next, 0);   // waves 4-7: k-step 0 of their next matrix phase (the barrier and the build hide it)
   };
 
   // SIMD partners (waves w and w + 4) in opposite phase, one barrier per chunk (edge_x_m16.hip); two chunks per loop iteration
   // (NC is even: edge_f16c8_supported)
-  const std::integral_constant<int, 0> P0;
-  const std::integral_constant<int, 1> P1;
-  if (wave < 4) {   // multiply chunk i, then build chunk i + 1 and request the fragments of chunk i + 1
+  if (wave < 4) {   // multiply chunk i, then build chunk i + 1 and request the table rows of chunk i + 2
     const int my_mode = tid < S ? segment_mode(p, L, e0, tid) : 0;   // row_ptr loads of the segment modes: under the first matrix phase
-    mphase(P0, 0, 1, false, -1);
+    DIAG_STAMP(0, 0);
+    mphase(P0, P1, 0, false);
+    DIAG_STAMP(0, 1);
     if (tid < S) L.seg_mode[tid] = my_mode;
-    vfinish(P1, 1, 1, 0, 1);
+    vfinish(P1, 1); vload(2);
+    DIAG_STAMP(0, 2);
     __syncthreads();
+    DIAG_STAMP(0, 3);
     for (int i = 1; i + 1 < NC - 1; i += 2) {
-      mphase(P1, i, i + 1, false, -1); vfinish(P0, i + 1, i + 1, 0, i + 1); __syncthreads();
-      mphase(P0, i + 1, i + 2, false, -1); vfinish(P1, i + 2, i + 2, 0, i + 2); __syncthreads();
+      DIAG_STAMP(i, 0); mphase(P1, P0, i, false); DIAG_STAMP(i, 1); vfinish(P0, i + 1); vload(i + 2); DIAG_STAMP(i, 2); __syncthreads(); DIAG_STAMP(i, 3);
+      DIAG_STAMP(i + 1, 0); mphase(P0, P1, i + 1, false); DIAG_STAMP(i + 1, 1); vfinish(P1, i + 2); vload(i + 3); DIAG_STAMP(i + 1, 2); __syncthreads(); DIAG_STAMP(i + 1, 3);
     }
-  } else {          // build chunk i + 1 (requesting k-step 1 of chunk i half way), multiply chunk i, request k-step 0 of chunk i + 1
-    vfinish(P1, 1, 0, 1, -1);
+  } else {          // build chunk i + 1 first, then multiply chunk i
+    DIAG_STAMP(0, 0);
+    vfinish(P1, 1); vload(2);
+    DIAG_STAMP(0, 1);
     __builtin_amdgcn_sched_barrier(0);
-    mphase(P0, 0, 2, false, 1);
+    mphase(P0, P1, 0, false);
+    DIAG_STAMP(0, 2);
     __syncthreads();
+    DIAG_STAMP(0, 3);
     for (int i = 1; i + 1 < NC - 1; i += 2) {
-      vfinish(P0, i + 1, i, 1, -1); __builtin_amdgcn_sched_barrier(0); mphase(P1, i, i + 2, false, i + 1); __syncthreads();
-      vfinish(P1, i + 2, i + 1, 1, -1); __builtin_amdgcn_sched_barrier(0); mphase(P0, i + 1, i + 3, false, i + 2); __syncthreads();
+      DIAG_STAMP(i, 0); vfinish(P0, i + 1); vload(i + 2); DIAG_STAMP(i, 1); __builtin_amdgcn_sched_barrier(0); mphase(P1, P0, i, false); DIAG_STAMP(i, 2); __syncthreads(); DIAG_STAMP(i, 3);
+      DIAG_STAMP(i + 1, 0); vfinish(P1, i + 2); vload(i + 3); DIAG_STAMP(i + 1, 1); __builtin_amdgcn_sched_barrier(0); mphase(P0, P1, i + 1, false); DIAG_STAMP(i + 1, 2); __syncthreads(); DIAG_STAMP(i + 1, 3);
     }
-    wload16(NC - 1, 1);   // the last matrix phase has no build in front of it
   }
-  mphase(P1, NC - 1, NC - 1, true, -1);
+  DIAG_STAMP(NC - 1, 0);
+  mphase(P1, P0, NC - 1, true);
+  DIAG_STAMP(NC - 1, 1);
   __syncthreads();
+  DIAG_STAMP(NC - 1, 3);
+  DIAG_STAMP(30, 3);   // K loop done
+  DIAG_RSTAMP(31, 2);
 
   // ---- epilogue ---- accumulator layout of a 16x16 tile: column = lane & 15, row = 4 (lane >> 4) + register
   constexpr float kAcc = kNegLog2e / kF16WScale;   // the weight fragments carry 2^8
+  if constexpr (diag::kC8NoEpi) {
+    float v = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < 8; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) v += acc[rb][cb][0] + acc[rb][cb][1] + acc[rb][cb][2] + acc[rb][cb][3];
+    if (v == 123.456f) p.agg_x[0] = v;
+    return;
+  }
   if constexpr (!IS_M) {
     // s[row] = [b3] + sum_n w3[n] * SiLU(a2[row][n] + b2[n]) over this workgroup's 512 columns (edge_x_m16.hip)
     float part[32];
@@ -400,14 +604,14 @@ __global__ __launch_bounds__(kT, 2) void edge_c8_kernel(const EdgeParams p) {
       }
     }
   }
+  DIAG_STAMP(31, 0);   // epilogue done
 }
 
 // e4m3 B fragments of the correction product for v_mfma_scale_f32_16x16x128_f8f6f4, one instruction per 64-deep chunk:
 //   out[((nb * NC + c) * 2 + piece) * 1024 + lane * 16 + j],  lane l: column 16 nb + (l & 15), K block q = l >> 4
 //   block q covers hidden units 64 c + 32 (q >> 1) + [0, 32): even q holds e4m3(2^s_hi W_hi), odd q e4m3(2^s_lo W_lo) with
 //   v = W * scale (what the fp16 stream holds), W_hi = fp16(v), W_lo = v - W_hi;
-//   register piece `piece` of the lane holds k-piece piece ^ (q & 1) (16 hidden units each): the A operand's LDS image swaps
-//   the two 16-byte halves of a row in odd blocks (bank spreading), and a lane reads its 32 bytes in address order.
+//   register piece `piece` of the lane holds hidden units 16 piece .. + 15 of its block (the A operand's 32 bytes in address order).
 // exps[0..1] = {127 - s_hi, 127 - s_lo} (e8m0 bytes of the block scales), from c8_exponents_kernel.
 __global__ void pack_frags_c8(const float* __restrict__ W, int Nout, int K, int ldw, int NP, int KP, unsigned char* __restrict__ out,
                               float scale, const int* __restrict__ exps) {
@@ -420,7 +624,7 @@ __global__ void pack_frags_c8(const float* __restrict__ W, int Nout, int K, int 
     const size_t f = i >> 10;
     const int c = f % NC, nb = f / NC;
     const int q = lane >> 4, n = 16 * nb + (lane & 15);
-    const int k = 64 * c + 32 * (q >> 1) + 16 * (piece ^ (q & 1)) + 2 * jp;
+    const int k = 64 * c + 32 * (q >> 1) + 16 * piece + 2 * jp;
     float v[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {

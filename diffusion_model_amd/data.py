@@ -275,10 +275,13 @@ class GraphLoader:
             gb = (s * self.world_size + self.rank) % nb
             idx = order[gb * self.batch_size:(gb + 1) * self.batch_size]
             recs = [self.dataset[i] for i in idx]
+            if s == steps - 1 and self.shuffle and self.seed is not None and self.epoch == epoch_at_start:
+                # the pass counts as completed when its LAST batch is handed out (the order is already drawn): a consumer that stops
+                # exactly there -- zip(range(len(loader)), loader), itertools.islice(loader, len(loader)) -- never resumes the
+                # generator, and would otherwise see the same permutation every epoch
+                self.epoch += 1
             if not on_gpu:
                 yield collate(recs, device=self.device)
-                if s == steps - 1 and self.shuffle and self.seed is not None and self.epoch == epoch_at_start:
-                    self.epoch += 1   # a COMPLETED pass (see _order)
                 continue
             with torch.cuda.stream(self._copy_stream):
                 batch = collate(recs, device=dev)
@@ -292,8 +295,6 @@ class GraphLoader:
                     v.record_stream(cur)
             plan_record_stream(plan, cur)
             yield batch
-        if on_gpu and self.shuffle and self.seed is not None and self.epoch == epoch_at_start:
-            self.epoch += 1   # a COMPLETED pass: the next one draws the next permutation (see _order)
 
 
 # ---- flat on-disk format ---------------------------------------------------------------------------------------------

@@ -16,6 +16,29 @@ import torch.distributed as dist
 from .diffusion import remove_mean
 
 
+class EarlyStopping:
+    """Patience counter of the reference's training drivers (parts/train_per_iretation.py:19-34): ``validate(loss)`` returns True
+    once the loss has been worse than the best one seen for more than ``patience`` consecutive calls; a loss that is not worse
+    (equal counts as not worse) becomes the new best and resets the counter.  Accepts a Python float or a 0-dim tensor (the
+    epoch loss of ``eval_epoch`` stays on the device until it is compared here)."""
+
+    def __init__(self, patience: int = 0):
+        self._step = 0
+        self._loss = float("inf")
+        self._patience = patience
+
+    def validate(self, loss) -> bool:
+        loss = float(loss)
+        if self._loss < loss:
+            self._step += 1
+            if self._step > self._patience:
+                return True
+        else:
+            self._step = 0
+            self._loss = loss
+        return False
+
+
 def diffuse_as_batch(pos, x_types, batch, diffusion_process, times: Optional[Sequence[int]] = None,
                      noise_pos: Optional[torch.Tensor] = None, noise_h: Optional[torch.Tensor] = None,
                      num_graphs: Optional[int] = None):

@@ -204,6 +204,13 @@ def test_shuffled_multi_rank_loader_draws_one_permutation():
     assert ld.epoch == 0 and [list(b.id) for b in ld] == [list(b.id) for b in peer]
     assert ld.epoch == 1 and peer.epoch == 1
     assert [list(b.id) for b in ld] == [list(b.id) for b in peer] == second
+    # a consumer that stops exactly AT the last batch (zip / islice never resume the generator) has completed the pass too
+    import itertools
+    z = dma.GraphLoader(recs, batch_size=2, shuffle=True, seed=7)
+    e1 = [list(b.id) for _, b in zip(range(len(z)), z)]
+    assert z.epoch == 1
+    e2 = [list(b.id) for b in itertools.islice(z, len(z))]
+    assert z.epoch == 2 and e1 == first and e2 == second
 
 
 def test_batch_copy_does_not_carry_a_plan_of_another_device():
@@ -215,3 +222,13 @@ def test_batch_copy_does_not_carry_a_plan_of_another_device():
     assert c.plan() is not p0 and torch.equal(c.plan().edge_dst, p0.edge_dst)
     d = b.to("cpu")
     assert d.plan() is not p0 and d.plan().edge_dst.device == d.pos.device
+
+
+def test_early_stopping_counts_consecutive_worse_losses():
+    """EarlyStopping (parts/train_per_iretation.py:19-34): stop once the loss was worse than the best for more than `patience`
+    consecutive validations; an equal or better loss resets the counter and becomes the best (NaN never compares worse)."""
+    es = dma.EarlyStopping(patience=2)
+    assert [es.validate(v) for v in (5.0, 4.0, 4.5, 4.2, 3.9, 4.0, 4.0, 4.1)] == [False] * 7 + [True]
+    es0 = dma.EarlyStopping()
+    assert es0.validate(torch.tensor(1.0)) is False and es0.validate(1.0) is False and es0.validate(1.5) is True
+    assert dma.EarlyStopping(patience=0).validate(float("nan")) is False

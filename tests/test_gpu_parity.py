@@ -54,8 +54,10 @@ def test_egnn_fp32_matches_reference_golden(tag):
             assert max_rel(xx.cpu(), layers[l][1]) <= 1e-4, f"layer {l} x"
 
 
-@pytest.mark.parametrize("tag", ["g64_H36", "g16x3_H36", "full_g64"])
+@pytest.mark.parametrize("tag", EGNN_CASES)
 def test_egnn_bf16_close_to_oracle(tag):
+    """every golden case: the full-width ones of <= 2,048 / 6,144 edges (full_g16x3, full_toy2x4_H3 / full_g64) run the 32- / 64-row
+    small-graph kernels of csrc/edge_small.hip in bf16, the narrow ones the generic bf16 kernel"""
     sd, h, x, sizes, layers, d = golden_case(G_EGNN, tag)
     net = build_net(sd, d, len(layers), precision="bf16")
     ei = dma.fully_connected_edge_index(sizes, device=DEV)
@@ -88,6 +90,47 @@ def test_egnn_bf16x3_matches_reference_golden(tag):
             hh, xx = net.egcl_list[l](ei, hh, xx)
             assert max_rel(hh.cpu(), layers[l][0]) <= 1e-4, f"layer {l} h"
             assert max_rel(xx.cpu(), layers[l][1]) <= 1e-4, f"layer {l} x"
+
+
+# precision 'f16c8' (csrc/edge_f16c8.hip): fp16 heads on v_mfma_f32_16x16x32_f16 + both remainder products on one block-scaled
+# e4m3 instruction: north_star's 1e-4 for two bf16-equivalents of matrix work per product.  Measured (profiles/r05b_prec_errors_
+# f16c8_first.log, tools/prec_errors.py): 9.2e-6 / 5.6e-6 / 3.5e-5 max-relative on the three full-width goldens (the CPU emulation
+# of its roundings, tools/rounding_budget.py, predicts 6e-6 / 5e-6 / 4e-5); the bar here is 5e-5, per layer 1e-4.
+F16C8_TOL = 5e-5
+@pytest.mark.parametrize("tag", EGNN_CASES)
+def test_egnn_f16c8_matches_reference_golden(tag):
+    sd, h, x, sizes, layers, d = golden_case(G_EGNN, tag)
+    L = len(layers)
+    net = build_net(sd, d, L, precision="f16c8")
+    ei = dma.fully_connected_edge_index(sizes, device=DEV)
+    with torch.no_grad():
+        h_o, x_o = net(ei, h.to(DEV), x.to(DEV))
+    eh, ex = max_rel(h_o.cpu(), layers[-1][0]), max_rel(x_o.cpu(), layers[-1][1])
+    ee = rel_err(x_o.cpu() - x, layers[-1][1] - x)
+    print(f"f16c8 {tag}: h {eh:.2e} x {ex:.2e} eps_x {ee:.2e}")
+    assert eh <= F16C8_TOL and ex <= F16C8_TOL and ee <= F16C8_TOL
+    hh, xx = h.to(DEV), x.to(DEV)
+    with torch.no_grad():
+        for l in range(L):
+            net.egcl_list[l].precision = "f16c8"   # the single-layer modules carry their own precision attribute
+            hh, xx = net.egcl_list[l](ei, hh, xx)
+            assert max_rel(hh.cpu(), layers[l][0]) <= 1e-4, f"layer {l} h"
+            assert max_rel(xx.cpu(), layers[l][1]) <= 1e-4, f"layer {l} x"
+
+
+def test_f16c8_saturates_and_propagates_nan():
+    """the e4m3 conversions saturate (MODE.FP16_OVFL) instead of producing the e4m3 NaN on overflow: huge activations stay finite;
+    a NaN input must still come out as NaN (the sampler's sticky non-finite flag relies on it)"""
+    sd, h, x, sizes, layers, d = golden_case(G_EGNN, "full_g64")
+    net = build_net(sd, d, len(layers), precision="f16c8")
+    ei = dma.fully_connected_edge_index(sizes, device=DEV)
+    with torch.no_grad():
+        h_o, x_o = net(ei, (h * 3.0e4).to(DEV), x.to(DEV))
+        assert torch.isfinite(h_o).all() and torch.isfinite(x_o).all()
+        hb = h.clone()
+        hb[5, 3] = float("nan")
+        h_n, x_n = net(ei, hb.to(DEV), x.to(DEV))
+        assert not torch.isfinite(h_n).all()
 
 
 # precision 'fp16': the bf16 path's kernels on fp16 MFMA operands (11 significant bits instead of 8, same matrix-core rate)
@@ -228,7 +271,7 @@ def c2_inputs(batch, n_atoms=64, H=36, seed=0):
 # re-association) -> h' 2.9e-5 (node MLP operands re-rounded) -> 2.4e-4 -> 5.3e-4 -> 1.2e-3; the 32x32x16 kernels of commit
 # aadce9a give the same table (profiles/r04a_perm_table_aadce9a_32x32x16.log), fp32 and bf16x3 stay at 0 / 3e-7;
 # test_graph_permutation_seed_is_fp32_reassociation asserts the seed.
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16x3", 1e-4), ("bf16", 3e-2), ("fp16", 1.5e-3)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16x3", 1e-4), ("f16c8", 1e-4), ("bf16", 3e-2), ("fp16", 1.5e-3)])
 def test_full_size_c2_properties(precision, tol):
     """BASELINE configs[1] size (256 graphs x 64 atoms, L=4, widths 1024/256): size-independent
     properties -- E(3) equivariance, graph-permutation equivariance, batch == single-graph calls --
@@ -303,7 +346,7 @@ def test_graph_permutation_seed_is_fp32_reassociation(precision):
     assert max(errs) <= 1e-6 and float(per_graph) <= 1e-6
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16x3", 1e-4), ("bf16", 3e-2), ("fp16", 3e-3)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16x3", 1e-4), ("f16c8", 1e-4), ("bf16", 3e-2), ("fp16", 3e-3)])
 def test_full_size_c3_properties(precision, tol):
     """BASELINE configs[2] size at FULL width (32 graphs x 512 atoms, E = 8,372,224, L=4, widths 1024/256: the
     edge_kernel_bf16_v3<2,false> / <1,true> kernels on degree-511 rows, 4 tiles per receiving node): E(3)
@@ -535,7 +578,7 @@ def test_sampler_graph_replay_equals_eager_and_is_seed_deterministic():
     assert not torch.equal(smp2.sample()[0], pos)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16", "fp16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16c8", "bf16", "fp16"])
 def test_no_scratch_read_before_write(precision, monkeypatch):
     """The library's own device buffers (context scratch, weight packs, sampler state) come from hipMalloc, which hands out zeros
     in a fresh process and the previous owner's bytes afterwards.  With EGNN_DEBUG_POISON=1 every such buffer starts as 0xFF
@@ -679,7 +722,8 @@ def test_width_sweep_all_edge_kernel_variants(H, m_size, wm, wx, wh):
     batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes)).to(DEV)
     for scope in ("call", "graph"):
         h_ref, x_ref = egnn_ref.egnn_forward(sd, ei_cpu, h, x, norm_scope=scope, graph_ptr=ptr)
-        for precision, tol in (("fp32", 1e-4), ("bf16x3", 1e-4), ("bf16", 1e-2)):
+        # fp16 / f16c8: the reference widths run their own kernels, every other shape the exact fp32 kernels (include/egnn_amd.h)
+        for precision, tol in (("fp32", 1e-4), ("bf16x3", 1e-4), ("f16c8", 1e-4), ("bf16", 1e-2), ("fp16", 2.5e-3)):
             net = build_net(sd, d, 2, precision=precision, norm_scope=scope)
             with torch.no_grad():
                 h_o, x_o = net(ei_cpu.to(DEV), h.to(DEV), x.to(DEV), batch=batch)

@@ -90,7 +90,7 @@ def oracle_batches():
     return out
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16c8", "bf16", "fp16"])
 def test_sampled_structure_statistics_match_oracle(precision, oracle_batches):
     net, sd, A, T, proc = _net(precision)
     for n in (3, 9):

@@ -195,7 +195,7 @@ def _run_threads(fns):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16x3", 1e-3), ("bf16", 5e-2)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16x3", 1e-3), ("f16c8", 1e-3), ("bf16", 5e-2), ("fp16", 5e-3)])
 def test_partitioned_sampler_emulated_ranks_match_single_context(precision, tol):
     """3 emulated ranks (threads, own egnn_ctx each) on a 2-graph radius batch whose node ranges cut through the
     graphs == DeviceSampler on the same graph with the same seed (same Philox draws).  Not bitwise: a rank's edge

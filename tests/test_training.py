@@ -598,6 +598,74 @@ def test_graph_form_backward_against_the_chain_and_fp32_incl_input_gradients(gra
           f"chain {rel_err(gc['input.x'], gf['input.x']):.2e}")
 
 
+# Input gradients against the ORACLE.  The round-4 bug (a dropped dL/d(x_i - x_j) term of the kept-activation
+# backward) lived exactly in dL/dx of a layer's input, and the test that found it compared HIP with HIP.  Here dL/dh and dL/dx of
+# EVERY precision and EVERY backward form are held against the oracle's autograd on the same inputs and the same loss, together
+# with the parameter gradients, on ragged fully connected graphs and on sparse radius graphs of uneven degree.
+# Bars = 1.5 x the printed measurement (profiles/r05*_gpu_tests.log), per precision: (parameters, dL/dh, dL/dx).
+_INPUT_GRAD_TOL = {
+    "fp32": (2e-4, 2e-4, 2e-4), "bf16x3": (2e-4, 2e-4, 2e-4), "f16c8": (2e-4, 2e-4, 2e-4),
+    "bf16": (2e-2, 2e-2, 2e-2), "fp16": (2e-2, 2e-2, 2e-2),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graphs", ["fully_connected", "radius"])
+@pytest.mark.parametrize("form", ["graph", "chain", "factorised", "recompute"])
+def test_input_and_parameter_gradients_match_oracle_autograd(form, graphs, monkeypatch):
+    from diffusion_model_amd import autograd as _ag
+    from oracle.egnn_ref import egnn_forward as oracle_forward
+    H = 36
+    d = dims_for(H, 256, 1024, 1024, 1024)
+    sizes = (33, 64, 1, 17, 50)
+    n = sum(sizes)
+    dev = "cuda"
+    g = torch.Generator().manual_seed(12)
+    h0, x0 = torch.randn(n, H, generator=g), torch.randn(n, 3, generator=g) * 1.5
+    wh, wx = torch.randn(n, H, generator=g), torch.randn(n, 3, generator=g)
+    monkeypatch.setattr(_ag, "EDGE_CHUNK", 4300)          # 64 x 63 = 4032 edges: the big graph alone; the others in pairs
+    monkeypatch.setenv("EGNN_BWD_FIRST", "1" if form == "factorised" else "0")
+    monkeypatch.setenv("EGNN_BWD_GRAPH", "0" if form in ("chain", "factorised") else "1")
+    monkeypatch.setenv("EGNN_BWD_SAVE", "0" if form == "recompute" else "1")
+    if graphs == "radius":
+        plan = dma.radius_plan(x0.to(dev), list(sizes), 1.6)
+    else:
+        plan = dma.fully_connected_plan(list(sizes), torch.device(dev))
+    ei = dma.plan_edge_index(plan).cpu()
+    ptr = torch.tensor([0] + torch.cumsum(torch.tensor(sizes), 0).tolist())
+    torch.manual_seed(9)
+    ref_net = dma.EquivariantGNN(2, **d)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in ref_net.state_dict().items()}
+    hr, xr = h0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+    ho_r, xo_r = oracle_forward(sd, ei, hr, xr, "graph", ptr)
+    ((ho_r * wh).sum() + (xo_r * wx).sum()).backward()
+    want = {k: v.grad for k, v in sd.items()}
+    # the fp32-grade precisions share one backward (the fp32 chain): they run under the default form only
+    precisions = ("bf16", "fp16") if form != "graph" else ("fp32", "bf16x3", "f16c8", "bf16", "fp16")
+    for prec in precisions:
+        m = dma.EquivariantGNN(2, **d)
+        m.load_state_dict({k: v.detach() for k, v in sd.items()})
+        m.to(dev).train()
+        m.precision, m.norm_scope = prec, "graph"
+        h = h0.to(dev).requires_grad_(True)
+        x = x0.to(dev).requires_grad_(True)
+        ho, xo = m(plan, h, x)
+        ((ho * wh.to(dev)).sum() + (xo * wx.to(dev)).sum()).backward()
+        if prec == "bf16":     # the form under test is the one that ran (fp16 forwards recompute on the bf16 kernels)
+            assert _ag.LAST_FIRST_LAYER_FORM == {"graph": "graph", "chain": None, "factorised": "reduce", "recompute": "graph"}[form]
+            assert m._ctx.last_backward_path == ("recompute" if form == "recompute" else "kept activations")
+        e_par = {k: rel_err(p.grad.detach().cpu(), want[k]) for k, p in m.named_parameters()}
+        e_h, e_x = rel_err(h.grad.detach().cpu(), hr.grad), rel_err(x.grad.detach().cpu(), xr.grad)
+        worst = max(e_par, key=e_par.get)
+        print(f"input gradients vs oracle autograd [{graphs}, {form}] {prec}: dL/dh {e_h:.2e} dL/dx {e_x:.2e} "
+              f"parameters worst {e_par[worst]:.2e} ({worst})")
+        tp, th, tx = _INPUT_GRAD_TOL[prec]
+        assert torch.isfinite(h.grad).all() and torch.isfinite(x.grad).all()
+        assert e_h <= th and e_x <= tx, (prec, e_h, e_x)
+        for k, e in e_par.items():
+            assert e <= tp, (prec, k, e)
+
+
 @pytest.mark.gpu
 def test_node_activation_stage_matches_torch():
     """egcl_backward_node_act: s = SiLU(z + b1), dL/dz = dL/ds * SiLU'(z + b1) as bf16 and the bias gradient, against float64

@@ -139,14 +139,15 @@ def c2(f, precisions, weights="default"):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="gpurun_out/prec.log")
-    ap.add_argument("--precisions", default="bf16,fp16,bf16x3")
+    ap.add_argument("--precisions", default="bf16,fp16,bf16x3,f16c8")
     ap.add_argument("--skip-c2", action="store_true")
     ap.add_argument("--skip-goldens", action="store_true")
     a = ap.parse_args()
     os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
     precisions = a.precisions.split(",")
     with open(a.out, "a") as f:
-        log(f, f"# tools/prec_errors.py  EGNN_F16_NODE={os.environ.get('EGNN_F16_NODE', '1')}  lib {_lib.LIB_PATH}")
+        log(f, f"# tools/prec_errors.py  EGNN_F16_NODE={os.environ.get('EGNN_F16_NODE', '2')}  lib {_lib.LIB_PATH}  "
+                   f"forward_sources_sha256={_lib.forward_sources_sha256()}")
         if not a.skip_goldens:
             goldens(f, precisions)
         if not a.skip_c2:

@@ -7,7 +7,7 @@ import diffusion_model_amd as dma
 from diffusion_model_amd import _lib
 H, M, W, A, T, L, B, n = 36, 256, 1024, 2, 1000, 1, int(os.environ.get("EGNN_STAMP_B", "256")), 64
 torch.manual_seed(0)
-net = dma.EquivariantGNN(L, 2*H+1, W, M, 2*H+1, W, 1, H+M, W, H).cuda().eval(); net.precision = "bf16"
+net = dma.EquivariantGNN(L, 2*H+1, W, M, 2*H+1, W, 1, H+M, W, H).cuda().eval(); net.precision = os.environ.get("EGNN_STAMP_PREC", "bf16")
 for l in net.egcl_list:
     l.mlp_x[4].weight.data.mul_(1e-3)
 proc = dma.E3DiffusionProcess(1e-5, 2.0, T)
