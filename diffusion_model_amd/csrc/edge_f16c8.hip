@@ -41,7 +41,16 @@ namespace {
 using namespace tile128;
 constexpr int kT = 512;
 constexpr int kKC = 64;                        // activation chunk depth
-constexpr int kCBX = 2;                        // coordinate kernel: 16-column blocks per wave (2: 256 columns per workgroup; see edge_c8_kernel)
+#ifndef C8_CBX      // (A/B builds: tools/c8_ab2.sh)
+#define C8_CBX 4
+#endif
+#ifndef C8_VPRIO    // s_setprio of a wave in its build / in its matrix phase
+#define C8_VPRIO 3
+#endif
+#ifndef C8_MPRIO
+#define C8_MPRIO 0
+#endif
+constexpr int kCBX = C8_CBX;                        // coordinate kernel: 16-column blocks per wave (4: 512 columns per workgroup; see edge_c8_kernel)
 constexpr size_t kA1 = (size_t)8 * kR * 16;    // fp16 image of a chunk: [8 k-groups][128 rows][8 f16], rows XOR-swizzled (edge_x_m16.hip)
 // e4m3 image of a chunk: four K blocks [a_lo8 0-31 | a_hi8 0-31 | a_lo8 32-63 | a_hi8 32-63] of [128 rows][32 B], block q at
 // q * 4096 + 16 (q & 1) + 64 (q >> 1).  No swizzle: an operand read (ds_read_b128, 16-lane groups = rows 0-3 and 12-15 of block q
@@ -92,6 +101,20 @@ __device__ __forceinline__ void unit_finish_c8(const Unit& u, const float* wd, f
 }
 
 // CB = 16-column blocks per wave: the workgroup's 8 waves cover 128 CB columns (message branch: CB = 2 = all 256 columns)
+// table rows of one build unit: voffset = byte offset of the row (+ the unit's column piece), soffset = column offset of the chunk;
+// the second 16-byte piece's + 16 rides in the SCALAR offset (unit_load of kernels.h adds it to the vector offset, and hipcc then
+// keeps row + 16 in a register of its own across the K loop: four more address registers, which spilled)
+__device__ __forceinline__ void unit_load_c8(Unit& u, rsrc_t tab, unsigned vdst, unsigned vsrc, unsigned sP, unsigned sQ) {
+#ifndef C8_UNIT_SOFF   // default: the shared unit_load (+16 on the vector offset); -DC8_UNIT_SOFF = +16 on the scalar offset: measured 8 % SLOWER (profiles/r05n_c8_voff_ab.txt)
+  unit_load(u, tab, vdst, vsrc, sP, sQ);
+#else
+  u.p0 = ldbuf_f32x4(tab, vdst, sP);
+  u.p1 = ldbuf_f32x4(tab, vdst, sP + 16u);
+  u.q0 = ldbuf_f32x4(tab, vsrc, sQ);
+  u.q1 = ldbuf_f32x4(tab, vsrc, sQ + 16u);
+#endif
+}
+
 template <bool IS_M, int CB>
 __global__ __launch_bounds__(kT, 2) void edge_c8_kernel(const EdgeParams p) {
   static_assert(!IS_M || CB == 2, "the message branch is 256 columns wide");
@@ -114,17 +137,44 @@ __global__ __launch_bounds__(kT, 2) void edge_c8_kernel(const EdgeParams p) {
 
   DIAG_STAMP_SETUP(p.stamps + ((size_t)(IS_M ? 1 : 0) * 8 + wave) * 32 * 4);   // tools/stamps.py (diagnostic build only)
   DIAG_STAMP(30, 0);   // kernel entry
-  prologue_rows(p, L, e0, nvalid, IS_M ? p.wdm : p.wdx, KP, s_wd, tid);
-  DIAG_STAMP(30, 1);   // edge rows and geometry ready
 
-  // ---- K loop ----
+  // ---- weight streams ----
   const int NC = KP / kKC, KS = KP / 32;
   const int brow = tid >> 3, kg = tid & 7;   // this thread builds rows brow and brow + 64, hidden units 8 kg .. 8 kg + 7 of a chunk
-  const rsrc_t rs_tab = make_rsrc(p.table, diag::drop_table_loads(p.dbg) ? 0u : (unsigned)min((size_t)p.N * p.TC * 4, (size_t)0xFFFFFFFFu));
   const size_t ncols = IS_M ? (size_t)p.MP : (size_t)p.WxP;
   const unsigned wbytes = diag::drop_weight_loads(p.dbg) ? 0u : (unsigned)(ncols * KP * 2);
   const rsrc_t rs_w = make_rsrc(IS_M ? p.w2m16 : p.w2x16, wbytes);    // fp16 fragments [N/16][K/32][64][8]
   const rsrc_t rs_w8 = make_rsrc(IS_M ? p.w2m_c8 : p.w2x_c8, wbytes);   // e4m3 fragments [N/16][K/64][2][64][16 B]
+  const unsigned lane16 = lane * 16u;
+  const int cb0 = IS_M ? wave * CB : half * (8 * CB) + wave * CB;   // first 16-column block of this wave
+  const unsigned w0 = (unsigned)cb0 * KS * 1024u;              // fp16 stream: 1 KiB per (column block, k-step)
+  const unsigned w80 = (unsigned)cb0 * NC * 2048u;             // e4m3 stream: 2 KiB per (column block, chunk)
+  auto ld16 = [&](const int c, const int s, const int cb) {   // fp16 fragment of (chunk c, k-step s, column block cb)
+    return ldbuf_v8<f16x8>(rs_w, lane16, w0 + ((unsigned)cb * KS + (unsigned)(2 * c + s)) * 1024u);
+  };
+  auto ld8 = [&](const int c, const int cb) {                 // e4m3 fragment (32 bytes per lane) of (chunk c, column block cb)
+    const unsigned o = w80 + ((unsigned)cb * NC + (unsigned)c) * 2048u;
+    const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rs_w8, lane16, __builtin_amdgcn_readfirstlane(o), 0);
+    const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rs_w8, lane16, __builtin_amdgcn_readfirstlane(o + 1024u), 0);
+    return i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+  };
+  // 2 column blocks: two register sets, set c & 1 for chunk c (a whole chunk of request distance); 4 column blocks: one set
+  constexpr int NSET = CB == 2 ? 2 : 1;
+  f16x8 bq[NSET][2][CB];   // [set][k-step][column block] fp16
+  i32x8 b8[NSET][CB];      // [set][column block] e4m3
+  prologue_rows(p, L, e0, nvalid, IS_M ? p.wdm : p.wdx, KP, s_wd, tid);
+  DIAG_STAMP(30, 1);   // edge rows and geometry ready
+  // the first chunk's fragments (requested here, behind the row prologue: at kernel entry they were 1.5 % SLOWER in the A/B of
+  // profiles/r05p_c8_entry_ab.txt)
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) bq[0][0][cb] = ld16(0, 0, cb);
+  if constexpr (CB == 2) {
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) { bq[0][1][cb] = ld16(0, 1, cb); b8[0][cb] = ld8(0, cb); }
+  }
+
+  // ---- K loop ----
+  const rsrc_t rs_tab = make_rsrc(p.table, diag::drop_table_loads(p.dbg) ? 0u : (unsigned)min((size_t)p.N * p.TC * 4, (size_t)0xFFFFFFFFu));
   const unsigned vdst0 = (unsigned)L.dst[brow] * (unsigned)p.TC * 4u + (unsigned)kg * 32u;
   const unsigned vsrc0 = (unsigned)L.src[brow] * (unsigned)p.TC * 4u + (unsigned)kg * 32u;
   const unsigned vdst1 = (unsigned)L.dst[brow + 64] * (unsigned)p.TC * 4u + (unsigned)kg * 32u;
@@ -135,15 +185,11 @@ __global__ __launch_bounds__(kT, 2) void edge_c8_kernel(const EdgeParams p) {
   // e4m3 image: hidden units 8 kg .. + 7 sit in K block 2 (kg >> 2) (remainder) / + 1 (value), bytes 8 (kg & 3) .. + 7 of the row
   char* slo0 = s_c8 + (size_t)(kg >> 2) * (c8_block(2) - c8_block(0)) + (size_t)brow * 32 + (size_t)(kg & 3) * 8;
   constexpr int shi_delta = (int)(c8_block(1) - c8_block(0));   // the value slot: same place in the next block
-  const unsigned lane16 = lane * 16u;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)s_a1;
   const unsigned abase0 = lds0 + (unsigned)q4 * (kR * 16) + (unsigned)(r15 ^ q4) * 16u;
   const unsigned abase1 = lds0 + (unsigned)(4 + q4) * (kR * 16) + (unsigned)(r15 ^ (4 + q4)) * 16u;
   const unsigned lds8 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)s_c8;
   const unsigned cbase = lds8 + (unsigned)q4 * 4096u + 16u * (unsigned)(q4 & 1) + 64u * (unsigned)(q4 >> 1) + (unsigned)r15 * 32u;   // c8_block(q4): this lane's 32 operand bytes of row block 0
-  const int cb0 = IS_M ? wave * CB : half * (8 * CB) + wave * CB;   // first 16-column block of this wave
-  const unsigned w0 = (unsigned)cb0 * KS * 1024u;              // fp16 stream: 1 KiB per (column block, k-step)
-  const unsigned w80 = (unsigned)cb0 * NC * 2048u;             // e4m3 stream: 2 KiB per (column block, chunk)
   // block scales (e8m0, byte 0 of the scale operands): the hardware applies scale_a(row, block) * scale_b(column, block), and the
   // two kinds of block need the same product -- even blocks a_lo8 x W_hi8: 2^-12 x 2^-s_hi, odd blocks a_hi8 x W_lo8: 2^-1 x
   // 2^-(s_hi + 11) -- so both operands take ONE wave-uniform scale: a literal and a scalar register, no vector registers
@@ -160,320 +206,242 @@ __global__ __launch_bounds__(kT, 2) void edge_c8_kernel(const EdgeParams p) {
   auto vload = [&](const int cq) {   // fp32 table rows for the activations of chunk cq (clamped: a harmless repeat at the end)
     const int c = cq < NC ? cq : NC - 1;
     const unsigned kb = (unsigned)c * kKC * 4u;
-    unit_load(ua0, rs_tab, vdst0, vsrc0, offP + kb, offQ + kb);
-    unit_load(ua1, rs_tab, vdst1, vsrc1, offP + kb, offQ + kb);
+    unit_load_c8(ua0, rs_tab, vdst0, vsrc0, offP + kb, offQ + kb);
+    unit_load_c8(ua1, rs_tab, vdst1, vsrc1, offP + kb, offQ + kb);
   };
-  // weight fragments: two register sets each, set c & 1 for chunk c; the sets of chunk c + 1 are requested at the start of the
-  // matrix phase of chunk c (a whole chunk of distance, as edge_x_m16.hip)
-  f16x8 bq[2][2][CB];   // [set][k-step][column block] fp16
-  i32x8 b8[2][CB];      // [set][column block] e4m3 (32 bytes per lane)
-  auto wload = [&](auto par_c, const int cq) {
-    constexpr int PAR = decltype(par_c)::value;
-    const int c = cq < NC ? cq : NC - 1;   // past the end: a harmless repeat
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb) bq[PAR][s][cb] = ldbuf_v8<f16x8>(rs_w, lane16, w0 + ((unsigned)cb * KS + (unsigned)(2 * c + s)) * 1024u);
-#pragma unroll
-    for (int cb = 0; cb < CB; ++cb) {
-      const unsigned o = w80 + ((unsigned)cb * NC + (unsigned)c) * 2048u;
-      const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rs_w8, lane16, __builtin_amdgcn_readfirstlane(o), 0);
-      const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rs_w8, lane16, __builtin_amdgcn_readfirstlane(o + 1024u), 0);
-      b8[PAR][cb] = i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
-    }
-  };
-  // SiLU + operand forms of chunk c into LDS buffer PAR = c & 1 (a compile-time parity: the loop below is unrolled by two so
-  // that every LDS address of the K loop is a per-thread base + an immediate)
-  auto vfinish = [&](auto par_c, const int c) {
-    constexpr int PAR = decltype(par_c)::value;
-    if constexpr (diag::kC8NoBuild) { if (c > 1) { asm volatile("" :: "v"(ua0.p0), "v"(ua0.p1), "v"(ua0.q0), "v"(ua0.q1), "v"(ua1.p0), "v"(ua1.p1), "v"(ua1.q0), "v"(ua1.q1)); return; } }
-    __builtin_amdgcn_s_setprio(3);   // vector work wins issue arbitration over the partner wave's MFMAs
-    unit_finish_c8(ua0, s_wd + c * kKC + kg * 8, L.d2[brow], slot0 + PAR * kA1, slo0 + PAR * kC8, slo0 + PAR * kC8 + shi_delta);
-    unit_finish_c8(ua1, s_wd + c * kKC + kg * 8, L.d2[brow + 64], slot0 + PAR * kA1 + 64 * 16, slo0 + PAR * kC8 + 64 * 32,
-                   slo0 + PAR * kC8 + 64 * 32 + shi_delta);
-    __builtin_amdgcn_s_setprio(0);
+  // SiLU + operand forms of one row of chunk c into LDS buffer PAR = c & 1 (a compile-time parity: the K loops below are
+  // unrolled by two so that every LDS address is a per-thread base + an immediate)
+  auto vrow = [&](auto par_c, auto row_c, const int c) {
+    constexpr int PAR = decltype(par_c)::value, ROW = decltype(row_c)::value;
+    unit_finish_c8(ROW ? ua1 : ua0, s_wd + c * kKC + kg * 8, L.d2[brow + 64 * ROW], slot0 + PAR * kA1 + ROW * 64 * 16,
+                   slo0 + PAR * kC8 + ROW * 64 * 32, slo0 + PAR * kC8 + ROW * 64 * 32 + shi_delta);
   };
   const std::integral_constant<int, 0> P0;
   const std::integral_constant<int, 1> P1;
+  int S = 0;   // segments of the tile
 
-  // chunk 0: table rows and the first weight fragments are requested, then the segment structure is worked out while they fly
-  vload(0);
-  wload(P0, 0);
-  const int S = prologue_segments<false>(p, L, e0, nvalid, tid, lane, wave);
-  vfinish(P0, 0);
-  vload(1);
-  __syncthreads();
-  DIAG_STAMP(30, 2);   // chunk 0 built, first weights requested
-  DIAG_RSTAMP(31, 1);
-
-  // matrix phase of chunk c (LDS buffer and weight set PAR):  the weights of chunk c + 1 are requested first, then 2 fp16
-  // k-steps x (8 row blocks x CB), then the correction: 8 row blocks x CB scaled e4m3 MFMAs.  Operand pipelines as in
-  // edge_x_m16.hip (inline-asm ds_read_b128, counted lgkmcnt): a ring of 3 fp16 pieces, then a ring of 2 x 32-byte e4m3 operands
-  // (a lane's 32 bytes are contiguous in the image).
-  auto mphase = [&](auto par_c, auto npar_c, const int c, const bool last) {
-    constexpr int PAR = decltype(par_c)::value;
-    constexpr int kO16 = PAR * (int)kA1, kO8 = PAR * (int)kC8;
-    // One operand pipeline through both parts of the phase (LDS returns in order; every wait below counts the reads issued AFTER
-    // the one it needs).  At 2 column blocks per wave an fp16 piece feeds 32 cycles of MFMAs and an e4m3 operand 64, so the reads
-    // (a scheduling barrier behind every group of MFMAs: hipcc otherwise sinks the MFMA builtins past the volatile asm that
-    // follows -- the waits then run back to back and the matrix work behind them, and accumulators get renamed and spilled)
-    // run 8 pieces / 4 operands = 256 cycles ahead of their use (the first build's rings of 3 / 2, copied from the 4-column-block
-    // kernel, left the matrix phase waiting on LDS: 4.0 ms of a 5.0 ms kernel with the whole build compiled out,
-    // profiles/r05e_c8_decomposition.txt); the first e4m3 operands are requested under the last fp16 MFMAs.
-    f16x8 a[8];
-    u32x4 c0[4], c1[4];
+  // ---- the operand pipeline of a matrix phase, shared by both schedules (bodies generated: tools/gen/gen_c8_mphase.py) ----
+  // LDS returns in order and every wait counts the reads issued AFTER the one it needs.  A scheduling barrier sits behind every
+  // group of MFMAs: hipcc otherwise sinks the MFMA builtins past the volatile asm that follows -- the waits then run back to
+  // back with the matrix work behind them, accumulators get renamed and the K loop spills.
 #define LDS_RD(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(off))
 #define LDS_WAIT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
-    LDS_RD(a[0], abase0, kO16 + 0); LDS_RD(a[1], abase0, kO16 + 256); LDS_RD(a[2], abase0, kO16 + 512); LDS_RD(a[3], abase0, kO16 + 768);
-    LDS_RD(a[4], abase0, kO16 + 1024); LDS_RD(a[5], abase0, kO16 + 1280); LDS_RD(a[6], abase0, kO16 + 1536); LDS_RD(a[7], abase0, kO16 + 1792);
-    if (!last) wload(npar_c, c + 1);
-    LDS_WAIT(7);
-    asm volatile("" : "+v"(a[0]));
-    if constexpr (!diag::kC8NoMain) {
+#define MAIN_STEP(A, KSTEP, RB)                                                                                          \
+  do {                                                                                                                   \
+    asm volatile("" : "+v"(A)); /* uses of the piece stay below the wait */                                              \
+    if constexpr (!diag::kC8NoMain) {                                                                                    \
+      _Pragma("unroll") for (int cb = 0; cb < CB; ++cb)                                                                  \
+          acc[RB][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, BQ(KSTEP)[cb], acc[RB][cb], 0, 0, 0);                  \
+    } else {                                                                                                             \
+      asm volatile("" ::"v"(BQ(KSTEP)[0]), "v"(BQ(KSTEP)[CB - 1]));                                                      \
+    }                                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  } while (0)
+#define CORR_STEP(C0, C1, RB)                                                                                            \
+  do {                                                                                                                   \
+    if constexpr (!diag::kC8NoCorr) {                                                                                    \
+      asm volatile("" : "+v"(C0), "+v"(C1));                                                                             \
+      const u32x4 x0_ = C0, x1_ = C1;                                                                                    \
+      const i32x8 a8_ = {(int)x0_.x, (int)x0_.y, (int)x0_.z, (int)x0_.w, (int)x1_.x, (int)x1_.y, (int)x1_.z, (int)x1_.w}; \
+      _Pragma("unroll") for (int cb = 0; cb < CB; ++cb)                                                                  \
+          acc[RB][cb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8_, B8[cb], acc[RB][cb], 0, 0, 0, kScaleA, 0, scale_b); \
+    } else {                                                                                                             \
+      asm volatile("" ::"v"(B8[0]), "v"(B8[CB - 1]));                                                                    \
+    }                                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  } while (0)
+
+  if constexpr (CB == 2) {
+    // ================= 2 column blocks per wave (256 columns per workgroup): the registers allow a whole chunk of request
+    // distance for everything, as in edge_x_m16.hip =================
+    // weight fragments: two register sets, set c & 1 for chunk c; the set of chunk c + 1 is requested at the start of the matrix
+    // phase of chunk c; the table rows of a build right behind the previous build.  An fp16 piece feeds only 32 cycles of MFMAs
+    // here and an e4m3 operand 64, so the operand reads run 8 pieces / 4 operands (256 cycles) ahead of their use.
+    auto wload = [&](auto par_c, const int cq) {
+      constexpr int PAR = decltype(par_c)::value;
+      const int c = cq < NC ? cq : NC - 1;   // past the end: a harmless repeat
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb) acc[0][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], bq[PAR][0][cb], acc[0][cb], 0, 0, 0);
-    } else { asm volatile("" :: "v"(bq[PAR][0][0]), "v"(bq[PAR][0][1])); }
-    __builtin_amdgcn_sched_barrier(0);
-    LDS_RD(a[0], abase1, kO16 + 0);
-    LDS_WAIT(7);
-    asm volatile("" : "+v"(a[1]));
-    if constexpr (!diag::kC8NoMain) {
+      for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb) acc[1][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], bq[PAR][0][cb], acc[1][cb], 0, 0, 0);
-    } else { asm volatile("" :: "v"(bq[PAR][0][0]), "v"(bq[PAR][0][1])); }
-    __builtin_amdgcn_sched_barrier(0);
-    LDS_RD(a[1], abase1, kO16 + 256);
-    LDS_WAIT(7);
-    asm volatile("" : "+v"(a[2]));
-    if constexpr (!diag::kC8NoMain) {
+        for (int cb = 0; cb < CB; ++cb) bq[PAR][s][cb] = ld16(c, s, cb);
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb) acc[2][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[2], bq[PAR][0][cb], acc[2][cb], 0, 0, 0);
-    } else { asm volatile("" :: "v"(bq[PAR][0][0]), "v"(bq[PAR][0][1])); }
-    __builtin_amdgcn_sched_barrier(0);
-    LDS_RD(a[2], abase1, kO16 + 512);
-    LDS_WAIT(7);
-    asm volatile("" : "+v"(a[3]));
-    if constexpr (!diag::kC8NoMain) {
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb) acc[3][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[3], bq[PAR][0][cb], acc[3][cb], 0, 0, 0);
-    } else { asm volatile("" :: "v"(bq[PAR][0][0]), "v"(bq[PAR][0][1])); }
-    __builtin_amdgcn_sched_barrier(0);
-    LDS_RD(a[3], abase1, kO16 + 768);
-    LDS_WAIT(7);
-    asm volatile("" : "+v"(a[4]));
-    if constexpr (!diag::kC8NoMain) {
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb) acc[4][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[4], bq[PAR][0][cb], acc[4][cb], 0, 0, 0);
-    } else { asm volatile("" :: "v"(bq[PAR][0][0]), "v"(bq[PAR][0][1])); }
-    __builtin_amdgcn_sched_barrier(0);
-    LDS_RD(a[4], abase1, kO16 + 1024);
-    LDS_WAIT(7);
-    asm volatile("" : "+v"(a[5]));
-    if constexpr (!diag::kC8NoMain) {
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb) acc[5][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[5], bq[PAR][0][cb], acc[5][cb], 0, 0, 0);
-    } else { asm volatile("" :: "v"(bq[PAR][0][0]), "v"(bq[PAR][0][1])); }
-    __builtin_amdgcn_sched_barrier(0);
-    LDS_RD(a[5], abase1, kO16 + 1280);
-    LDS_WAIT(7);
-    asm volatile("" : "+v"(a[6]));
-    if constexpr (!diag::kC8NoMain) {
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb) acc[6][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[6], bq[PAR][0][cb], acc[6][cb], 0, 0, 0);
-    } else { asm volatile("" :: "v"(bq[PAR][0][0]), "v"(bq[PAR][0][1])); }
-    __builtin_amdgcn_sched_barrier(0);
-    LDS_RD(a[6], abase1, kO16 + 1536);
-    LDS_WAIT(7);
-    asm volatile("" : "+v"(a[7]));
-    if constexpr (!diag::kC8NoMain) {
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb) acc[7][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[7], bq[PAR][0][cb], acc[7][cb], 0, 0, 0);
-    } else { asm volatile("" :: "v"(bq[PAR][0][0]), "v"(bq[PAR][0][1])); }
-    __builtin_amdgcn_sched_barrier(0);
-    LDS_RD(a[7], abase1, kO16 + 1792);
-    LDS_WAIT(7);
-    asm volatile("" : "+v"(a[0]));
-    if constexpr (!diag::kC8NoMain) {
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb) acc[0][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], bq[PAR][1][cb], acc[0][cb], 0, 0, 0);
-    } else { asm volatile("" :: "v"(bq[PAR][1][0]), "v"(bq[PAR][1][1])); }
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (!diag::kC8NoCorr) { LDS_RD(c0[0], cbase, kO8 + 0); LDS_RD(c1[0], cbase, kO8 + 16); }
-    LDS_WAIT(8);
-    asm volatile("" : "+v"(a[1]));
-    if constexpr (!diag::kC8NoMain) {
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb) acc[1][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], bq[PAR][1][cb], acc[1][cb], 0, 0, 0);
-    } else { asm volatile("" :: "v"(bq[PAR][1][0]), "v"(bq[PAR][1][1])); }
-    __builtin_amdgcn_sched_barrier(0);
-    LDS_WAIT(7);
-    asm volatile("" : "+v"(a[2]));
-    if constexpr (!diag::kC8NoMain) {
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb) acc[2][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[2], bq[PAR][1][cb], acc[2][cb], 0, 0, 0);
-    } else { asm volatile("" :: "v"(bq[PAR][1][0]), "v"(bq[PAR][1][1])); }
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (!diag::kC8NoCorr) { LDS_RD(c0[1], cbase, kO8 + 512); LDS_RD(c1[1], cbase, kO8 + 528); }
-    LDS_WAIT(8);
-    asm volatile("" : "+v"(a[3]));
-    if constexpr (!diag::kC8NoMain) {
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb) acc[3][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[3], bq[PAR][1][cb], acc[3][cb], 0, 0, 0);
-    } else { asm volatile("" :: "v"(bq[PAR][1][0]), "v"(bq[PAR][1][1])); }
-    __builtin_amdgcn_sched_barrier(0);
-    LDS_WAIT(7);
-    asm volatile("" : "+v"(a[4]));
-    if constexpr (!diag::kC8NoMain) {
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb) acc[4][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[4], bq[PAR][1][cb], acc[4][cb], 0, 0, 0);
-    } else { asm volatile("" :: "v"(bq[PAR][1][0]), "v"(bq[PAR][1][1])); }
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (!diag::kC8NoCorr) { LDS_RD(c0[2], cbase, kO8 + 1024); LDS_RD(c1[2], cbase, kO8 + 1040); }
-    LDS_WAIT(8);
-    asm volatile("" : "+v"(a[5]));
-    if constexpr (!diag::kC8NoMain) {
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb) acc[5][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[5], bq[PAR][1][cb], acc[5][cb], 0, 0, 0);
-    } else { asm volatile("" :: "v"(bq[PAR][1][0]), "v"(bq[PAR][1][1])); }
-    __builtin_amdgcn_sched_barrier(0);
-    LDS_WAIT(7);
-    asm volatile("" : "+v"(a[6]));
-    if constexpr (!diag::kC8NoMain) {
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb) acc[6][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[6], bq[PAR][1][cb], acc[6][cb], 0, 0, 0);
-    } else { asm volatile("" :: "v"(bq[PAR][1][0]), "v"(bq[PAR][1][1])); }
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (!diag::kC8NoCorr) { LDS_RD(c0[3], cbase, kO8 + 1536); LDS_RD(c1[3], cbase, kO8 + 1552); }
-    LDS_WAIT(8);
-    asm volatile("" : "+v"(a[7]));
-    if constexpr (!diag::kC8NoMain) {
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb) acc[7][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[7], bq[PAR][1][cb], acc[7][cb], 0, 0, 0);
-    } else { asm volatile("" :: "v"(bq[PAR][1][0]), "v"(bq[PAR][1][1])); }
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (diag::kC8NoCorr) { asm volatile("" :: "v"(b8[PAR][0]), "v"(b8[PAR][1])); } else {
-    LDS_WAIT(6);
-    asm volatile("" : "+v"(c0[0]), "+v"(c1[0]));
-    {
-      const u32x4 x0 = c0[0], x1 = c1[0];
-      const i32x8 a8 = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb)
-        acc[0][cb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8[PAR][cb], acc[0][cb], 0, 0, 0, kScaleA, 0, scale_b);
+      for (int cb = 0; cb < CB; ++cb) b8[PAR][cb] = ld8(c, cb);
+    };
+    auto vfinish = [&](auto par_c, const int c) {
+      if constexpr (diag::kC8NoBuild) { if (c > 1) { asm volatile("" :: "v"(ua0.p0), "v"(ua0.p1), "v"(ua0.q0), "v"(ua0.q1), "v"(ua1.p0), "v"(ua1.p1), "v"(ua1.q0), "v"(ua1.q1)); return; } }
+      __builtin_amdgcn_s_setprio(C8_VPRIO);   // vector work wins issue arbitration over the partner wave's MFMAs
+      vrow(par_c, P0, c);
+      vrow(par_c, P1, c);
+      __builtin_amdgcn_s_setprio(C8_MPRIO);
+    };
+    // chunk 0: table rows requested (the first weight fragments already are), then the segment structure is worked out while they fly
+    vload(0);
+    S = prologue_segments<false>(p, L, e0, nvalid, tid, lane, wave);
+    vfinish(P0, 0);
+    vload(1);
+    __syncthreads();
+    DIAG_STAMP(30, 2);   // chunk 0 built, first weights requested
+    DIAG_RSTAMP(31, 1);
+    auto mphase = [&](auto par_c, auto npar_c, const int c, const bool last) {
+      constexpr int PAR = decltype(par_c)::value;
+      constexpr int kO16 = PAR * (int)kA1, kO8 = PAR * (int)kC8;
+      f16x8 a[8];
+      u32x4 c0[4], c1[4];
+#define BQ(s) bq[PAR][s]
+#define B8 b8[PAR]
+#define MPHASE_AFTER_FIRST_READS if (!last) wload(npar_c, c + 1)
+#define MPHASE_AFTER_KSTEP0
+#define MPHASE_AFTER_KSTEP1
+#include "edge_f16c8_mphase2.inc"
+#undef MPHASE_AFTER_KSTEP1
+#undef MPHASE_AFTER_KSTEP0
+#undef MPHASE_AFTER_FIRST_READS
+#undef B8
+#undef BQ
+    };
+    // SIMD partners (waves w and w + 4) in opposite phase, one barrier per chunk (edge_x_m16.hip); two chunks per loop iteration
+    // (NC is even: edge_f16c8_supported)
+    if (wave < 4) {   // multiply chunk i, then build chunk i + 1 and request the table rows of chunk i + 2
+      const int my_mode = tid < S ? segment_mode(p, L, e0, tid) : 0;   // row_ptr loads of the segment modes: under the first matrix phase
+      DIAG_STAMP(0, 0);
+      mphase(P0, P1, 0, false);
+      DIAG_STAMP(0, 1);
+      if (tid < S) L.seg_mode[tid] = my_mode;
+      vfinish(P1, 1); vload(2);
+      DIAG_STAMP(0, 2);
+      __syncthreads();
+      DIAG_STAMP(0, 3);
+      for (int i = 1; i + 1 < NC - 1; i += 2) {
+        DIAG_STAMP(i, 0); mphase(P1, P0, i, false); DIAG_STAMP(i, 1); vfinish(P0, i + 1); vload(i + 2); DIAG_STAMP(i, 2); __syncthreads(); DIAG_STAMP(i, 3);
+        DIAG_STAMP(i + 1, 0); mphase(P0, P1, i + 1, false); DIAG_STAMP(i + 1, 1); vfinish(P1, i + 2); vload(i + 3); DIAG_STAMP(i + 1, 2); __syncthreads(); DIAG_STAMP(i + 1, 3);
+      }
+    } else {          // build chunk i + 1 first, then multiply chunk i
+      DIAG_STAMP(0, 0);
+      vfinish(P1, 1); vload(2);
+      DIAG_STAMP(0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mphase(P0, P1, 0, false);
+      DIAG_STAMP(0, 2);
+      __syncthreads();
+      DIAG_STAMP(0, 3);
+      for (int i = 1; i + 1 < NC - 1; i += 2) {
+        DIAG_STAMP(i, 0); vfinish(P0, i + 1); vload(i + 2); DIAG_STAMP(i, 1); __builtin_amdgcn_sched_barrier(0); mphase(P1, P0, i, false); DIAG_STAMP(i, 2); __syncthreads(); DIAG_STAMP(i, 3);
+        DIAG_STAMP(i + 1, 0); vfinish(P1, i + 2); vload(i + 3); DIAG_STAMP(i + 1, 1); __builtin_amdgcn_sched_barrier(0); mphase(P0, P1, i + 1, false); DIAG_STAMP(i + 1, 2); __syncthreads(); DIAG_STAMP(i + 1, 3);
+      }
     }
-    __builtin_amdgcn_sched_barrier(0);
-    LDS_RD(c0[0], cbase, kO8 + 2048); LDS_RD(c1[0], cbase, kO8 + 2064);
-    LDS_WAIT(6);
-    asm volatile("" : "+v"(c0[1]), "+v"(c1[1]));
-    {
-      const u32x4 x0 = c0[1], x1 = c1[1];
-      const i32x8 a8 = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
+    DIAG_STAMP(NC - 1, 0);
+    mphase(P1, P0, NC - 1, true);
+    DIAG_STAMP(NC - 1, 1);
+  } else {
+    // ================= 4 column blocks per wave (512 columns per workgroup: the mlp_x activations are built twice per tile
+    // instead of four times) =================
+    // 128 accumulator registers leave 128 for everything else -- fp16 fragments (2 k-steps x 16), e4m3 fragments (32), fp32 table
+    // rows (2 x 16), operand rings (12 / 16), a row's build temporaries (~30), addresses (~14) -- and hipcc needs ~40 of slack or
+    // it spills inside the K loop.  So every operand group is requested as LATE as its latency allows, and no two 32-register
+    // groups are ever live together:
+    //   fp16 fragments, k-step 1 of chunk c      at the start of its matrix phase (used 512 cycles later)
+    //   e4m3 fragments of chunk c                behind its first fp16 k-step (used 512 cycles later)
+    //   table rows of the next build: row 0      behind the second fp16 k-step (used 1,024 cycles later); row 1 at the start of
+    //                                            the build (used behind row 0's arithmetic)
+    //   fp16 fragments, k-step 0 of the next matrix phase: between the two rows of the build in front of it
+    // and the build finishes its two rows one after the other (scheduling barriers): one row's temporaries are live at a time.
+    auto wload16 = [&](const int cq, const int s) {
+      const int c = cq < NC ? cq : NC - 1;
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb)
-        acc[1][cb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8[PAR][cb], acc[1][cb], 0, 0, 0, kScaleA, 0, scale_b);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    LDS_RD(c0[1], cbase, kO8 + 2560); LDS_RD(c1[1], cbase, kO8 + 2576);
-    LDS_WAIT(6);
-    asm volatile("" : "+v"(c0[2]), "+v"(c1[2]));
-    {
-      const u32x4 x0 = c0[2], x1 = c1[2];
-      const i32x8 a8 = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
+      for (int cb = 0; cb < CB; ++cb) bq[0][s][cb] = ld16(c, s, cb);
+    };
+    auto wload8 = [&](const int c) {
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb)
-        acc[2][cb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8[PAR][cb], acc[2][cb], 0, 0, 0, kScaleA, 0, scale_b);
+      for (int cb = 0; cb < CB; ++cb) b8[0][cb] = ld8(c, cb);
+    };
+    auto vload0 = [&](const int cq) {
+      const int c = cq < NC ? cq : NC - 1;
+      unit_load_c8(ua0, rs_tab, vdst0, vsrc0, offP + (unsigned)c * kKC * 4u, offQ + (unsigned)c * kKC * 4u);
+    };
+    auto vload1 = [&](const int cq) {
+      const int c = cq < NC ? cq : NC - 1;
+      unit_load_c8(ua1, rs_tab, vdst1, vsrc1, offP + (unsigned)c * kKC * 4u, offQ + (unsigned)c * kKC * 4u);
+    };
+    // build of chunk c (row 0's table rows were requested by the matrix phase in front of it); mchunk: the chunk of the NEXT matrix
+    // phase of this wave, whose k-step-0 fragments are requested between the rows
+    auto vfinish = [&](auto par_c, const int c, const int mchunk) {
+      __builtin_amdgcn_s_setprio(C8_VPRIO);
+      vload1(c);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(diag::kC8NoBuild && c > 1)) vrow(par_c, P0, c);
+      else asm volatile("" :: "v"(ua0.p0), "v"(ua0.p1), "v"(ua0.q0), "v"(ua0.q1));
+      __builtin_amdgcn_sched_barrier(0);
+      DIAG_STAMP2(c + 15, 3, c >= 1 && c < 15);   // row 0 done (slot of chunk c - 1's matrix phase: c + 15)
+      if (mchunk >= 0) wload16(mchunk, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(diag::kC8NoBuild && c > 1)) vrow(par_c, P1, c);
+      else asm volatile("" :: "v"(ua1.p0), "v"(ua1.p1), "v"(ua1.q0), "v"(ua1.q1));
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(C8_MPRIO);
+    };
+    vload0(0);
+    S = prologue_segments<false>(p, L, e0, nvalid, tid, lane, wave);
+    vfinish(P0, 0, -1);         // chunk 0 (its k-step-0 fragments were requested behind the row prologue)
+    if (wave >= 4) vload0(1);   // waves 4-7 build chunk 1 first thing in the loop
+    __syncthreads();
+    DIAG_STAMP(30, 2);
+    DIAG_RSTAMP(31, 1);
+    // tab_chunk: chunk whose row-0 table rows are requested behind the second k-step (-1: none)
+    auto mphase = [&](auto par_c, const int c, const int tab_chunk) {
+      constexpr int PAR = decltype(par_c)::value;
+      constexpr int kO16 = PAR * (int)kA1, kO8 = PAR * (int)kC8;
+      f16x8 a[3];
+      u32x4 c0[2], c1[2];
+#define BQ(s) bq[0][s]
+#define B8 b8[0]
+#define MPHASE_AFTER_FIRST_READS do { __builtin_amdgcn_sched_barrier(0); wload16(c, 1); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define MPHASE_AFTER_KSTEP0 do { DIAG_STAMP2(c + 16, 0, c < 14); wload8(c); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define MPHASE_AFTER_KSTEP1 do { DIAG_STAMP2(c + 16, 1, c < 14); if (tab_chunk >= 0) vload0(tab_chunk); __builtin_amdgcn_sched_barrier(0); } while (0)
+#include "edge_f16c8_mphase4.inc"
+      DIAG_STAMP2(c + 16, 2, c < 14);
+#undef MPHASE_AFTER_KSTEP1
+#undef MPHASE_AFTER_KSTEP0
+#undef MPHASE_AFTER_FIRST_READS
+#undef B8
+#undef BQ
+    };
+    if (wave < 4) {   // multiply chunk i, then build chunk i + 1
+      const int my_mode = tid < S ? segment_mode(p, L, e0, tid) : 0;
+      DIAG_STAMP(0, 0);
+      mphase(P0, 0, 1);
+      DIAG_STAMP(0, 1);
+      if (tid < S) L.seg_mode[tid] = my_mode;
+      vfinish(P1, 1, 1);
+      DIAG_STAMP(0, 2);
+      __syncthreads();
+      DIAG_STAMP(0, 3);
+      for (int i = 1; i + 1 < NC - 1; i += 2) {
+        DIAG_STAMP(i, 0); mphase(P1, i, i + 1); DIAG_STAMP(i, 1); vfinish(P0, i + 1, i + 1); DIAG_STAMP(i, 2); __syncthreads(); DIAG_STAMP(i, 3);
+        DIAG_STAMP(i + 1, 0); mphase(P0, i + 1, i + 2); DIAG_STAMP(i + 1, 1); vfinish(P1, i + 2, i + 2); DIAG_STAMP(i + 1, 2); __syncthreads(); DIAG_STAMP(i + 1, 3);
+      }
+    } else {          // build chunk i + 1, then multiply chunk i
+      DIAG_STAMP(0, 0);
+      vfinish(P1, 1, 0);
+      DIAG_STAMP(0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mphase(P0, 0, 2);
+      DIAG_STAMP(0, 2);
+      __syncthreads();
+      DIAG_STAMP(0, 3);
+      for (int i = 1; i + 1 < NC - 1; i += 2) {
+        DIAG_STAMP(i, 0); vfinish(P0, i + 1, i); DIAG_STAMP(i, 1); __builtin_amdgcn_sched_barrier(0); mphase(P1, i, i + 2); DIAG_STAMP(i, 2); __syncthreads(); DIAG_STAMP(i, 3);
+        DIAG_STAMP(i + 1, 0); vfinish(P1, i + 2, i + 1); DIAG_STAMP(i + 1, 1); __builtin_amdgcn_sched_barrier(0); mphase(P0, i + 1, i + 3); DIAG_STAMP(i + 1, 2); __syncthreads(); DIAG_STAMP(i + 1, 3);
+      }
+      wload16(NC - 1, 0);   // the last matrix phase has no build in front of it
     }
-    __builtin_amdgcn_sched_barrier(0);
-    LDS_RD(c0[2], cbase, kO8 + 3072); LDS_RD(c1[2], cbase, kO8 + 3088);
-    LDS_WAIT(6);
-    asm volatile("" : "+v"(c0[3]), "+v"(c1[3]));
-    {
-      const u32x4 x0 = c0[3], x1 = c1[3];
-      const i32x8 a8 = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb)
-        acc[3][cb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8[PAR][cb], acc[3][cb], 0, 0, 0, kScaleA, 0, scale_b);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    LDS_RD(c0[3], cbase, kO8 + 3584); LDS_RD(c1[3], cbase, kO8 + 3600);
-    LDS_WAIT(6);
-    asm volatile("" : "+v"(c0[0]), "+v"(c1[0]));
-    {
-      const u32x4 x0 = c0[0], x1 = c1[0];
-      const i32x8 a8 = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb)
-        acc[4][cb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8[PAR][cb], acc[4][cb], 0, 0, 0, kScaleA, 0, scale_b);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    LDS_WAIT(4);
-    asm volatile("" : "+v"(c0[1]), "+v"(c1[1]));
-    {
-      const u32x4 x0 = c0[1], x1 = c1[1];
-      const i32x8 a8 = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb)
-        acc[5][cb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8[PAR][cb], acc[5][cb], 0, 0, 0, kScaleA, 0, scale_b);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    LDS_WAIT(2);
-    asm volatile("" : "+v"(c0[2]), "+v"(c1[2]));
-    {
-      const u32x4 x0 = c0[2], x1 = c1[2];
-      const i32x8 a8 = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb)
-        acc[6][cb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8[PAR][cb], acc[6][cb], 0, 0, 0, kScaleA, 0, scale_b);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    LDS_WAIT(0);
-    asm volatile("" : "+v"(c0[3]), "+v"(c1[3]));
-    {
-      const u32x4 x0 = c0[3], x1 = c1[3];
-      const i32x8 a8 = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb)
-        acc[7][cb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8[PAR][cb], acc[7][cb], 0, 0, 0, kScaleA, 0, scale_b);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    }
+    DIAG_STAMP(NC - 1, 0);
+    mphase(P1, NC - 1, -1);
+    DIAG_STAMP(NC - 1, 1);
+  }
+#undef CORR_STEP
+#undef MAIN_STEP
 #undef LDS_WAIT
 #undef LDS_RD
-  };
-
-  // SIMD partners (waves w and w + 4) in opposite phase, one barrier per chunk (edge_x_m16.hip); two chunks per loop iteration
-  // (NC is even: edge_f16c8_supported)
-  if (wave < 4) {   // multiply chunk i, then build chunk i + 1 and request the table rows of chunk i + 2
-    const int my_mode = tid < S ? segment_mode(p, L, e0, tid) : 0;   // row_ptr loads of the segment modes: under the first matrix phase
-    DIAG_STAMP(0, 0);
-    mphase(P0, P1, 0, false);
-    DIAG_STAMP(0, 1);
-    if (tid < S) L.seg_mode[tid] = my_mode;
-    vfinish(P1, 1); vload(2);
-    DIAG_STAMP(0, 2);
-    __syncthreads();
-    DIAG_STAMP(0, 3);
-    for (int i = 1; i + 1 < NC - 1; i += 2) {
-      DIAG_STAMP(i, 0); mphase(P1, P0, i, false); DIAG_STAMP(i, 1); vfinish(P0, i + 1); vload(i + 2); DIAG_STAMP(i, 2); __syncthreads(); DIAG_STAMP(i, 3);
-      DIAG_STAMP(i + 1, 0); mphase(P0, P1, i + 1, false); DIAG_STAMP(i + 1, 1); vfinish(P1, i + 2); vload(i + 3); DIAG_STAMP(i + 1, 2); __syncthreads(); DIAG_STAMP(i + 1, 3);
-    }
-  } else {          // build chunk i + 1 first, then multiply chunk i
-    DIAG_STAMP(0, 0);
-    vfinish(P1, 1); vload(2);
-    DIAG_STAMP(0, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mphase(P0, P1, 0, false);
-    DIAG_STAMP(0, 2);
-    __syncthreads();
-    DIAG_STAMP(0, 3);
-    for (int i = 1; i + 1 < NC - 1; i += 2) {
-      DIAG_STAMP(i, 0); vfinish(P0, i + 1); vload(i + 2); DIAG_STAMP(i, 1); __builtin_amdgcn_sched_barrier(0); mphase(P1, P0, i, false); DIAG_STAMP(i, 2); __syncthreads(); DIAG_STAMP(i, 3);
-      DIAG_STAMP(i + 1, 0); vfinish(P1, i + 2); vload(i + 3); DIAG_STAMP(i + 1, 1); __builtin_amdgcn_sched_barrier(0); mphase(P0, P1, i + 1, false); DIAG_STAMP(i + 1, 2); __syncthreads(); DIAG_STAMP(i + 1, 3);
-    }
-  }
-  DIAG_STAMP(NC - 1, 0);
-  mphase(P1, P0, NC - 1, true);
-  DIAG_STAMP(NC - 1, 1);
   __syncthreads();
   DIAG_STAMP(NC - 1, 3);
   DIAG_STAMP(30, 3);   // K loop done

@@ -24,6 +24,14 @@ for k, name in enumerate(("X", "M")):
         p1, p2, bar = s[:, 1]-s[:, 0], s[:, 2]-s[:, 1], s[:, 3]-s[:, 2]
         tot = s[15, 3] - s[0, 0]
         print(f" wave {w}: phase1 {p1[1:15].mean():7.0f}  phase2 {p2[1:15].mean():7.0f}  barrier {bar[1:15].mean():7.0f}  chunk {np.diff(s[:,0])[1:14].mean():7.0f}  loop total {tot}")
+    if os.environ.get("EGNN_STAMP_FINE"):   # EGNN_EXP_STAMP2 build of edge_f16c8.hip: slots c + 16 = inside the matrix phase of chunk c
+        for w in (0, 4):
+            f = st[k, w, 16:30]
+            s0 = st[k, w, :14]
+            mstart = s0[:, 0] if w < 4 else s0[:, 1]
+            print(f" wave {w} matrix phase: k-step 0 {np.mean(f[2:12,0]-mstart[2:12]):7.0f}  k-step 1 {np.mean(f[2:12,1]-f[2:12,0]):7.0f}  correction {np.mean(f[2:12,2]-f[2:12,1]):7.0f}")
+            vstart = (s0[:, 1] if w < 4 else s0[:, 0])
+            print(f" wave {w} build: row 0 done after {np.mean(f[2:12,3]-vstart[2:12]):7.0f}")
     t = st[k, :, 30:32]
     for w in (0, 4):
         if t[w, 0, 0] == 0: continue
