@@ -140,7 +140,7 @@ def test_gradients_full_width_64_atom_graphs(first_layer, sizes, monkeypatch):
     old_chunk = _ag.EDGE_CHUNK
     _ag.EDGE_CHUNK = 5000
     try:
-        for prec in ("fp32", "bf16x3", "bf16", "fp16"):
+        for prec in ("fp32", "bf16x3", "f16c8", "bf16", "fp16"):
             m = dma.EquivariantGNN(2, **d)
             m.load_state_dict({k: v.detach() for k, v in sd.items()})
             m.to(dev).train()
@@ -152,13 +152,15 @@ def test_gradients_full_width_64_atom_graphs(first_layer, sizes, monkeypatch):
             grads[prec] = {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
             if prec in ("bf16", "fp16"):   # the form under test is the one that ran
                 assert _ag.LAST_FIRST_LAYER_FORM == {"chain": None, "factorised": "reduce", "graph": "graph"}[first_layer]
-            if prec in ("fp32", "bf16x3"):
+            if prec in ("fp32", "bf16x3", "f16c8"):
                 assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 1e-4 * abs(float(loss_ref.detach()))
                 assert rel_err(ex.detach().cpu(), ex_ref.detach()) <= 1e-4 and rel_err(eh.detach().cpu(), eh_ref.detach()) <= 1e-4
     finally:
         _ag.EDGE_CHUNK = old_chunk
-    # measured (profiles/r04d_gpu_tests.log): fp32 5.8e-6, bf16x3 2.1e-5, bf16 6.5e-3, fp16 4.2e-3 (worst parameter tensor)
-    GRAD_TOL = {"fp32": 2e-3, "bf16x3": 2e-3, "bf16": 2e-2, "fp16": 2e-2}
+    # measured (profiles/r05r_gpu_tests.log, worst parameter tensor over the four forms): fp32 6.2e-6, bf16x3 2.4e-5, f16c8 as
+    # bf16x3 (same backward), bf16 6.8e-3, fp16 4.4e-3.  Bars: north_star's 1e-4 for the fp32-grade precisions, 1.5 x the
+    # measurement for the half-precision ones (they were 3-5 x, wide enough to hide a dropped term)
+    GRAD_TOL = {"fp32": 1e-4, "bf16x3": 1e-4, "f16c8": 1e-4, "bf16": 1.0e-2, "fp16": 6.5e-3}
     for prec, gr in grads.items():
         errs = {k: rel_err(gr[k], sd[k].grad) for k in gr}
         worst = max(errs, key=errs.get)
@@ -608,7 +610,8 @@ def test_graph_form_backward_against_the_chain_and_fp32_incl_input_gradients(gra
 # RELATIVE error is several times that of the weight tensors the same terms feed.
 _INPUT_GRAD_TOL = {
     "fp32": (1e-4, 1e-4, 1e-4, 1e-4), "bf16x3": (1e-4, 1e-4, 1e-4, 1e-4), "f16c8": (1e-4, 1e-4, 1e-4, 1e-4),
-    "bf16": (2e-2, 9e-2, 1.25e-2, 6.5e-3), "fp16": (2e-2, 9e-2, 1.1e-2, 5.5e-3),
+    # measured worst over graphs x forms (profiles/r05r_gpu_tests.log): bf16 1.29e-2 / 5.9e-2 / 8.2e-3 / 4.3e-3, fp16 7.9e-3 / 7.3e-2 / 7.0e-3 / 4.0e-3
+    "bf16": (1.9e-2, 9e-2, 1.25e-2, 6.5e-3), "fp16": (1.2e-2, 1.1e-1, 1.05e-2, 6e-3),
 }
 
 
