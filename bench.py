@@ -703,6 +703,19 @@ def main():
         if rk.world == 1 and not args.no_precision_legs and args.atoms == 64 and args.batch == 256 and args.precision == "bf16":
             out.update(precision_legs(args, rk))
             valid = valid and all(out[k]["nonfinite_graphs"] == 0 for k in ("tolerance_grade", "fp16", "c3"))
+        if (rk.world == 1 and not args.no_train_leg and not args.no_precision_legs and args.atoms == 64 and args.batch == 256 and
+                args.precision == "bf16" and "tolerance_grade" in out):
+            # the same training step at the tolerance grade: forward on the tolerance-grade precision's kernels, backward = the fp32
+            # chain of stage kernels with head + remainder products on the library's own GEMM kernels (no BLAS library in the step)
+            import copy
+            a2 = copy.copy(args)
+            a2.precision = out["tolerance_grade"]["precision"]
+            tg_tr = train_leg(a2, rk, 3, 1, 256)
+            tg_tr["precision"] = a2.precision
+            tg_tr["backward"] = ("fp32 chain of stage kernels, every product as head + remainder bf16 operands on egnn_gemm_tn_bf16 / "
+                                 "egnn_gemm_rows_bf16 (gemm.mm_tn_split / mm_nn_split): no BLAS library in the step")
+            out["ddp_train_tolerance_grade"] = tg_tr
+            valid = valid and tg_tr["finite"]
         if rk.world == 1 and not args.no_latency_leg and args.atoms == 64:
             out["latency"] = latency_leg(args, rk)
         if rk.world == 1 and rk.rank == 0 and not args.no_cpu_baseline:

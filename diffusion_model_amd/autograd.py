@@ -103,9 +103,35 @@ def _graph_chunks(plan, rows):
     return out
 
 
+_SPLIT_PRODUCTS = False   # set per backward call (see _EGNNFunction.backward)
+
+
+def _own_fp32_products() -> bool:
+    """True while the backward of a tolerance-grade precision (bf16x3, f16c8) runs: its products go through the library's own
+    kernels as head + remainder products (gemm.mm_tn_split / mm_nn_split, 2^-16 per operand -- what those precisions' forward
+    carries) instead of through the BLAS library.  Precision fp32 keeps the exact fp32 products of torch.mm / bmm (parity mode)
+    unless EGNN_BWD_OWN=1; EGNN_BWD_BLAS=1 forces the BLAS library for every precision (A/B)."""
+    return _SPLIT_PRODUCTS
+
+
+def _mm(a, b, out=None):
+    """a @ b for fp32 operands of the fp32-grade chain"""
+    if _own_fp32_products() and a.is_cuda and a.dtype == torch.float32:
+        from .gemm import mm_nn_split
+        r = mm_nn_split(a, b.float())
+        if out is None:
+            return r
+        out.copy_(r)
+        return out
+    return torch.mm(a, b, out=out) if out is not None else torch.mm(a, b)
+
+
 def _wgrad(g, a, n_pad, splits):
     """g[:n_pad]^T . a[:n_pad] with the long edge dimension cut into `splits` batched products (the BLAS library's
     single-GEMM choice for K = 2^18 and a small output runs at a fraction of its batched rate); fp32 result"""
+    if _own_fp32_products() and g.is_cuda and g.dtype == torch.float32:
+        from .gemm import mm_tn_split
+        return mm_tn_split(g[:n_pad], a[:n_pad])
     S = splits
     while S > 1 and (n_pad % S or n_pad // S < 1024):
         S //= 2
@@ -158,8 +184,8 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_
         w = lin.weight.detach()
         if hip:        # the fused kernels take P / Q from the forward's table; the dgrad runs on packed fragments
             return None, None, None, (None if first else pack_rows_weights(w.float().contiguous(), 2 * H + 1))
-        Pn = torch.addmm(lin.bias.detach(), h, w[:, :H].t()).contiguous()
-        Qn = torch.mm(h, w[:, H:2 * H].t()).contiguous()
+        Pn = (_mm(h, w[:, :H].t().contiguous()) + lin.bias.detach()).contiguous()
+        Qn = _mm(h, w[:, H:2 * H].t().contiguous()).contiguous()
         wpad = torch.zeros(w.shape[0], K1P, dtype=dt, device=h.device)
         wpad[:, :2 * H + 1] = w
         return Pn, Qn, w[:, 2 * H].contiguous(), wpad
@@ -230,8 +256,8 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_
         else:
             _lib.check(L.egcl_backward_l1_act(st, prec, n, Wx, P(d32), P(s32), P(Px), P(Qx), P(wdx), P(d2), P(s1x)))
             _lib.check(L.egcl_backward_l1_act(st, prec, n, Wm, P(d32), P(s32), P(Pm), P(Qm), P(wdm), P(d2), P(s1m)))
-            torch.mm(s1x, w2x.t(), out=a2x)
-            torch.mm(s1m, w2m.t(), out=a2m)
+            _mm(s1x, w2x.t().contiguous(), out=a2x)
+            _mm(s1m, w2m.t().contiguous(), out=a2m)
             _lib.check(L.egcl_backward_heads(st, prec, n, Wx, M, P(d32), P(s32), P(x), P(g_ax), P(g_am), P(a2x), P(a2m),
                                              P(b2x), P(w3), P(b3), P(b2m), P(wa), P(ba), P(g_diff), P(g_b2x), P(g_w3),
                                              P(g_b3), P(g_b2m), P(g_wa), P(g_ba)))
@@ -253,8 +279,8 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_
             # dgrad of the second layers with SiLU'(a1) in the epilogue, on MFMA (no [n, W] round trip in between)
             _lib.check(L.egcl_backward_dgrad(fused[0], st, fused[1], P(x), a, n, P(a2x), P(a2m), P(g1x), P(g1m)))
         else:
-            torch.mm(a2x, w2x, out=g1x)
-            torch.mm(a2m, w2m, out=g1m)
+            _mm(a2x, w2x, out=g1x)
+            _mm(a2m, w2m, out=g1m)
             _lib.check(L.egcl_backward_l1_grad(st, prec, n, Wx, P(d32), P(s32), P(Px), P(Qx), P(wdx), P(d2), P(g1x)))
             _lib.check(L.egcl_backward_l1_grad(st, prec, n, Wm, P(d32), P(s32), P(Pm), P(Qm), P(wdm), P(d2), P(g1m)))
         # first Linear layers: wgrad against in = [h_i | h_j | d2 | 1], dgrad back to the gathered inputs
@@ -273,8 +299,8 @@ def _edge_backward(layer, prec, ws, h, x, dst32, src32, node_seg, g_am, g_ax, g_
         else:
             g_w1x += _wgrad(ws.g1x, ws.inp, n_pad, 32)
             g_w1m += _wgrad(ws.g1m, ws.inp, n_pad, 32)
-            torch.mm(g1x, w1x, out=g_in)
-            g_in.addmm_(g1m, w1m)
+            _mm(g1x, w1x, out=g_in)
+            g_in += _mm(g1m, w1m)
         _lib.check(L.egcl_backward_scatter(st, prec, n, H, K1P, P(d32), P(s32), P(x), P(g_in), P(g_diff), P(g_S),
                                            P(node_seg), P(g_h), P(g_x)))
 
@@ -355,6 +381,28 @@ def _node_backward_hip(layer, h_l, sum_m, gh, grads):
     return g_cat[:, :H].contiguous(), g_cat[:, H:K1].contiguous()
 
 
+def _node_backward_split(layer, h_l, sum_m, gh, grads):
+    """backward of h' = mlp_h([h | sum_m]) (EquivariantGraphNeuralNetwork.py:26-30, :69) for the fp32-grade precisions on the
+    library's own kernels: the formulas of _node_backward_hip with every product as head + remainder (gemm.mm_nn_split /
+    mm_tn_split) and the element-wise stages in fp32."""
+    lin1, lin2 = layer.mlp_h[0], layer.mlp_h[2]
+    H = h_l.shape[1]
+    w1, w2 = lin1.weight.detach().float(), lin2.weight.detach().float()
+    hcat = torch.cat((h_l, sum_m), dim=1).float()
+    z1 = _mm(hcat, w1.t().contiguous()) + lin1.bias.detach()
+    sg = torch.sigmoid(z1)
+    s = z1 * sg
+    g_s = _mm(gh.float().contiguous(), w2)                      # [N, Wh] = gh @ W2
+    g_z1 = g_s * (sg * (1.0 + z1 * (1.0 - sg)))                 # SiLU'(z1)
+    acc = lambda p_, g_: grads.__setitem__(p_, g_ if p_ not in grads else grads[p_] + g_)
+    acc(lin2.bias, gh.sum(0))
+    acc(lin1.bias, g_z1.sum(0))
+    acc(lin2.weight, _wgrad(gh.float().contiguous(), s, gh.shape[0], 1))        # [H, Wh]
+    acc(lin1.weight, _wgrad(g_z1, hcat, hcat.shape[0], 1))                     # [Wh, H + M]
+    g_cat = _mm(g_z1, w1)                                                      # [N, H + M]
+    return g_cat[:, :H].contiguous(), g_cat[:, H:].contiguous()
+
+
 class _EGNNFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, owner, layers, plan, prec, scope, h, x, *params):
@@ -424,8 +472,11 @@ class _EGNNFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gh, gx):
         layers, plan, prec = ctx.layers, ctx.plan, ctx.prec
-        if prec in (_lib.PREC_BF16X3, _lib.PREC_F16C8):   # forward on the split-operand kernels; the backward chain is the fp32 one
-            prec = _lib.PREC_F32
+        global _SPLIT_PRODUCTS
+        _SPLIT_PRODUCTS = (os.environ.get("EGNN_BWD_BLAS", "0") != "1" and
+                           (prec in (_lib.PREC_BF16X3, _lib.PREC_F16C8) or os.environ.get("EGNN_BWD_OWN", "0") == "1"))
+        if prec in (_lib.PREC_BF16X3, _lib.PREC_F16C8):   # forward on the split-operand kernels; the backward is the fp32 chain of
+            prec = _lib.PREC_F32                          # stage kernels with head + remainder products on the own GEMM kernels
         if prec == _lib.PREC_F16:      # forward on fp16 operands; the backward recomputes on the bf16 kernels
             prec = _lib.PREC_BF16
         scope_graph = ctx.scope == _lib.NORM_GRAPH
@@ -473,6 +524,15 @@ class _EGNNFunction(torch.autograd.Function):
                     o = torch.autograd.grad([x_new], [x_leaf, ax, S_leaf], [gx], allow_unused=True)
                 g_x, g_ax, g_S = zero(o[0], x_l), zero(o[1], sum_x), zero(o[2], S)
                 g_h, g_am = _node_backward_hip(layer, h_l, sum_m, gh, grads)
+            elif _own_fp32_products() and h_l.dtype == torch.float32:
+                # the same formulas with head + remainder products (no BLAS library): fp32 element-wise stages by torch
+                with torch.enable_grad():
+                    x_leaf = x_l.detach().requires_grad_(True)
+                    ax, S_leaf = sum_x.detach().requires_grad_(True), S.detach().requires_grad_(True)
+                    x_new = x_leaf + ax * _segment_scale(S_leaf, scope_graph, node_graph)
+                    o = torch.autograd.grad([x_new], [x_leaf, ax, S_leaf], [gx], allow_unused=True)
+                g_x, g_ax, g_S = zero(o[0], x_l), zero(o[1], sum_x), zero(o[2], S)
+                g_h, g_am = _node_backward_split(layer, h_l, sum_m, gh, grads)
             else:
                 node_params = list(layer.mlp_h.parameters())
                 with torch.enable_grad():

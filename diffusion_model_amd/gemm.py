@@ -89,3 +89,54 @@ def linear_rows(a: torch.Tensor, weight: torch.Tensor, k: int | None = None) -> 
     out = torch.empty(a.shape[0], chunks * 128, dtype=torch.float32, device=a.device)
     gemm_rows(a, pack_rows_weights(wt, n_out), out=out, k0=k, chunks=chunks)   # all column chunks in one launch
     return out[:, :n_out]
+
+
+# ---- fp32-grade products on the bf16 matrix cores: head + remainder operands, three products ---------------
+# The backward of the fp32-grade precisions (fp32, bf16x3, f16c8: autograd.py) multiplied through the BLAS library (torch.mm /
+# bmm).  These two wrappers run the same products on the library's OWN kernels: every fp32 operand is split into a bf16 head and a
+# bf16 remainder (a = a_hi + a_lo, 16 significant bits) and the product is a_lo b_hi + a_hi b_lo + a_hi b_hi with fp32
+# accumulation -- what precision bf16x3 does in the forward -- as three calls of gemm_tn (accumulating into one fp32 result) or two
+# calls of gemm_rows (its two-operand form carries the small terms).  Relative error 2^-16 per operand (measured against a
+# float64 product: tests/test_training.py::test_split_products_match_fp64).
+def _split_bf16(t: torch.Tensor, cols: int):
+    """fp32 [R, C] -> (head, remainder) bf16 [R, cols] (cols >= C, zero-padded: operand widths of the kernels)"""
+    R, C = t.shape
+    hi = torch.zeros(R, cols, dtype=torch.bfloat16, device=t.device)
+    lo = torch.zeros(R, cols, dtype=torch.bfloat16, device=t.device)
+    h = t.to(torch.bfloat16)
+    hi[:, :C] = h
+    lo[:, :C] = (t - h.float()).to(torch.bfloat16)
+    return hi, lo
+
+
+def mm_tn_split(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """fp32 [Ma, Nb] = a^T b for fp32 a [E, Ma], b [E, Nb] (the weight-gradient products: reduction over the rows)"""
+    Ma, Nb = a.shape[1], b.shape[1]
+    Mp, Np = (Ma + 255) // 256 * 256, (Nb + 127) // 128 * 128
+    a_hi, a_lo = _split_bf16(a, Mp)
+    b_hi, b_lo = _split_bf16(b, Np)
+    out = torch.zeros(Ma, Nb, dtype=torch.float32, device=a.device)
+    gemm_tn(a_lo, b_hi, rows=Ma, cols=Nb, out=out, accumulate=True)   # small terms first
+    gemm_tn(a_hi, b_lo, rows=Ma, cols=Nb, out=out, accumulate=True)
+    gemm_tn(a_hi, b_hi, rows=Ma, cols=Nb, out=out, accumulate=True)
+    return out
+
+
+def mm_nn_split(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """fp32 [E, N] = a w for fp32 a [E, K], w [K, N] (forward / input-gradient products: every row of a streamed once per 128
+    output columns)"""
+    E, K = a.shape
+    N = w.shape[1]
+    Kp = (K + 63) // 64 * 64
+    a_hi, a_lo = _split_bf16(a, Kp)
+    wp = torch.zeros(Kp, N, dtype=torch.float32, device=a.device)
+    wp[:K] = w
+    w_hi = wp.to(torch.bfloat16).float()
+    w_lo = wp - w_hi
+    p_hi, p_lo = pack_rows_weights(w_hi.contiguous(), N), pack_rows_weights(w_lo.contiguous(), N)
+    chunks = (N + 127) // 128
+    small = torch.empty(E, chunks * 128, dtype=torch.float32, device=a.device)
+    big = torch.empty(E, chunks * 128, dtype=torch.float32, device=a.device)
+    gemm_rows(a_lo, p_hi, a_hi, p_lo, out=small, k0=Kp, chunks=chunks)
+    gemm_rows(a_hi, p_hi, out=big, k0=Kp, chunks=chunks)
+    return (big + small)[:, :N]

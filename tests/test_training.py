@@ -676,6 +676,31 @@ def test_input_and_parameter_gradients_match_oracle_autograd(form, graphs, monke
 
 
 @pytest.mark.gpu
+def test_split_products_match_fp64():
+    """gemm.mm_tn_split / mm_nn_split (head + remainder bf16 operands, three products on the library's own kernels: the products of
+    the tolerance-grade backward) against float64 products: 2^-16 per operand -> <= 3e-5 relative (measured
+    ~6e-6); odd sizes exercise the padding (rows not a multiple of 64, widths not multiples of 64 / 128 / 256)."""
+    from diffusion_model_amd.gemm import mm_nn_split, mm_tn_split
+    g = torch.Generator().manual_seed(4)
+    for E, Ma, Nb in ((5000, 1024, 1024), (4097, 36, 1024), (3001, 1024, 74), (777, 292, 130)):
+        a = (torch.randn(E, Ma, generator=g) * torch.logspace(-2, 1, Ma)).cuda()      # columns of very different magnitude
+        b = torch.randn(E, Nb, generator=g).cuda()
+        got = mm_tn_split(a, b)
+        want = a.double().t() @ b.double()
+        e = rel_err(got.cpu(), want.cpu())
+        print(f"mm_tn_split [{E}, {Ma}]^T [{E}, {Nb}]: {e:.2e}")
+        assert e <= 3e-5
+    for E, K, N in ((5000, 1024, 1024), (4097, 36, 1024), (3001, 1024, 74), (777, 292, 292)):
+        a = torch.randn(E, K, generator=g).cuda()
+        w = (torch.randn(K, N, generator=g) * 0.05).cuda()
+        got = mm_nn_split(a, w)
+        want = a.double() @ w.double()
+        e = rel_err(got.cpu(), want.cpu())
+        print(f"mm_nn_split [{E}, {K}] [{K}, {N}]: {e:.2e}")
+        assert e <= 3e-5 and got.shape == (E, N)
+
+
+@pytest.mark.gpu
 def test_node_activation_stage_matches_torch():
     """egcl_backward_node_act: s = SiLU(z + b1), dL/dz = dL/ds * SiLU'(z + b1) as bf16 and the bias gradient, against float64
     torch on the same inputs (row strides wider than W, N not a multiple of the 64-row block, W not a multiple of 256)"""
