@@ -118,11 +118,7 @@ def _mm(a, b, out=None):
     """a @ b for fp32 operands of the fp32-grade chain"""
     if _own_fp32_products() and a.is_cuda and a.dtype == torch.float32:
         from .gemm import mm_nn_split
-        r = mm_nn_split(a, b.float())
-        if out is None:
-            return r
-        out.copy_(r)
-        return out
+        return mm_nn_split(a, b.float(), out=out)
     return torch.mm(a, b, out=out) if out is not None else torch.mm(a, b)
 
 

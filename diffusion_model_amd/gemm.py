@@ -101,11 +101,14 @@ def linear_rows(a: torch.Tensor, weight: torch.Tensor, k: int | None = None) -> 
 def _split_bf16(t: torch.Tensor, cols: int):
     """fp32 [R, C] -> (head, remainder) bf16 [R, cols] (cols >= C, zero-padded: operand widths of the kernels)"""
     R, C = t.shape
+    h = t.to(torch.bfloat16)
+    l = (t - h.float()).to(torch.bfloat16)
+    if cols == C:
+        return h, l
     hi = torch.zeros(R, cols, dtype=torch.bfloat16, device=t.device)
     lo = torch.zeros(R, cols, dtype=torch.bfloat16, device=t.device)
-    h = t.to(torch.bfloat16)
     hi[:, :C] = h
-    lo[:, :C] = (t - h.float()).to(torch.bfloat16)
+    lo[:, :C] = l
     return hi, lo
 
 
@@ -115,28 +118,35 @@ def mm_tn_split(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     Mp, Np = (Ma + 255) // 256 * 256, (Nb + 127) // 128 * 128
     a_hi, a_lo = _split_bf16(a, Mp)
     b_hi, b_lo = _split_bf16(b, Np)
-    out = torch.zeros(Ma, Nb, dtype=torch.float32, device=a.device)
-    gemm_tn(a_lo, b_hi, rows=Ma, cols=Nb, out=out, accumulate=True)   # small terms first
+    out = torch.empty(Ma, Nb, dtype=torch.float32, device=a.device)
+    gemm_tn(a_lo, b_hi, rows=Ma, cols=Nb, out=out, accumulate=False)   # small terms first
     gemm_tn(a_hi, b_lo, rows=Ma, cols=Nb, out=out, accumulate=True)
     gemm_tn(a_hi, b_hi, rows=Ma, cols=Nb, out=out, accumulate=True)
     return out
 
 
-def mm_nn_split(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+def mm_nn_split(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
     """fp32 [E, N] = a w for fp32 a [E, K], w [K, N] (forward / input-gradient products: every row of a streamed once per 128
-    output columns)"""
+    output columns).  ONE launch: the kernel's two-operand form out = A0 W0 + A1 W1 with A0 = [a_hi | a_lo] against [W_hi ; W_hi]
+    (both products that share W_hi, reduction width 2 K) and A1 = a_hi against W_lo."""
     E, K = a.shape
     N = w.shape[1]
     Kp = (K + 63) // 64 * 64
-    a_hi, a_lo = _split_bf16(a, Kp)
+    hl = torch.zeros(E, 2 * Kp, dtype=torch.bfloat16, device=a.device) if Kp != K else torch.empty(E, 2 * Kp, dtype=torch.bfloat16, device=a.device)
+    hl[:, :K] = a                                    # head (implicit rounding to bf16)
+    hl[:, Kp:Kp + K] = a - hl[:, :K].float()         # remainder
     wp = torch.zeros(Kp, N, dtype=torch.float32, device=a.device)
     wp[:K] = w
     w_hi = wp.to(torch.bfloat16).float()
-    w_lo = wp - w_hi
-    p_hi, p_lo = pack_rows_weights(w_hi.contiguous(), N), pack_rows_weights(w_lo.contiguous(), N)
+    p0 = pack_rows_weights(torch.cat((w_hi, w_hi), 0).contiguous(), N)
+    p1 = pack_rows_weights((wp - w_hi).contiguous(), N)
     chunks = (N + 127) // 128
-    small = torch.empty(E, chunks * 128, dtype=torch.float32, device=a.device)
-    big = torch.empty(E, chunks * 128, dtype=torch.float32, device=a.device)
-    gemm_rows(a_lo, p_hi, a_hi, p_lo, out=small, k0=Kp, chunks=chunks)
-    gemm_rows(a_hi, p_hi, out=big, k0=Kp, chunks=chunks)
-    return (big + small)[:, :N]
+    direct = out is not None and out.dtype == torch.float32 and out.stride(1) == 1 and out.stride(0) >= 128 * chunks and out.shape[0] >= E
+    res = out if direct else torch.empty(E, chunks * 128, dtype=torch.float32, device=a.device)
+    gemm_rows(hl, p0, hl[:, :Kp], p1, out=res, k0=2 * Kp, chunks=chunks)
+    if direct:
+        return out[:, :N]
+    if out is not None:
+        out.copy_(res[:, :N])
+        return out
+    return res[:, :N]
