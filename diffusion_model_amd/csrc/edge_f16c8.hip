@@ -194,7 +194,7 @@ __global__ __launch_bounds__(kT, 2) void edge_c8_kernel(const EdgeParams p) {
   // two kinds of block need the same product -- even blocks a_lo8 x W_hi8: 2^-12 x 2^-s_hi, odd blocks a_hi8 x W_lo8: 2^-1 x
   // 2^-(s_hi + 11) -- so both operands take ONE wave-uniform scale: a literal and a scalar register, no vector registers
   constexpr int kScaleA = 127 - 12;
-  const int scale_b = __builtin_amdgcn_readfirstlane((IS_M ? p.c8_exp + 2 : p.c8_exp)[0]);   // 127 - s_hi (c8_exponents_kernel)
+  const int scale_b = __builtin_amdgcn_readfirstlane((IS_M ? p.c8_exp + 2 : p.c8_exp)[0]);   // 127 - s_hi (pack_frags_c8)
 
   f32x4v acc[8][CB];
 #pragma unroll
@@ -580,12 +580,22 @@ __global__ __launch_bounds__(kT, 2) void edge_c8_kernel(const EdgeParams p) {
 //   block q covers hidden units 64 c + 32 (q >> 1) + [0, 32): even q holds e4m3(2^s_hi W_hi), odd q e4m3(2^s_lo W_lo) with
 //   v = W * scale (what the fp16 stream holds), W_hi = fp16(v), W_lo = v - W_hi;
 //   register piece `piece` of the lane holds hidden units 16 piece .. + 15 of its block (the A operand's 32 bytes in address order).
-// exps[0..1] = {127 - s_hi, 127 - s_lo} (e8m0 bytes of the block scales), from c8_exponents_kernel.
+// The scale exponents come from the matrix's largest |v| (c8_absmax_kernel): 2^s_hi max in [112, 224] (e4m3 tops out at 448),
+// s_lo = s_hi + 11 (a remainder is at most 2^-11 of its head); exps[0..1] = {127 - s_hi, 127 - s_lo} = the e8m0 bytes of the block
+// scales, written by block 0 for the edge kernels.
+__device__ __forceinline__ int c8_shift(unsigned maxbits) {
+  const float mx = fminf(__builtin_bit_cast(float, maxbits), 65504.f);
+  int s_hi = 0;
+  if (mx > 0.f) s_hi = (int)floorf(log2f(224.0f / mx));
+  return s_hi > 40 ? 40 : (s_hi < -40 ? -40 : s_hi);
+}
 __global__ void pack_frags_c8(const float* __restrict__ W, int Nout, int K, int ldw, int NP, int KP, unsigned char* __restrict__ out,
-                              float scale, const int* __restrict__ exps) {
+                              float scale, const unsigned* __restrict__ maxbits, int* __restrict__ exps) {
   __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);   // MODE.FP16_OVFL: the conversions saturate
   const int NC = KP / 64;
-  const float inv_hi = __builtin_ldexpf(1.0f, exps[0] - 127), inv_lo = __builtin_ldexpf(1.0f, exps[1] - 127);   // 2^-s: the cvt divides
+  const int s_hi = c8_shift(*maxbits);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { exps[0] = 127 - s_hi; exps[1] = 127 - s_hi - 11; }
+  const float inv_hi = __builtin_ldexpf(1.0f, -s_hi), inv_lo = __builtin_ldexpf(1.0f, -s_hi - 11);   // 2^-s: the cvt divides
   const size_t total = (size_t)(NP / 16) * NC * 2 * 64 * 8;   // byte PAIRS
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int jp = i & 7, lane = (i >> 3) & 63, piece = (i >> 9) & 1;
@@ -607,26 +617,24 @@ __global__ void pack_frags_c8(const float* __restrict__ W, int Nout, int K, int 
     reinterpret_cast<unsigned short*>(out)[i] = (unsigned short)r.x;
   }
 }
-// exps[0] = 127 - s_hi with 2^s_hi max|fp16(W scale)| in [112, 224] (e4m3 tops out at 448); exps[1] = exps[0] - 11 (a remainder
-// is at most 2^-11 of its head).  One workgroup.
-__global__ void c8_exponents_kernel(const float* __restrict__ W, int Nout, int K, int ldw, float scale, int* __restrict__ exps) {
+// largest |W scale| of the matrix as float bits (non-negative floats order like unsigned integers): grid-stride maximum, one
+// atomicMax per workgroup into *maxbits (zeroed by the caller).  (The first build reduced in ONE workgroup: 0.87 ms per matrix,
+// 7 ms of every TRAINING step, which repacks all layers -- profiles/r05u_train_f16c8_summary.txt.)
+__global__ void c8_absmax_kernel(const float* __restrict__ W, int Nout, int K, int ldw, float scale, unsigned* __restrict__ maxbits) {
   __shared__ float red[256];
   float m = 0.f;
-  for (size_t i = threadIdx.x; i < (size_t)Nout * K; i += blockDim.x) m = fmaxf(m, fabsf(W[(i / K) * ldw + (i % K)] * scale));
+  const size_t total = (size_t)Nout * K;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = fabsf(W[(i / K) * ldw + (i % K)] * scale);
+    m = v > m ? v : m;   // (a NaN weight never becomes the maximum: the scale stays finite)
+  }
   red[threadIdx.x] = m;
   __syncthreads();
   for (int s = 128; s >= 1; s >>= 1) {
     if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    const float mx = fminf(red[0], 65504.f);
-    int s_hi = 0;
-    if (mx > 0.f && mx == mx) s_hi = (int)floorf(log2f(224.0f / mx));
-    s_hi = s_hi > 40 ? 40 : (s_hi < -40 ? -40 : s_hi);
-    exps[0] = 127 - s_hi;
-    exps[1] = 127 - s_hi - 11;
-  }
+  if (threadIdx.x == 0) atomicMax(maxbits, __builtin_bit_cast(unsigned, red[0]));
 }
 
 }  // namespace
@@ -661,10 +669,13 @@ int launch_edge_f16c8_m(const EdgeParams& p, hipStream_t st) {
   return EGNN_OK;
 }
 
-// out: e4m3 fragment stream of NP x KP bytes x 2; exps: int[2]
-int pack_c8_stream(const float* W, int Nout, int K, int ldw, int NP, int KP, void* out, float scale, int* exps, hipStream_t st) {
-  hipLaunchKernelGGL(c8_exponents_kernel, dim3(1), dim3(256), 0, st, W, Nout, K, ldw, scale, exps);
-  hipLaunchKernelGGL(pack_frags_c8, dim3(256), dim3(256), 0, st, W, Nout, K, ldw, NP, KP, static_cast<unsigned char*>(out), scale, exps);
+// out: e4m3 fragment stream of NP x KP bytes x 2; exps: int[2] (e8m0 bytes of the block scales); maxbits: one scratch word
+int pack_c8_stream(const float* W, int Nout, int K, int ldw, int NP, int KP, void* out, float scale, int* exps, unsigned* maxbits,
+                   hipStream_t st) {
+  EGNN_HIP(hipMemsetAsync(maxbits, 0, sizeof(unsigned), st));
+  hipLaunchKernelGGL(c8_absmax_kernel, dim3(128), dim3(256), 0, st, W, Nout, K, ldw, scale, maxbits);
+  hipLaunchKernelGGL(pack_frags_c8, dim3(256), dim3(256), 0, st, W, Nout, K, ldw, NP, KP, static_cast<unsigned char*>(out), scale,
+                     maxbits, exps);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }

@@ -1628,7 +1628,7 @@ int egnn_pack_layer(egnn_ctx* c, void* stream, int l, const float* m0_w, const f
     lp.w2x_c8 = tmp; tmp = nullptr;
     if ((rc = dev_alloc(&tmp, (size_t)MP * WmP))) return rc;
     lp.w2m_c8 = tmp; tmp = nullptr;
-    if ((rc = dev_alloc(&lp.c8_exp, (size_t)4))) return rc;
+    if ((rc = dev_alloc(&lp.c8_exp, (size_t)8))) return rc;   // [0..3] scale exponents {x: hi, lo, m: hi, lo}, [4..5] max |w| scratch
   }
   const dim3 g(256), b(256);
   hipLaunchKernelGGL(pack_first, g, b, 0, st, x0_w, x0_b, m0_w, m0_b, H, Wx, Wm, WxP, WmP, lp.w1catT, lp.b1cat);
@@ -1677,8 +1677,8 @@ int egnn_pack_layer(egnn_ctx* c, void* stream, int l, const float* m0_w, const f
       hipLaunchKernelGGL((pack_frags_bf16_accperm<_Float16, true>), g, b, 0, st, h2_w, H, Wh, Wh, HP, WhP, reinterpret_cast<_Float16*>(lp.w2h_f16p_lo), kF16WScale);
     }
     // precision f16c8: the same scaled weights as e4m3 head / remainder fragments for the block-scaled correction product
-    if ((rc = pack_c8_stream(x2_w, Wx, Wx, Wx, WxP, WxP, lp.w2x_c8, s2 * kF16WScale, lp.c8_exp, st))) return rc;
-    if ((rc = pack_c8_stream(m2_w, M, Wm, Wm, MP, WmP, lp.w2m_c8, s2 * kF16WScale, lp.c8_exp + 2, st))) return rc;
+    if ((rc = pack_c8_stream(x2_w, Wx, Wx, Wx, WxP, WxP, lp.w2x_c8, s2 * kF16WScale, lp.c8_exp, reinterpret_cast<unsigned*>(lp.c8_exp + 4), st))) return rc;
+    if ((rc = pack_c8_stream(m2_w, M, Wm, Wm, MP, WmP, lp.w2m_c8, s2 * kF16WScale, lp.c8_exp + 2, reinterpret_cast<unsigned*>(lp.c8_exp + 5), st))) return rc;
     hipLaunchKernelGGL(pack_frags_bf16_lo, g, b, 0, st, x2_w, Wx, Wx, Wx, WxP, WxP, reinterpret_cast<__bf16*>(lp.w2x_bf16s_lo), s2);
     hipLaunchKernelGGL(pack_frags_bf16_lo, g, b, 0, st, m2_w, M, Wm, Wm, MP, WmP, reinterpret_cast<__bf16*>(lp.w2m_bf16s_lo), s2);
     hipLaunchKernelGGL(pack_frags_bf16<__bf16>, g, b, 0, st, h0_w, Wh, H + M, H + M, WhP, c->K1Q, reinterpret_cast<__bf16*>(lp.w1h_bf16), 1.0f);

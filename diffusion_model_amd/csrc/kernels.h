@@ -349,6 +349,7 @@ int launch_edge_f16c8_m(const EdgeParams& p, hipStream_t st);
 bool edge_f16c8_supported(const EdgeParams& p);
 int edge_f16c8_x_split(int WxP);
 int init_edge_f16c8_attributes();
-int pack_c8_stream(const float* W, int Nout, int K, int ldw, int NP, int KP, void* out, float scale, int* exps, hipStream_t st);
+int pack_c8_stream(const float* W, int Nout, int K, int ldw, int NP, int KP, void* out, float scale, int* exps, unsigned* maxbits,
+                   hipStream_t st);
 
 }  // namespace egnn
