@@ -50,6 +50,11 @@ constexpr int kKC = 64;                        // activation chunk depth
 #ifndef C8_MPRIO
 #define C8_MPRIO 0
 #endif
+#ifndef C8_MPHASE4_INC   // generated body of the 4-column-block matrix phase and its ring depths (tools/gen/gen_c8_mphase.py)
+#define C8_MPHASE4_INC "edge_f16c8_mphase4.inc"
+#define C8_RA4 3
+#define C8_RC4 2
+#endif
 constexpr int kCBX = C8_CBX;                        // coordinate kernel: 16-column blocks per wave (4: 512 columns per workgroup; see edge_c8_kernel)
 constexpr size_t kA1 = (size_t)8 * kR * 16;    // fp16 image of a chunk: [8 k-groups][128 rows][8 f16], rows XOR-swizzled (edge_x_m16.hip)
 // e4m3 image of a chunk: four K blocks [a_lo8 0-31 | a_hi8 0-31 | a_lo8 32-63 | a_hi8 32-63] of [128 rows][32 B], block q at
@@ -390,14 +395,14 @@ __global__ __launch_bounds__(kT, 2) void edge_c8_kernel(const EdgeParams p) {
     auto mphase = [&](auto par_c, const int c, const int tab_chunk) {
       constexpr int PAR = decltype(par_c)::value;
       constexpr int kO16 = PAR * (int)kA1, kO8 = PAR * (int)kC8;
-      f16x8 a[3];
-      u32x4 c0[2], c1[2];
+      f16x8 a[C8_RA4];
+      u32x4 c0[C8_RC4], c1[C8_RC4];
 #define BQ(s) bq[0][s]
 #define B8 b8[0]
 #define MPHASE_AFTER_FIRST_READS do { __builtin_amdgcn_sched_barrier(0); wload16(c, 1); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define MPHASE_AFTER_KSTEP0 do { DIAG_STAMP2(c + 16, 0, c < 14); wload8(c); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define MPHASE_AFTER_KSTEP1 do { DIAG_STAMP2(c + 16, 1, c < 14); if (tab_chunk >= 0) vload0(tab_chunk); __builtin_amdgcn_sched_barrier(0); } while (0)
-#include "edge_f16c8_mphase4.inc"
+#include C8_MPHASE4_INC
       DIAG_STAMP2(c + 16, 2, c < 14);
 #undef MPHASE_AFTER_KSTEP1
 #undef MPHASE_AFTER_KSTEP0

@@ -157,6 +157,9 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
           acc[rb][cb] = mfma16(a[u % 3], bq[s][cb], acc[rb][cb]);
+#ifdef XM16_PIN   // (A/B, tools/c8_ab2.sh: a scheduling barrier behind every group of MFMAs, as edge_f16c8.hip needs)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         // refill in place for use u + 3 (the MFMAs above have read the registers at issue): row block (u + 3) & 7 of k-step (u + 3) >> 3
         if (u == 0) LDS_RD(a[0], ab0, 768); if (u == 1) LDS_RD(a[1], ab0, 1024); if (u == 2) LDS_RD(a[2], ab0, 1280);
         if (u == 3) LDS_RD(a[0], ab0, 1536); if (u == 4) LDS_RD(a[1], ab0, 1792); if (u == 5) LDS_RD(a[2], ab1, 0);

@@ -8,7 +8,8 @@ usage: python tools/gen/gen_c8_mphase.py {2|4}  -> C++ text for the body of `mph
 import sys
 
 CB = int(sys.argv[1])
-RA, RC = (8, 4) if CB == 2 else (3, 2)          # ring depths
+import os
+RA, RC = (8, 4) if CB == 2 else (int(os.environ.get('C8_RA', 3)), int(os.environ.get('C8_RC', 2)))          # ring depths (C8_RA / C8_RC: experiments)
 out = []
 P = lambda u: f"LDS_RD(a[{u % RA}], {'abase1' if u >= 8 else 'abase0'}, kO16 + {256 * (u & 7)});"
 C = lambda v: f"LDS_RD(c0[{v % RC}], cbase, kO8 + {512 * v}); LDS_RD(c1[{v % RC}], cbase, kO8 + {512 * v + 16});"
@@ -19,7 +20,7 @@ corr_slots = {}                                   # main use u after which a cor
 if CB == 2:
     corr_slots = {8: 0, 10: 1, 12: 2, 14: 3}
 else:
-    corr_slots = {13: 0, 15: 1}
+    corr_slots = {13: 0, 15: 1} if RC == 2 else {11: 0, 13: 1, 15: 2}
 for u in range(16):
     seq.append(("useP", u))
     if nextP < 16:
