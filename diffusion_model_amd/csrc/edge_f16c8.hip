@@ -169,14 +169,6 @@ __global__ __launch_bounds__(kT, 2) void edge_c8_kernel(const EdgeParams p) {
   i32x8 b8[NSET][CB];      // [set][column block] e4m3
   prologue_rows(p, L, e0, nvalid, IS_M ? p.wdm : p.wdx, KP, s_wd, tid);
   DIAG_STAMP(30, 1);   // edge rows and geometry ready
-  // the first chunk's fragments (requested here, behind the row prologue: at kernel entry they were 1.5 % SLOWER in the A/B of
-  // profiles/r05p_c8_entry_ab.txt)
-#pragma unroll
-  for (int cb = 0; cb < CB; ++cb) bq[0][0][cb] = ld16(0, 0, cb);
-  if constexpr (CB == 2) {
-#pragma unroll
-    for (int cb = 0; cb < CB; ++cb) { bq[0][1][cb] = ld16(0, 1, cb); b8[0][cb] = ld8(0, cb); }
-  }
 
   // ---- K loop ----
   const rsrc_t rs_tab = make_rsrc(p.table, diag::drop_table_loads(p.dbg) ? 0u : (unsigned)min((size_t)p.N * p.TC * 4, (size_t)0xFFFFFFFFu));
@@ -279,8 +271,11 @@ __global__ __launch_bounds__(kT, 2) void edge_c8_kernel(const EdgeParams p) {
       vrow(par_c, P1, c);
       __builtin_amdgcn_s_setprio(C8_MPRIO);
     };
-    // chunk 0: table rows requested (the first weight fragments already are), then the segment structure is worked out while they fly
+    // chunk 0: table rows and the first weight fragments are requested, then the segment structure is worked out while they fly.
+    // (Same-box A/Bs of other placements, each SLOWER: fragments at kernel entry -1.5 %, behind the row prologue + both rows'
+    // table requests in front of the segment structure -0.8 %: profiles/r05p_c8_entry_ab.txt, r05z_c8_prologue_ab.txt.)
     vload(0);
+    wload(P0, 0);
     S = prologue_segments<false>(p, L, e0, nvalid, tid, lane, wave);
     vfinish(P0, 0);
     vload(1);
@@ -369,9 +364,9 @@ __global__ __launch_bounds__(kT, 2) void edge_c8_kernel(const EdgeParams p) {
     };
     // build of chunk c (row 0's table rows were requested by the matrix phase in front of it); mchunk: the chunk of the NEXT matrix
     // phase of this wave, whose k-step-0 fragments are requested between the rows
-    auto vfinish = [&](auto par_c, const int c, const int mchunk) {
+    auto vfinish = [&](auto par_c, const int c, const int mchunk, const bool row1_requested = false) {
       __builtin_amdgcn_s_setprio(C8_VPRIO);
-      vload1(c);
+      if (!row1_requested) vload1(c);
       __builtin_amdgcn_sched_barrier(0);
       if (!(diag::kC8NoBuild && c > 1)) vrow(par_c, P0, c);
       else asm volatile("" :: "v"(ua0.p0), "v"(ua0.p1), "v"(ua0.q0), "v"(ua0.q1));
@@ -386,7 +381,7 @@ __global__ __launch_bounds__(kT, 2) void edge_c8_kernel(const EdgeParams p) {
     };
     vload0(0);
     S = prologue_segments<false>(p, L, e0, nvalid, tid, lane, wave);
-    vfinish(P0, 0, -1);         // chunk 0 (its k-step-0 fragments were requested behind the row prologue)
+    vfinish(P0, 0, 0);          // chunk 0 (+ the k-step-0 fragments of chunk 0, between its rows)
     if (wave >= 4) vload0(1);   // waves 4-7 build chunk 1 first thing in the loop
     __syncthreads();
     DIAG_STAMP(30, 2);

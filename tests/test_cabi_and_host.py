@@ -249,3 +249,37 @@ def test_graph_plan_is_a_csr_view_of_any_edge_list(sizes, n_edges, seed):
         keep = (dst >= lo_) & (dst < hi_)
         assert lp.E == int(keep.sum()) and lp.N == n
         assert torch.equal(lp.row_ptr.long()[lo_ + 1:hi_ + 1] - lp.row_ptr.long()[lo_:hi_], (rp[1:] - rp[:-1])[lo_:hi_])
+
+
+def test_generated_f16c8_matrix_phases_match_their_generator():
+    """csrc/edge_f16c8_mphase{2,4}.inc (fully unrolled operand pipelines: ring slots, LDS offsets and every s_waitcnt lgkmcnt
+    count) are generated by tools/gen/gen_c8_mphase.py: the committed files must be what the generator prints, and every wait
+    count must equal the number of LDS reads issued after the read it waits for (recounted here from the text)."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for cb in (2, 4):
+        want = subprocess.run([sys.executable, os.path.join(root, "tools", "gen", "gen_c8_mphase.py"), str(cb)], capture_output=True,
+                              text=True, check=True, env={k: v for k, v in os.environ.items() if not k.startswith("C8_")}).stdout
+        have = open(os.path.join(root, "diffusion_model_amd", "csrc", f"edge_f16c8_mphase{cb}.inc")).read()
+        assert have == want, f"edge_f16c8_mphase{cb}.inc is stale: python tools/gen/gen_c8_mphase.py {cb} > ..."
+        # recount: walk the text, track the issue position of every register's latest read, check each wait
+        pos, last_read, nreads = 0, {}, []
+        pending_wait = None
+        for line in have.splitlines():
+            for m in re.finditer(r"LDS_RD\((\w+\[\d+\])", line):
+                pos += 1
+                last_read[m.group(1)] = pos
+            m = re.search(r"LDS_WAIT\((\d+)\)", line)
+            if m:
+                pending_wait = int(m.group(1))
+            m = re.search(r"MAIN_STEP\((a\[\d+\])", line)
+            if m:
+                assert pending_wait == pos - last_read[m.group(1)], line
+                pending_wait = None
+            m = re.search(r"CORR_STEP\((c0\[\d+\]), (c1\[\d+\])", line)
+            if m:
+                assert pending_wait == pos - last_read[m.group(2)], line      # both halves landed = the younger one landed
+                pending_wait = None
+        assert pos == 16 + 16     # 16 fp16 pieces + 8 e4m3 operands of two reads

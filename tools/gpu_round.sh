@@ -14,9 +14,10 @@ if [ "$2" = "profile" ]; then
   GIT_HEAD=${GIT_HEAD:-unknown} bash tools/profile_train_pmc.sh ${tag}_train > gpurun_out/$tag/profile_train.log 2>&1; echo "profile_train rc=$?"
   cp gpurun_out/prof_${tag}_train/traffic_train.json profiles/traffic_train.json 2>/dev/null   # (fingerprint of csrc/ + autograd.py + gemm.py)
 fi
+# measured errors of every precision on the goldens + C2 batch, with this tree's forward-source fingerprint: the bench lines below quote it
+python tools/prec_errors.py --out gpurun_out/$tag/prec_errors.log > gpurun_out/$tag/prec.out 2>&1; cp gpurun_out/$tag/prec_errors.log profiles/${tag}_prec_errors.log; grep golden_max gpurun_out/$tag/prec.out
 python bench.py > gpurun_out/$tag/bench_c2.json 2> gpurun_out/$tag/bench_c2.err; echo "c2 rc=$?"
 python bench.py --atoms 512 --batch 32 --steps 5 --warmup 2 --reps 3 --no-cpu-baseline > gpurun_out/$tag/bench_c3.json 2> gpurun_out/$tag/bench_c3.err; echo "c3 rc=$?"
-python tools/prec_errors.py --out gpurun_out/$tag/prec_errors.log > gpurun_out/$tag/prec.out 2>&1; cp gpurun_out/$tag/prec_errors.log profiles/${tag}_prec_errors.log; grep golden_max gpurun_out/$tag/prec.out
 python bench.py --mode train --steps 10 --warmup 3 > gpurun_out/$tag/bench_train.json 2> gpurun_out/$tag/bench_train.err; echo "train rc=$?"
 BENCH_DEVICE=0 BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 5 --warmup 2 --reps 2 --train-steps 3 > gpurun_out/$tag/bench_2rank_gloo.json 2> gpurun_out/$tag/bench_2rank_gloo.err; echo "2rank rc=$?"
 tail -c 600 gpurun_out/$tag/bench_c2.json; echo
