@@ -71,6 +71,9 @@ struct LayerPack {
   // above (hi | lo K blocks interleaved), and the e8m0 bytes of their block scales {x: hi, lo, m: hi, lo}
   void *w2x_c8 = nullptr, *w2m_c8 = nullptr;
   int* c8_exp = nullptr;
+  // the same on 32x32 matrix tiles (edge_f16c8w.hip): mlp_x.2 as v_mfma_f32_32x32x16_f16 B fragments (mlp_m.2: w2m_f16s above) and
+  // e4m3 fragments [N/32][K/32][2][64][16 B]
+  void *w2x_f16s = nullptr, *w2x_c8w = nullptr, *w2m_c8w = nullptr;
 };
 
 constexpr int kGraphSteps = 8;   // reverse steps captured per hipGraph

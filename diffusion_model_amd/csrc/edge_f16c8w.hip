@@ -1,0 +1,472 @@
+// Precision 'f16c8' on 32x32 matrix tiles (gfx950): the arithmetic of edge_f16c8.hip -- fp16 heads on the f16 matrix instruction +
+// both remainder products on one block-scaled e4m3 instruction (EquivariantGraphNeuralNetwork.py:15-16, :21-22; see that file's
+// header for the numerics) -- with the instruction shapes changed to
+//     v_mfma_f32_32x32x16_f16              (32 cycles, 4 per 32 x 32 tile and 64-deep chunk)
+//     v_mfma_scale_f32_32x32x64_f8f6f4     (64 cycles with e4m3 operands; K = 64 = [a_lo8 | a_hi8] of 32 hidden units against
+//                                           [W_hi8 ; W_lo8]: 2 per tile and chunk).
+// Why: the 16x16 kernels are stall-bound, not power-bound (held clock 2.38 GHz, MFMA pipe ~50 % busy: DESIGN.md section 4), and an
+// MFMA holds its SIMD's vector issue for 8 cycles whatever its shape (MI355X_MICROARCH.md, cycle constants): 48 MFMAs per wave and
+// chunk take 384 issue cycles out of the partner wave's activation build, 24 of the 32x32 shapes take 192 -- and there are half as
+// many operand waits.  (edge_x_m16.hip chose 16x16 tiles because its loop runs against the power limit at 2.1 GHz, where the
+// 16x16 shape holds a higher clock; that does not apply here.)
+// Same workgroup tile (128 edges; coordinate branch 512 columns = 2 column blocks of 32 per wave, message branch 256 columns = 1
+// per wave), same two schedules (late requests beside 128 accumulator registers, whole-chunk request distances beside 64), same
+// generated matrix-phase bodies (tools/gen/gen_c8_mphase.py w); the epilogues are the shared 32x32-accumulator ones of edge_tile.h.
+//   fp16 image of a chunk: [8 k-groups][129 rows][16 B] (row padding instead of an XOR swizzle: a lane's pieces of all four k-steps
+//   and row blocks are ONE base + immediates; the 8 lanes that store a row's pieces hit 8 different slots);
+//   e4m3 image: four K blocks [128 rows][32 B] at q * 4096 + 64 (q >> 1) (a store instruction's two blocks on the two halves of
+//   the store bank row), the two 16-byte halves of a row swapped in rows with bit 4 set (an operand read of 16 lanes covers rows
+//   0-3, 12-15 and 20-27 of one block: they then hit 16 different slots);
+//   weight streams: fp16 [N/32][K/16][64][8] (pack_frags_bf16<_Float16>), e4m3 [N/32][K/32][2][64][16 B] (pack_frags_c8w).
+#include <type_traits>
+
+#include "diag.h"
+#include "edge_tile.h"
+
+namespace egnn {
+
+namespace {
+
+using namespace tile128;
+constexpr int kT = 512;
+constexpr int kKC = 64;
+constexpr int kRPADW = kR + 1;
+constexpr size_t kA1W = (size_t)8 * kRPADW * 16;   // fp16 image of a chunk
+constexpr size_t kC8W = 4 * 4096 + 128;            // e4m3 image of a chunk
+__host__ __device__ constexpr size_t c8w_block(int q) { return (size_t)q * 4096 + 64 * (q >> 1); }
+__host__ __device__ inline size_t c8w_smem_bytes(int KP) { return kOffLoop + 2 * kA1W + 2 * kC8W + (size_t)KP * 4; }
+
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(2))) short i16x2;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+// SiLU + the three operand forms of one build unit (8 hidden units of one row), as unit_finish_c8 of edge_f16c8.hip
+__device__ __forceinline__ void unit_finish_c8w(const Unit& u, const float* wd, float d2, char* slot16, char* slot_lo, char* slot_hi) {
+  const f32x4 w0 = *reinterpret_cast<const f32x4*>(wd), w1 = *reinterpret_cast<const f32x4*>(wd + 4);
+  float a[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    a[j] = silu_s(fmaf(w0[j], d2, u.p0[j] + u.q0[j]));
+    a[j + 4] = silu_s(fmaf(w1[j], d2, u.p1[j] + u.q1[j]));
+  }
+  const f16x8 h = pack8<f16x8>(a);
+  if constexpr (diag::kC8NoCvt8) { *reinterpret_cast<f16x8*>(slot16) = h; return; }
+  float lo[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) lo[j] = a[j] - (float)h[j];
+  i16x2 l0 = {0, 0}, l1 = {0, 0}, h0 = {0, 0}, h1 = {0, 0};
+  l0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(l0, lo[0], lo[1], 0x1p-12f, false);
+  l0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(l0, lo[2], lo[3], 0x1p-12f, true);
+  l1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(l1, lo[4], lo[5], 0x1p-12f, false);
+  l1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(l1, lo[6], lo[7], 0x1p-12f, true);
+  h0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(h0, a[0], a[1], 0.5f, false);
+  h0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(h0, a[2], a[3], 0.5f, true);
+  h1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(h1, a[4], a[5], 0.5f, false);
+  h1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(h1, a[6], a[7], 0.5f, true);
+  *reinterpret_cast<f16x8*>(slot16) = h;
+  *reinterpret_cast<u32x2*>(slot_lo) = u32x2{__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1)};
+  *reinterpret_cast<u32x2*>(slot_hi) = u32x2{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
+}
+
+// CB = 32-column blocks per wave: 2 = coordinate branch (512 columns per workgroup), 1 = message branch (256 columns)
+template <bool IS_M, int CB>
+__global__ __launch_bounds__(kT, 2) void edge_c8w_kernel(const EdgeParams p) {
+  static_assert(IS_M ? CB == 1 : CB == 2, "coordinate branch: 2 column blocks per wave, message branch: 1");
+  f16_saturate_mode();
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const Lds L(smem);
+  char* s_a1 = smem + kOffLoop;             // [2 buffers] fp16 image
+  char* s_c8 = s_a1 + 2 * kA1W;             // [2 buffers] e4m3 image
+  float* s_wd = reinterpret_cast<float*>(s_c8 + 2 * kC8W);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int KP = IS_M ? p.WmP : p.WxP;
+  const int nsplit = IS_M ? 1 : p.WxP / 512;
+  const int j = xcd_tile(blockIdx.x, gridDim.x);
+  const int tile = j / nsplit, half = j - tile * nsplit;
+  const int e0 = tile * kR;
+  const int nvalid = min(kR, p.E - e0);
+  DIAG_STAMP_SETUP(p.stamps + ((size_t)(IS_M ? 1 : 0) * 8 + wave) * 32 * 4);
+  DIAG_STAMP(30, 0);
+
+  // ---- weight streams ----
+  const int NC = KP / kKC, KS16 = KP / 16, KS32 = KP / 32;
+  const int brow = tid >> 3, kg = tid & 7;   // this thread builds rows brow and brow + 64, hidden units 8 kg .. 8 kg + 7 of a chunk
+  const size_t ncols = IS_M ? (size_t)p.MP : (size_t)p.WxP;
+  const unsigned wbytes = diag::drop_weight_loads(p.dbg) ? 0u : (unsigned)(ncols * KP * 2);
+  const rsrc_t rs_w = make_rsrc(IS_M ? p.w2m : p.w2x, wbytes);        // fp16 fragments [N/32][K/16][64][8]
+  const rsrc_t rs_w8 = make_rsrc(IS_M ? p.w2m_c8 : p.w2x_c8, wbytes);   // e4m3 fragments [N/32][K/32][2][64][16 B]
+  const unsigned lane16 = lane * 16u;
+  const int cb0 = IS_M ? wave : half * 16 + wave * 2;            // first 32-column block of this wave
+  const unsigned w0 = (unsigned)cb0 * KS16 * 1024u;              // fp16 stream: 1 KiB per (column block, k-step of 16)
+  const unsigned w80 = (unsigned)cb0 * KS32 * 2048u;             // e4m3 stream: 2 KiB per (column block, 32 hidden units)
+  auto ld16 = [&](const int c, const int ks, const int cb) {     // fp16 fragment of (chunk c, k-step ks of 16, column block cb)
+    return ldbuf_v8<f16x8>(rs_w, lane16, w0 + ((unsigned)cb * KS16 + (unsigned)(4 * c + ks)) * 1024u);
+  };
+  auto ld8 = [&](const int c, const int t, const int cb) {       // e4m3 fragment (32 bytes per lane) of (chunk c, hidden half t, column block cb)
+    const unsigned o = w80 + ((unsigned)cb * KS32 + (unsigned)(2 * c + t)) * 2048u;
+    const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rs_w8, lane16, __builtin_amdgcn_readfirstlane(o), 0);
+    const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rs_w8, lane16, __builtin_amdgcn_readfirstlane(o + 1024u), 0);
+    return i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+  };
+  // message branch (64 accumulator registers): two register sets, set c & 1 for chunk c; coordinate branch: one set
+  constexpr int NSET = IS_M ? 2 : 1;
+  f16x8 bq[NSET][4][CB];   // [set][k-step of 16][column block]
+  i32x8 b8[NSET][2][CB];   // [set][hidden half][column block]
+
+  prologue_rows(p, L, e0, nvalid, IS_M ? p.wdm : p.wdx, KP, s_wd, tid);
+  DIAG_STAMP(30, 1);
+
+  // ---- K loop ----
+  const rsrc_t rs_tab = make_rsrc(p.table, diag::drop_table_loads(p.dbg) ? 0u : (unsigned)min((size_t)p.N * p.TC * 4, (size_t)0xFFFFFFFFu));
+  const unsigned vdst0 = (unsigned)L.dst[brow] * (unsigned)p.TC * 4u + (unsigned)kg * 32u;
+  const unsigned vsrc0 = (unsigned)L.src[brow] * (unsigned)p.TC * 4u + (unsigned)kg * 32u;
+  const unsigned vdst1 = (unsigned)L.dst[brow + 64] * (unsigned)p.TC * 4u + (unsigned)kg * 32u;
+  const unsigned vsrc1 = (unsigned)L.src[brow + 64] * (unsigned)p.TC * 4u + (unsigned)kg * 32u;
+  const unsigned offP = (IS_M ? 2u * p.WxP : 0u) * 4u, offQ = (IS_M ? 2u * p.WxP + p.WmP : (unsigned)p.WxP) * 4u;   // fp32 table {Px|Qx|Pm|Qm}
+  // store slots of this thread (rows brow, brow + 64).  e4m3: hidden units 8 kg .. + 7 sit in block 2 (kg >> 2) (remainder) / + 1
+  // (value), bytes 8 (kg & 3) .. + 7 of the row's 32, the 16-byte halves swapped in rows with bit 4 set (same for brow + 64)
+  char* slot0 = s_a1 + ((size_t)kg * kRPADW + brow) * 16;
+  const unsigned sw = ((unsigned)brow >> 4) & 1u;
+  char* slo0 = s_c8 + (size_t)(kg >> 2) * (c8w_block(2) - c8w_block(0)) + (size_t)brow * 32 + ((((unsigned)kg >> 1) & 1u) ^ sw) * 16u + (unsigned)(kg & 1) * 8u;
+  constexpr int shi_delta = (int)(c8w_block(1) - c8w_block(0));
+  // operand reads of this lane: fp16 pieces (row r of a row block, k-group 2 ks + hh) = ONE base + immediates; e4m3 operands
+  // (row r, block 2 t + hh): the half that holds hidden units 0-15 of the block first, then the other
+  const unsigned abase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(s_a1 + ((size_t)hh * kRPADW + r) * 16);
+  const unsigned lds8 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)s_c8;
+  const unsigned rsw = ((unsigned)r >> 4) & 1u;
+  const unsigned cbaseA = lds8 + (unsigned)hh * 4096u + (unsigned)r * 32u + rsw * 16u;
+  const unsigned cbaseB = cbaseA ^ 16u;
+  constexpr int kScaleA = 127 - 12;   // block scales: see edge_f16c8.hip (both kinds of block need the same product of scales)
+  const int scale_b = __builtin_amdgcn_readfirstlane((IS_M ? p.c8_exp + 2 : p.c8_exp)[0]);
+
+  f32x16 acc[4][CB];
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[rb][cb][i] = 0.f;
+
+  Unit ua0, ua1;
+  auto vload0 = [&](const int cq) {
+    const int c = cq < NC ? cq : NC - 1;   // past the end: a harmless repeat
+    unit_load(ua0, rs_tab, vdst0, vsrc0, offP + (unsigned)c * kKC * 4u, offQ + (unsigned)c * kKC * 4u);
+  };
+  auto vload1 = [&](const int cq) {
+    const int c = cq < NC ? cq : NC - 1;
+    unit_load(ua1, rs_tab, vdst1, vsrc1, offP + (unsigned)c * kKC * 4u, offQ + (unsigned)c * kKC * 4u);
+  };
+  auto vrow = [&](auto par_c, auto row_c, const int c) {
+    constexpr int PAR = decltype(par_c)::value, ROW = decltype(row_c)::value;
+    unit_finish_c8w(ROW ? ua1 : ua0, s_wd + c * kKC + kg * 8, L.d2[brow + 64 * ROW], slot0 + PAR * kA1W + ROW * 64 * 16,
+                    slo0 + PAR * kC8W + ROW * 64 * 32, slo0 + PAR * kC8W + ROW * 64 * 32 + shi_delta);
+  };
+  const std::integral_constant<int, 0> P0;
+  const std::integral_constant<int, 1> P1;
+  int S = 0;
+
+#define LDS_RD(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(off))
+#define LDS_WAIT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
+#define MAIN_STEP(A, KSTEP, RB)                                                                                          \
+  do {                                                                                                                   \
+    asm volatile("" : "+v"(A));                                                                                          \
+    if constexpr (!diag::kC8NoMain) {                                                                                    \
+      _Pragma("unroll") for (int cb = 0; cb < CB; ++cb)                                                                  \
+          acc[RB][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, BQ(KSTEP)[cb], acc[RB][cb], 0, 0, 0);                  \
+    } else {                                                                                                             \
+      asm volatile("" ::"v"(BQ(KSTEP)[0]), "v"(BQ(KSTEP)[CB - 1]));                                                      \
+    }                                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  } while (0)
+#define CORR_STEP(C0, C1, T, RB)                                                                                         \
+  do {                                                                                                                   \
+    if constexpr (!diag::kC8NoCorr) {                                                                                    \
+      asm volatile("" : "+v"(C0), "+v"(C1));                                                                             \
+      const u32x4 x0_ = C0, x1_ = C1;                                                                                    \
+      const i32x8 a8_ = {(int)x0_.x, (int)x0_.y, (int)x0_.z, (int)x0_.w, (int)x1_.x, (int)x1_.y, (int)x1_.z, (int)x1_.w}; \
+      _Pragma("unroll") for (int cb = 0; cb < CB; ++cb)                                                                  \
+          acc[RB][cb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8_, B8(T)[cb], acc[RB][cb], 0, 0, 0, kScaleA, 0, scale_b); \
+    } else {                                                                                                             \
+      asm volatile("" ::"v"(B8(T)[0]), "v"(B8(T)[CB - 1]));                                                              \
+    }                                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  } while (0)
+
+  if constexpr (IS_M) {
+    // ================= message branch: 64 accumulator registers leave room for whole-chunk request distances =================
+    auto wload = [&](auto par_c, const int cq) {
+      constexpr int PAR = decltype(par_c)::value;
+      const int c = cq < NC ? cq : NC - 1;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) bq[PAR][ks][cb] = ld16(c, ks, cb);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) b8[PAR][t][cb] = ld8(c, t, cb);
+    };
+    auto vfinish = [&](auto par_c, const int c) {
+      if constexpr (diag::kC8NoBuild) { if (c > 1) { asm volatile("" :: "v"(ua0.p0), "v"(ua0.p1), "v"(ua0.q0), "v"(ua0.q1), "v"(ua1.p0), "v"(ua1.p1), "v"(ua1.q0), "v"(ua1.q1)); return; } }
+      __builtin_amdgcn_s_setprio(3);
+      vrow(par_c, P0, c);
+      vrow(par_c, P1, c);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    auto vload = [&](const int cq) { vload0(cq); vload1(cq); };
+    vload(0);
+    wload(P0, 0);
+    S = prologue_segments<false>(p, L, e0, nvalid, tid, lane, wave);
+    vfinish(P0, 0);
+    vload(1);
+    __syncthreads();
+    DIAG_STAMP(30, 2);
+    DIAG_RSTAMP(31, 1);
+    auto mphase = [&](auto par_c, auto npar_c, const int c, const bool last) {
+      constexpr int PAR = decltype(par_c)::value;
+      constexpr int kO16 = PAR * (int)kA1W, kO8 = PAR * (int)kC8W;
+      f16x8 a[8];
+      u32x4 c0[4], c1[4];
+#define BQ(ks) bq[PAR][ks]
+#define B8(t) b8[PAR][t]
+#define MPHASE_AFTER_FIRST_READS if (!last) wload(npar_c, c + 1)
+#define MPHASE_AFTER_KSTEP0
+#define MPHASE_AFTER_KSTEP1
+#include "edge_f16c8w_mphase1.inc"
+#undef MPHASE_AFTER_KSTEP1
+#undef MPHASE_AFTER_KSTEP0
+#undef MPHASE_AFTER_FIRST_READS
+#undef B8
+#undef BQ
+    };
+    if (wave < 4) {
+      const int my_mode = tid < S ? segment_mode(p, L, e0, tid) : 0;
+      DIAG_STAMP(0, 0);
+      mphase(P0, P1, 0, false);
+      DIAG_STAMP(0, 1);
+      if (tid < S) L.seg_mode[tid] = my_mode;
+      vfinish(P1, 1); vload(2);
+      DIAG_STAMP(0, 2);
+      __syncthreads();
+      DIAG_STAMP(0, 3);
+      for (int i = 1; i + 1 < NC - 1; i += 2) {
+        DIAG_STAMP(i, 0); mphase(P1, P0, i, false); DIAG_STAMP(i, 1); vfinish(P0, i + 1); vload(i + 2); DIAG_STAMP(i, 2); __syncthreads(); DIAG_STAMP(i, 3);
+        DIAG_STAMP(i + 1, 0); mphase(P0, P1, i + 1, false); DIAG_STAMP(i + 1, 1); vfinish(P1, i + 2); vload(i + 3); DIAG_STAMP(i + 1, 2); __syncthreads(); DIAG_STAMP(i + 1, 3);
+      }
+    } else {
+      DIAG_STAMP(0, 0);
+      vfinish(P1, 1); vload(2);
+      DIAG_STAMP(0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mphase(P0, P1, 0, false);
+      DIAG_STAMP(0, 2);
+      __syncthreads();
+      DIAG_STAMP(0, 3);
+      for (int i = 1; i + 1 < NC - 1; i += 2) {
+        DIAG_STAMP(i, 0); vfinish(P0, i + 1); vload(i + 2); DIAG_STAMP(i, 1); __builtin_amdgcn_sched_barrier(0); mphase(P1, P0, i, false); DIAG_STAMP(i, 2); __syncthreads(); DIAG_STAMP(i, 3);
+        DIAG_STAMP(i + 1, 0); vfinish(P1, i + 2); vload(i + 3); DIAG_STAMP(i + 1, 1); __builtin_amdgcn_sched_barrier(0); mphase(P0, P1, i + 1, false); DIAG_STAMP(i + 1, 2); __syncthreads(); DIAG_STAMP(i + 1, 3);
+      }
+    }
+    DIAG_STAMP(NC - 1, 0);
+    mphase(P1, P0, NC - 1, true);
+    DIAG_STAMP(NC - 1, 1);
+  } else {
+    // ================= coordinate branch: 128 accumulator registers; every operand group is requested as late as its latency
+    // allows and no two 32-register groups are live together (the schedule of edge_f16c8.hip's 4-column-block kernel) =================
+    //   fp16 fragments of k-steps 2, 3 of chunk c   at the start of its matrix phase
+    //   e4m3 fragments of chunk c                   behind its k-step 1
+    //   table rows of the next build: row 0         behind k-step 3; row 1 at the start of the build
+    //   fp16 fragments of k-steps 0, 1 of the next matrix phase: between the two rows of the build in front of it
+    auto wload16 = [&](const int cq, const int s) {   // k-steps 2 s, 2 s + 1 of chunk cq
+      const int c = cq < NC ? cq : NC - 1;
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) bq[0][2 * s + k2][cb] = ld16(c, 2 * s + k2, cb);
+    };
+    auto wload8 = [&](const int c) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) b8[0][t][cb] = ld8(c, t, cb);
+    };
+    auto vfinish = [&](auto par_c, const int c, const int mchunk) {
+      __builtin_amdgcn_s_setprio(3);
+      vload1(c);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(diag::kC8NoBuild && c > 1)) vrow(par_c, P0, c);
+      else asm volatile("" :: "v"(ua0.p0), "v"(ua0.p1), "v"(ua0.q0), "v"(ua0.q1));
+      __builtin_amdgcn_sched_barrier(0);
+      DIAG_STAMP2(c + 15, 3, c >= 1 && c < 15);
+      wload16(mchunk, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(diag::kC8NoBuild && c > 1)) vrow(par_c, P1, c);
+      else asm volatile("" :: "v"(ua1.p0), "v"(ua1.p1), "v"(ua1.q0), "v"(ua1.q1));
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    vload0(0);
+    S = prologue_segments<false>(p, L, e0, nvalid, tid, lane, wave);
+    vfinish(P0, 0, 0);
+    if (wave >= 4) vload0(1);
+    __syncthreads();
+    DIAG_STAMP(30, 2);
+    DIAG_RSTAMP(31, 1);
+    auto mphase = [&](auto par_c, const int c, const int tab_chunk) {
+      constexpr int PAR = decltype(par_c)::value;
+      constexpr int kO16 = PAR * (int)kA1W, kO8 = PAR * (int)kC8W;
+      f16x8 a[3];
+      u32x4 c0[2], c1[2];
+#define BQ(ks) bq[0][ks]
+#define B8(t) b8[0][t]
+#define MPHASE_AFTER_FIRST_READS do { __builtin_amdgcn_sched_barrier(0); wload16(c, 1); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define MPHASE_AFTER_KSTEP0 do { DIAG_STAMP2(c + 16, 0, c < 14); wload8(c); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define MPHASE_AFTER_KSTEP1 do { DIAG_STAMP2(c + 16, 1, c < 14); if (tab_chunk >= 0) vload0(tab_chunk); __builtin_amdgcn_sched_barrier(0); } while (0)
+#include "edge_f16c8w_mphase2.inc"
+      DIAG_STAMP2(c + 16, 2, c < 14);
+#undef MPHASE_AFTER_KSTEP1
+#undef MPHASE_AFTER_KSTEP0
+#undef MPHASE_AFTER_FIRST_READS
+#undef B8
+#undef BQ
+    };
+    if (wave < 4) {
+      const int my_mode = tid < S ? segment_mode(p, L, e0, tid) : 0;
+      DIAG_STAMP(0, 0);
+      mphase(P0, 0, 1);
+      DIAG_STAMP(0, 1);
+      if (tid < S) L.seg_mode[tid] = my_mode;
+      vfinish(P1, 1, 1);
+      DIAG_STAMP(0, 2);
+      __syncthreads();
+      DIAG_STAMP(0, 3);
+      for (int i = 1; i + 1 < NC - 1; i += 2) {
+        DIAG_STAMP(i, 0); mphase(P1, i, i + 1); DIAG_STAMP(i, 1); vfinish(P0, i + 1, i + 1); DIAG_STAMP(i, 2); __syncthreads(); DIAG_STAMP(i, 3);
+        DIAG_STAMP(i + 1, 0); mphase(P0, i + 1, i + 2); DIAG_STAMP(i + 1, 1); vfinish(P1, i + 2, i + 2); DIAG_STAMP(i + 1, 2); __syncthreads(); DIAG_STAMP(i + 1, 3);
+      }
+    } else {
+      DIAG_STAMP(0, 0);
+      vfinish(P1, 1, 0);
+      DIAG_STAMP(0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mphase(P0, 0, 2);
+      DIAG_STAMP(0, 2);
+      __syncthreads();
+      DIAG_STAMP(0, 3);
+      for (int i = 1; i + 1 < NC - 1; i += 2) {
+        DIAG_STAMP(i, 0); vfinish(P0, i + 1, i); DIAG_STAMP(i, 1); __builtin_amdgcn_sched_barrier(0); mphase(P1, i, i + 2); DIAG_STAMP(i, 2); __syncthreads(); DIAG_STAMP(i, 3);
+        DIAG_STAMP(i + 1, 0); vfinish(P1, i + 2, i + 1); DIAG_STAMP(i + 1, 1); __builtin_amdgcn_sched_barrier(0); mphase(P0, i + 1, i + 3); DIAG_STAMP(i + 1, 2); __syncthreads(); DIAG_STAMP(i + 1, 3);
+      }
+      wload16(NC - 1, 0);
+    }
+    DIAG_STAMP(NC - 1, 0);
+    mphase(P1, NC - 1, -1);
+    DIAG_STAMP(NC - 1, 1);
+  }
+#undef CORR_STEP
+#undef MAIN_STEP
+#undef LDS_WAIT
+#undef LDS_RD
+  __syncthreads();
+  DIAG_STAMP(NC - 1, 3);
+  DIAG_STAMP(30, 3);
+  DIAG_RSTAMP(31, 2);
+
+  // ---- epilogue: the shared 32x32-accumulator forms (edge_tile.h); the weight fragments carry 2^8 ----
+  constexpr float kAcc = kNegLog2e / kF16WScale;
+  if constexpr (diag::kC8NoEpi) {
+    float v = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v += acc[rb][cb][i];
+    if (v == 123.456f) p.agg_x[0] = v;
+    return;
+  }
+  if constexpr (IS_M) {
+    message_epilogue(p, L, acc, S, tile, tid, lane, wave, kAcc);
+  } else {
+    x_head<CB>(p, L, acc, cb0, half, tid, lane, wave, kAcc);
+    coordinate_segment_sums(p, L, S, tile, half, tid, lane, wave);
+  }
+  DIAG_STAMP(31, 0);
+}
+
+// e4m3 B fragments of the correction product for v_mfma_scale_f32_32x32x64_f8f6f4, one instruction per 32 hidden units:
+//   out[((nb * KS32 + t) * 2 + piece) * 1024 + lane * 16 + j],  lane l: column 32 nb + (l & 31), K block h = l >> 5
+//   block 0 holds e4m3(2^s_hi W_hi), block 1 e4m3(2^s_lo W_lo) of hidden units 32 t + [0, 32); register piece `piece` holds hidden
+//   units 16 piece .. + 15 of the block.  Scale exponents from *maxbits as pack_frags_c8 (c8_absmax_kernel ran before).
+__global__ void pack_frags_c8w(const float* __restrict__ W, int Nout, int K, int ldw, int NP, int KP, unsigned char* __restrict__ out,
+                               float scale, const unsigned* __restrict__ maxbits) {
+  __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);   // MODE.FP16_OVFL: the conversions saturate
+  const int KS32 = KP / 32;
+  const float mx = fminf(__builtin_bit_cast(float, *maxbits), 65504.f);
+  int s_hi = 0;
+  if (mx > 0.f) s_hi = (int)floorf(log2f(224.0f / mx));
+  s_hi = s_hi > 40 ? 40 : (s_hi < -40 ? -40 : s_hi);
+  const float inv_hi = __builtin_ldexpf(1.0f, -s_hi), inv_lo = __builtin_ldexpf(1.0f, -s_hi - 11);
+  const size_t total = (size_t)(NP / 32) * KS32 * 2 * 64 * 8;   // byte PAIRS
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int jp = i & 7, lane = (i >> 3) & 63, piece = (i >> 9) & 1;
+    const size_t f = i >> 10;
+    const int t = f % KS32, nb = f / KS32;
+    const int h = lane >> 5, n = 32 * nb + (lane & 31);
+    const int k = 32 * t + 16 * piece + 2 * jp;
+    float v[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      float w = (n < Nout && k + q < K) ? W[(size_t)n * ldw + k + q] * scale : 0.f;
+      w = fminf(fmaxf(w, -65504.f), 65504.f);
+      const float hi = (float)(_Float16)w;
+      v[q] = h ? w - hi : hi;
+    }
+    typedef __attribute__((ext_vector_type(2))) short i16x2_;
+    i16x2_ rr = {0, 0};
+    rr = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(rr, v[0], v[1], h ? inv_lo : inv_hi, false);
+    reinterpret_cast<unsigned short*>(out)[i] = (unsigned short)rr.x;
+  }
+}
+
+}  // namespace
+
+int init_edge_f16c8w_attributes() {
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_c8w_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_c8w_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  return EGNN_OK;
+}
+
+// shapes: hidden width 512 / 1024 (512-column workgroups), 256 message columns; p.w2x / p.w2m = the fp16 32-column streams,
+// p.w2x_c8 / p.w2m_c8 = the e4m3 streams of pack_c8w_stream
+bool edge_f16c8w_supported(const EdgeParams& p) {
+  return (p.WxP == 512 || p.WxP == 1024) && p.MP == 256 && p.WmP % 128 == 0 && p.WmP >= 128 && p.w2x && p.w2m && p.w2x_c8 && p.w2m_c8 && p.c8_exp &&
+         c8w_smem_bytes(p.WxP) <= 160 * 1024 && c8w_smem_bytes(p.WmP) <= 160 * 1024 && (size_t)p.N * p.TC * 4 < ((size_t)1 << 32);
+}
+
+int launch_edge_f16c8w_x(const EdgeParams& p, hipStream_t st) {
+  const int tiles = (p.E + kR - 1) / kR;
+  hipLaunchKernelGGL((edge_c8w_kernel<false, 2>), dim3(tiles * (p.WxP / 512)), dim3(kT), c8w_smem_bytes(p.WxP), st, p);
+  EGNN_HIP(hipGetLastError());
+  return EGNN_OK;
+}
+int launch_edge_f16c8w_m(const EdgeParams& p, hipStream_t st) {
+  const int tiles = (p.E + kR - 1) / kR;
+  hipLaunchKernelGGL((edge_c8w_kernel<true, 1>), dim3(tiles), dim3(kT), c8w_smem_bytes(p.WmP), st, p);
+  EGNN_HIP(hipGetLastError());
+  return EGNN_OK;
+}
+
+// e4m3 stream for the 32x32x64 instruction; maxbits: the matrix's largest |w| as float bits (pack_c8_stream ran before: it also
+// wrote the scale exponents the edge kernels read)
+int pack_c8w_stream(const float* W, int Nout, int K, int ldw, int NP, int KP, void* out, float scale, const unsigned* maxbits,
+                    hipStream_t st) {
+  hipLaunchKernelGGL(pack_frags_c8w, dim3(256), dim3(256), 0, st, W, Nout, K, ldw, NP, KP, static_cast<unsigned char*>(out), scale, maxbits);
+  EGNN_HIP(hipGetLastError());
+  return EGNN_OK;
+}
+
+}  // namespace egnn

@@ -170,9 +170,10 @@ __device__ __forceinline__ void coordinate_segment_sums(const EdgeParams& p, con
 
 // Head of the coordinate branch (:62-63): L.val[row] = [b3 +] sum over this workgroup's columns of w3[n] SiLU(a2[row][n]),
 // the bias only in column share 0.  Ends behind a barrier (L.val ordered for every thread).
+// acc_scale: t2 = acc_scale * acc + b2 (-log2(e); the fp16 streams of precision f16c8 carry 2^8, divided out here)
 template <int CB>
 __device__ __forceinline__ void x_head(const EdgeParams& p, const Lds& L, const f32x16 (&acc)[4][CB], int colblk0, int half,
-                                       int tid, int lane, int wave) {
+                                       int tid, int lane, int wave, const float acc_scale = kNegLog2e) {
   const int r = lane & 31;
   float part[64];
 #pragma unroll
@@ -184,7 +185,7 @@ __device__ __forceinline__ void x_head(const EdgeParams& p, const Lds& L, const 
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) part[rb * 16 + i] = fmaf(w, silu_s(fmaf(acc[rb][cb][i], kNegLog2e, bb)), part[rb * 16 + i]);
+      for (int i = 0; i < 16; ++i) part[rb * 16 + i] = fmaf(w, silu_s(fmaf(acc[rb][cb][i], acc_scale, bb)), part[rb * 16 + i]);
   }
   {
     float lo[32], hi[32];

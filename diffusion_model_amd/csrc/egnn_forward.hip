@@ -1028,6 +1028,7 @@ int init_kernel_attributes() {
   if ((rc = init_edge_x_m16_attributes())) return rc;
   if ((rc = init_edge_bf16x3_attributes())) return rc;
   if ((rc = init_edge_f16c8_attributes())) return rc;
+  if ((rc = init_edge_f16c8w_attributes())) return rc;
   done = true;
   return EGNN_OK;
 }
@@ -1302,19 +1303,27 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
       rc = launch_edge_bf16x3(p, st);
     } else if (path == 7) {   // precision f16c8 (edge_f16c8.hip): fp16 16-column streams + e4m3 correction streams
       R = 128;
-      nsplit_x = edge_f16c8_x_split(p.WxP);
       p.w2x16 = lp.w2x_f16s16; p.w2m16 = lp.w2m_f16s16;
+      // matrix tile shape: 32x32 (edge_f16c8w.hip) / 16x16 (edge_f16c8.hip); EGNN_C8_TILE = A/B switch
+      static const int c8_tile = getenv("EGNN_C8_TILE") ? atoi(getenv("EGNN_C8_TILE")) : 16;
+      bool wide = false;
+      if (c8_tile == 32) {
+        EdgeParams q = p;
+        q.w2x = lp.w2x_f16s; q.w2m = lp.w2m_f16s; q.w2x_c8 = lp.w2x_c8w; q.w2m_c8 = lp.w2m_c8w;
+        if (edge_f16c8w_supported(q)) { p = q; wide = true; }
+      }
+      nsplit_x = wide ? p.WxP / 512 : edge_f16c8_x_split(p.WxP);
       const bool fork = !c->prof && st != nullptr && c->side != nullptr && c->ev_fork != nullptr && fork_candidate(E, p.WxP);
       if (fork) {
         EGNN_HIP(hipEventRecord(c->ev_fork, st));
         EGNN_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-        rc = launch_edge_f16c8_x(p, st);
-        if (!rc) rc = launch_edge_f16c8_m(p, c->side);
+        rc = wide ? launch_edge_f16c8w_x(p, st) : launch_edge_f16c8_x(p, st);
+        if (!rc) rc = wide ? launch_edge_f16c8w_m(p, c->side) : launch_edge_f16c8_m(p, c->side);
         EGNN_HIP(hipEventRecord(c->ev_join, c->side));
         EGNN_HIP(hipStreamWaitEvent(st, c->ev_join, 0));
       } else {
-        rc = launch_edge_f16c8_x(p, st);
-        if (!rc) rc = launch_edge_f16c8_m(p, st);
+        rc = wide ? launch_edge_f16c8w_x(p, st) : launch_edge_f16c8_x(p, st);
+        if (!rc) rc = wide ? launch_edge_f16c8w_m(p, st) : launch_edge_f16c8_m(p, st);
       }
     } else if ((path == 6 || path == 4) && !c->save_s1x && small_tiles(c, p) != 0) {
       // small graphs (the reference's per-call workload): 32-edge tiles, weight-stream-bound workgroups (edge_small.hip);
@@ -1498,7 +1507,7 @@ static void free_layer(LayerPack& lp) {
                   lp.w2m_bf16, lp.b2m, lp.wa, lp.scal, lp.w1h_f32, lp.b1h, lp.w2h_f32, lp.b2h, lp.sc, lp.w2x_bf16s, lp.w2m_bf16s, lp.w1h_bf16, lp.w2h_bf16p,
                   lp.w2xT_bf16, lp.w2mT_bf16, lp.w1hl_bf16, lp.w2x_bf16s16, lp.w2x_bf16s_lo, lp.w2m_bf16s_lo,
                   lp.w2x_f16s16, lp.w2m_f16s, lp.w1h_f16, lp.w2h_f16p, lp.w1h_f16k, lp.w1h_f16k_lo, lp.w2h_f16p_lo,
-                  lp.w2m_bf16s16, lp.w2m_f16s16, lp.w2x_c8, lp.w2m_c8, lp.c8_exp};
+                  lp.w2m_bf16s16, lp.w2m_f16s16, lp.w2x_c8, lp.w2m_c8, lp.c8_exp, lp.w2x_f16s, lp.w2x_c8w, lp.w2m_c8w};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   lp = LayerPack();
@@ -1628,6 +1637,12 @@ int egnn_pack_layer(egnn_ctx* c, void* stream, int l, const float* m0_w, const f
     lp.w2x_c8 = tmp; tmp = nullptr;
     if ((rc = dev_alloc(&tmp, (size_t)MP * WmP))) return rc;
     lp.w2m_c8 = tmp; tmp = nullptr;
+    if ((rc = dev_alloc(&tmp, (size_t)WxP * WxP))) return rc;
+    lp.w2x_f16s = tmp; tmp = nullptr;
+    if ((rc = dev_alloc(&tmp, (size_t)WxP * WxP))) return rc;
+    lp.w2x_c8w = tmp; tmp = nullptr;
+    if ((rc = dev_alloc(&tmp, (size_t)MP * WmP))) return rc;
+    lp.w2m_c8w = tmp; tmp = nullptr;
     if ((rc = dev_alloc(&lp.c8_exp, (size_t)8))) return rc;   // [0..3] scale exponents {x: hi, lo, m: hi, lo}, [4..5] max |w| scratch
   }
   const dim3 g(256), b(256);
@@ -1679,6 +1694,10 @@ int egnn_pack_layer(egnn_ctx* c, void* stream, int l, const float* m0_w, const f
     // precision f16c8: the same scaled weights as e4m3 head / remainder fragments for the block-scaled correction product
     if ((rc = pack_c8_stream(x2_w, Wx, Wx, Wx, WxP, WxP, lp.w2x_c8, s2 * kF16WScale, lp.c8_exp, reinterpret_cast<unsigned*>(lp.c8_exp + 4), st))) return rc;
     if ((rc = pack_c8_stream(m2_w, M, Wm, Wm, MP, WmP, lp.w2m_c8, s2 * kF16WScale, lp.c8_exp + 2, reinterpret_cast<unsigned*>(lp.c8_exp + 5), st))) return rc;
+    // ... and for the 32x32 tiles of edge_f16c8w.hip (same scale exponents)
+    hipLaunchKernelGGL(pack_frags_bf16<_Float16>, g, b, 0, st, x2_w, Wx, Wx, Wx, WxP, WxP, reinterpret_cast<_Float16*>(lp.w2x_f16s), s2 * kF16WScale);
+    if ((rc = pack_c8w_stream(x2_w, Wx, Wx, Wx, WxP, WxP, lp.w2x_c8w, s2 * kF16WScale, reinterpret_cast<unsigned*>(lp.c8_exp + 4), st))) return rc;
+    if ((rc = pack_c8w_stream(m2_w, M, Wm, Wm, MP, WmP, lp.w2m_c8w, s2 * kF16WScale, reinterpret_cast<unsigned*>(lp.c8_exp + 5), st))) return rc;
     hipLaunchKernelGGL(pack_frags_bf16_lo, g, b, 0, st, x2_w, Wx, Wx, Wx, WxP, WxP, reinterpret_cast<__bf16*>(lp.w2x_bf16s_lo), s2);
     hipLaunchKernelGGL(pack_frags_bf16_lo, g, b, 0, st, m2_w, M, Wm, Wm, MP, WmP, reinterpret_cast<__bf16*>(lp.w2m_bf16s_lo), s2);
     hipLaunchKernelGGL(pack_frags_bf16<__bf16>, g, b, 0, st, h0_w, Wh, H + M, H + M, WhP, c->K1Q, reinterpret_cast<__bf16*>(lp.w1h_bf16), 1.0f);

@@ -349,6 +349,13 @@ int launch_edge_f16c8_m(const EdgeParams& p, hipStream_t st);
 bool edge_f16c8_supported(const EdgeParams& p);
 int edge_f16c8_x_split(int WxP);
 int init_edge_f16c8_attributes();
+// the same precision on 32x32 matrix tiles (edge_f16c8w.hip); p.w2x / p.w2m = the fp16 32-column streams, p.w2x_c8 / p.w2m_c8 =
+// the e4m3 streams of pack_c8w_stream (scale exponents: those pack_c8_stream wrote)
+int launch_edge_f16c8w_x(const EdgeParams& p, hipStream_t st);
+int launch_edge_f16c8w_m(const EdgeParams& p, hipStream_t st);
+bool edge_f16c8w_supported(const EdgeParams& p);
+int init_edge_f16c8w_attributes();
+int pack_c8w_stream(const float* W, int Nout, int K, int ldw, int NP, int KP, void* out, float scale, const unsigned* maxbits, hipStream_t st);
 int pack_c8_stream(const float* W, int Nout, int K, int ldw, int NP, int KP, void* out, float scale, int* exps, unsigned* maxbits,
                    hipStream_t st);
 

@@ -1,18 +1,27 @@
 #!/usr/bin/env python3
 """Generates the fully unrolled matrix-phase bodies of csrc/edge_f16c8.hip (the inline-asm LDS reads need compile-time offsets and
 register-ring slots, and every s_waitcnt lgkmcnt count depends on what was issued since the read it waits for).
-usage: python tools/gen/gen_c8_mphase.py {2|4}  -> C++ text for the body of `mphase` at CB column blocks per wave
+usage: python tools/gen/gen_c8_mphase.py {2|4}  -> C++ text for the body of `mphase` at CB 16-column blocks per wave (16x16 tiles)
+       python tools/gen/gen_c8_mphase.py w {1|2} -> the same for the 32x32-tile kernels (edge_f16c8w.hip) at CB 32-column blocks per wave:
+         16 fp16 pieces = 4 k-steps of 16 x 4 row blocks of 32 (padded image: k-group stride 129 rows), 8 e4m3 operands = 2
+         instructions (32 hidden units each) x 4 row blocks, two 16-byte reads each from bases that differ in the swizzled half
   CB = 2: an fp16 piece feeds 32 cycles of MFMAs, an e4m3 operand 64: rings of 8 pieces / 4 operands (256 cycles ahead)
   CB = 4: 64 / 128 cycles: rings of 3 pieces / 2 operands (as edge_x_m16.hip); the first e4m3 operands are requested under the
           last fp16 MFMAs in both"""
 import sys
 
-CB = int(sys.argv[1])
+WIDE = sys.argv[1] == "w"
+CB = int(sys.argv[2]) * 2 if WIDE else int(sys.argv[1])     # in 16-column units: the same ring arithmetic
 import os
 RA, RC = (8, 4) if CB == 2 else (int(os.environ.get('C8_RA', 3)), int(os.environ.get('C8_RC', 2)))          # ring depths (C8_RA / C8_RC: experiments)
 out = []
-P = lambda u: f"LDS_RD(a[{u % RA}], {'abase1' if u >= 8 else 'abase0'}, kO16 + {256 * (u & 7)});"
-C = lambda v: f"LDS_RD(c0[{v % RC}], cbase, kO8 + {512 * v}); LDS_RD(c1[{v % RC}], cbase, kO8 + {512 * v + 16});"
+if WIDE:
+    P = lambda u: f"LDS_RD(a[{u % RA}], abase, kO16 + {(u >> 2) * 4128 + (u & 3) * 512});"
+    C = lambda v: (f"LDS_RD(c0[{v % RC}], cbaseA, kO8 + {(v >> 2) * 8256 + (v & 3) * 1024}); "
+                   f"LDS_RD(c1[{v % RC}], cbaseB, kO8 + {(v >> 2) * 8256 + (v & 3) * 1024});")
+else:
+    P = lambda u: f"LDS_RD(a[{u % RA}], {'abase1' if u >= 8 else 'abase0'}, kO16 + {256 * (u & 7)});"
+    C = lambda v: f"LDS_RD(c0[{v % RC}], cbase, kO8 + {512 * v}); LDS_RD(c1[{v % RC}], cbase, kO8 + {512 * v + 16});"
 # issue order: list of ("P", u) / ("C", v) / ("useP", u) / ("useC", v)
 seq = [("P", u) for u in range(RA)]
 nextP, nextC = RA, 0
@@ -47,7 +56,7 @@ for i, (kind, idx) in enumerate(seq):
         if first:
             out.append("    MPHASE_AFTER_FIRST_READS;")
             first = False
-        s, rb = idx >> 3, idx & 7
+        s, rb = (idx >> 2, idx & 3) if WIDE else (idx >> 3, idx & 7)
         out.append(f"    LDS_WAIT({younger(i, 'P', idx)});")
         out.append(f"    MAIN_STEP(a[{idx % RA}], {s}, {rb});")
         if idx == 7:
@@ -56,5 +65,8 @@ for i, (kind, idx) in enumerate(seq):
             out.append("    MPHASE_AFTER_KSTEP1;")
     else:
         out.append(f"    LDS_WAIT({younger(i, 'C', idx)});")
-        out.append(f"    CORR_STEP(c0[{idx % RC}], c1[{idx % RC}], {idx});")
+        if WIDE:
+            out.append(f"    CORR_STEP(c0[{idx % RC}], c1[{idx % RC}], {idx >> 2}, {idx & 3});")
+        else:
+            out.append(f"    CORR_STEP(c0[{idx % RC}], c1[{idx % RC}], {idx});")
 print("\n".join(out))
