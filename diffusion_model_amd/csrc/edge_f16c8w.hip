@@ -235,7 +235,9 @@ __global__ __launch_bounds__(kT, 2) void edge_c8w_kernel(const EdgeParams p) {
 #define MPHASE_AFTER_FIRST_READS if (!last) wload(npar_c, c + 1)
 #define MPHASE_AFTER_KSTEP0
 #define MPHASE_AFTER_KSTEP1
+#define MPHASE_AFTER_CORR0
 #include "edge_f16c8w_mphase1.inc"
+#undef MPHASE_AFTER_CORR0
 #undef MPHASE_AFTER_KSTEP1
 #undef MPHASE_AFTER_KSTEP0
 #undef MPHASE_AFTER_FIRST_READS
@@ -274,12 +276,12 @@ __global__ __launch_bounds__(kT, 2) void edge_c8w_kernel(const EdgeParams p) {
     mphase(P1, P0, NC - 1, true);
     DIAG_STAMP(NC - 1, 1);
   } else {
-    // ================= coordinate branch: 128 accumulator registers; every operand group is requested as late as its latency
-    // allows and no two 32-register groups are live together (the schedule of edge_f16c8.hip's 4-column-block kernel) =================
-    //   fp16 fragments of k-steps 2, 3 of chunk c   at the start of its matrix phase
-    //   e4m3 fragments of chunk c                   behind its k-step 1
-    //   table rows of the next build: row 0         behind k-step 3; row 1 at the start of the build
-    //   fp16 fragments of k-steps 0, 1 of the next matrix phase: between the two rows of the build in front of it
+    // ================= coordinate branch: 128 accumulator registers.  The operands of a chunk are six groups of 16 registers,
+    // each consumed by 512 cycles of matrix instructions (or one row of the build): fp16 fragments of k-steps 0-1 (G1) and 2-3 (G2),
+    // e4m3 fragments of hidden units 0-31 (G3) and 32-63 (G4), table rows of the next build's two rows (U0, U1).  Three groups
+    // are live at any time -- one being consumed, two in flight (48 registers; hipcc spills beyond that):
+    //   G3 at the start of the matrix phase | G4 behind G1 | U0 behind G2 | U1 behind G3 | G1 and G2 of the next matrix phase
+    //   between the two rows of the build in front of it
     auto wload16 = [&](const int cq, const int s) {   // k-steps 2 s, 2 s + 1 of chunk cq
       const int c = cq < NC ? cq : NC - 1;
 #pragma unroll
@@ -287,21 +289,18 @@ __global__ __launch_bounds__(kT, 2) void edge_c8w_kernel(const EdgeParams p) {
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) bq[0][2 * s + k2][cb] = ld16(c, 2 * s + k2, cb);
     };
-    auto wload8 = [&](const int c) {
+    auto wload8 = [&](const int c, const int t) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb) b8[0][t][cb] = ld8(c, t, cb);
+      for (int cb = 0; cb < CB; ++cb) b8[0][t][cb] = ld8(c, t, cb);
     };
     auto vfinish = [&](auto par_c, const int c, const int mchunk) {
       __builtin_amdgcn_s_setprio(3);
-      vload1(c);
-      __builtin_amdgcn_sched_barrier(0);
       if (!(diag::kC8NoBuild && c > 1)) vrow(par_c, P0, c);
       else asm volatile("" :: "v"(ua0.p0), "v"(ua0.p1), "v"(ua0.q0), "v"(ua0.q1));
       __builtin_amdgcn_sched_barrier(0);
       DIAG_STAMP2(c + 15, 3, c >= 1 && c < 15);
       wload16(mchunk, 0);
+      wload16(mchunk, 1);
       __builtin_amdgcn_sched_barrier(0);
       if (!(diag::kC8NoBuild && c > 1)) vrow(par_c, P1, c);
       else asm volatile("" :: "v"(ua1.p0), "v"(ua1.p1), "v"(ua1.q0), "v"(ua1.q1));
@@ -309,9 +308,10 @@ __global__ __launch_bounds__(kT, 2) void edge_c8w_kernel(const EdgeParams p) {
       __builtin_amdgcn_s_setprio(0);
     };
     vload0(0);
+    vload1(0);
     S = prologue_segments<false>(p, L, e0, nvalid, tid, lane, wave);
     vfinish(P0, 0, 0);
-    if (wave >= 4) vload0(1);
+    if (wave >= 4) { vload0(1); vload1(1); }
     __syncthreads();
     DIAG_STAMP(30, 2);
     DIAG_RSTAMP(31, 1);
@@ -322,11 +322,13 @@ __global__ __launch_bounds__(kT, 2) void edge_c8w_kernel(const EdgeParams p) {
       u32x4 c0[2], c1[2];
 #define BQ(ks) bq[0][ks]
 #define B8(t) b8[0][t]
-#define MPHASE_AFTER_FIRST_READS do { __builtin_amdgcn_sched_barrier(0); wload16(c, 1); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define MPHASE_AFTER_KSTEP0 do { DIAG_STAMP2(c + 16, 0, c < 14); wload8(c); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define MPHASE_AFTER_FIRST_READS do { __builtin_amdgcn_sched_barrier(0); wload8(c, 0); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define MPHASE_AFTER_KSTEP0 do { DIAG_STAMP2(c + 16, 0, c < 14); wload8(c, 1); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define MPHASE_AFTER_KSTEP1 do { DIAG_STAMP2(c + 16, 1, c < 14); if (tab_chunk >= 0) vload0(tab_chunk); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define MPHASE_AFTER_CORR0 do { if (tab_chunk >= 0) vload1(tab_chunk); __builtin_amdgcn_sched_barrier(0); } while (0)
 #include "edge_f16c8w_mphase2.inc"
       DIAG_STAMP2(c + 16, 2, c < 14);
+#undef MPHASE_AFTER_CORR0
 #undef MPHASE_AFTER_KSTEP1
 #undef MPHASE_AFTER_KSTEP0
 #undef MPHASE_AFTER_FIRST_READS
@@ -361,6 +363,7 @@ __global__ __launch_bounds__(kT, 2) void edge_c8w_kernel(const EdgeParams p) {
         DIAG_STAMP(i + 1, 0); vfinish(P1, i + 2, i + 1); DIAG_STAMP(i + 1, 1); __builtin_amdgcn_sched_barrier(0); mphase(P0, i + 1, i + 3); DIAG_STAMP(i + 1, 2); __syncthreads(); DIAG_STAMP(i + 1, 3);
       }
       wload16(NC - 1, 0);
+      wload16(NC - 1, 1);
     }
     DIAG_STAMP(NC - 1, 0);
     mphase(P1, NC - 1, -1);

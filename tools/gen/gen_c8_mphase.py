@@ -67,6 +67,8 @@ for i, (kind, idx) in enumerate(seq):
         out.append(f"    LDS_WAIT({younger(i, 'C', idx)});")
         if WIDE:
             out.append(f"    CORR_STEP(c0[{idx % RC}], c1[{idx % RC}], {idx >> 2}, {idx & 3});")
+            if idx == 3:
+                out.append("    MPHASE_AFTER_CORR0;")
         else:
             out.append(f"    CORR_STEP(c0[{idx % RC}], c1[{idx % RC}], {idx});")
 print("\n".join(out))
