@@ -4,7 +4,7 @@ ARCH  ?= gfx950
 CSRC  := diffusion_model_amd/csrc
 OUT   := diffusion_model_amd/libegnn_amd.so
 SRCS  := $(CSRC)/egnn_forward.hip $(CSRC)/edge_bf16_v3.hip $(CSRC)/edge_bf16_v4.hip $(CSRC)/edge_x_m16.hip $(CSRC)/edge_small.hip $(CSRC)/edge_bf16x3.hip $(CSRC)/edge_f16c8.hip $(CSRC)/edge_f16c8w.hip $(CSRC)/edge_bwd_dgrad.hip $(CSRC)/edge_bwd_dgrad_graph.hip $(CSRC)/edge_bwd_heads.hip $(CSRC)/edge_bwd_first.hip $(CSRC)/gemm_tn.hip $(CSRC)/gemm_rows.hip $(CSRC)/sampler.hip $(CSRC)/graph_stats.hip $(CSRC)/aux_mlp.hip $(CSRC)/node_bf16.hip $(CSRC)/backward.hip
-HDRS  := $(CSRC)/edge_f16c8_mphase2.inc $(CSRC)/edge_f16c8_mphase4.inc $(CSRC)/edge_f16c8w_mphase1.inc $(CSRC)/edge_f16c8w_mphase2.inc $(CSRC)/common.h $(CSRC)/kernels.h $(CSRC)/edge_tile.h $(CSRC)/host_logic.h $(CSRC)/diag.h $(CSRC)/bwd_graph.h include/egnn_amd.h
+HDRS  := $(CSRC)/edge_f16c8_mphase2.inc $(CSRC)/edge_f16c8_mphase4.inc $(CSRC)/edge_f16c8w_mphase1.inc $(CSRC)/edge_f16c8w_mphase2.inc $(CSRC)/edge_f16c8w_mphasek.inc $(CSRC)/common.h $(CSRC)/kernels.h $(CSRC)/edge_tile.h $(CSRC)/host_logic.h $(CSRC)/diag.h $(CSRC)/bwd_graph.h include/egnn_amd.h
 # -fvisibility=hidden: the library exports exactly the functions include/egnn_amd.h declares (the header wraps its
 # declarations in a visibility push(default)); tests/test_cabi_and_host.py compares the two sets
 FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -ffp-contract=off -fno-slp-vectorize -fvisibility=hidden

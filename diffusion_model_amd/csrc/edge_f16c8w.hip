@@ -18,6 +18,7 @@
 //   the store bank row), the two 16-byte halves of a row swapped in rows with bit 4 set (an operand read of 16 lanes covers rows
 //   0-3, 12-15 and 20-27 of one block: they then hit 16 different slots);
 //   weight streams: fp16 [N/32][K/16][64][8] (pack_frags_bf16<_Float16>), e4m3 [N/32][K/32][2][64][16 B] (pack_frags_c8w).
+#include <cstdlib>
 #include <type_traits>
 
 #include "diag.h"
@@ -280,8 +281,8 @@ __global__ __launch_bounds__(kT, 2) void edge_c8w_kernel(const EdgeParams p) {
     // each consumed by 512 cycles of matrix instructions (or one row of the build): fp16 fragments of k-steps 0-1 (G1) and 2-3 (G2),
     // e4m3 fragments of hidden units 0-31 (G3) and 32-63 (G4), table rows of the next build's two rows (U0, U1).  Three groups
     // are live at any time -- one being consumed, two in flight (48 registers; hipcc spills beyond that):
-    //   G3 at the start of the matrix phase | G4 behind G1 | U0 behind G2 | U1 behind G3 | G1 and G2 of the next matrix phase
-    //   between the two rows of the build in front of it
+    //   G3 at the start of the matrix phase | G4 behind G1 | U0 behind G2 | U1 behind G3 | G1 of the next matrix phase at the
+    //   start of the build in front of it, G2 between its two rows
     auto wload16 = [&](const int cq, const int s) {   // k-steps 2 s, 2 s + 1 of chunk cq
       const int c = cq < NC ? cq : NC - 1;
 #pragma unroll
@@ -295,11 +296,12 @@ __global__ __launch_bounds__(kT, 2) void edge_c8w_kernel(const EdgeParams p) {
     };
     auto vfinish = [&](auto par_c, const int c, const int mchunk) {
       __builtin_amdgcn_s_setprio(3);
+      wload16(mchunk, 0);
+      __builtin_amdgcn_sched_barrier(0);
       if (!(diag::kC8NoBuild && c > 1)) vrow(par_c, P0, c);
       else asm volatile("" :: "v"(ua0.p0), "v"(ua0.p1), "v"(ua0.q0), "v"(ua0.q1));
       __builtin_amdgcn_sched_barrier(0);
       DIAG_STAMP2(c + 15, 3, c >= 1 && c < 15);
-      wload16(mchunk, 0);
       wload16(mchunk, 1);
       __builtin_amdgcn_sched_barrier(0);
       if (!(diag::kC8NoBuild && c > 1)) vrow(par_c, P1, c);
@@ -400,6 +402,267 @@ __global__ __launch_bounds__(kT, 2) void edge_c8w_kernel(const EdgeParams p) {
   DIAG_STAMP(31, 0);
 }
 
+// Message branch with the K loop SPLIT between the two waves of a SIMD pair.  With one 32-column block per wave (edge_c8w_kernel<true, 1>)
+// every operand read from LDS feeds ONE matrix instruction: 16 bytes per lane and 32 MFMA cycles, x 4 SIMDs = the 128 bytes per
+// clock the LDS delivers -- the message kernel's K loop ran against the LDS (49 % MFMA-busy, profiles/r05F_c8w_stamps.txt).  Here
+// wave w owns column blocks 2 (w & 3), 2 (w & 3) + 1 (64 columns: a read feeds two instructions) and HALF of every chunk: k-steps
+// 2 (w >> 2), + 1 of the fp16 product and e4m3 instruction (w >> 2).  Same matrix work and weight bytes per wave, half the LDS reads;
+// the build is unchanged (512 threads, 2 rows each).  After the K loop the pair exchanges half of its partial sums through LDS (the
+// loop buffers are dead): wave w keeps column block 2 (w & 3) + (w >> 2) -- one block per wave, the layout of message_epilogue.
+// Operand requests: four groups of 16 registers per chunk and wave -- fp16 fragments (G1), e4m3 fragments (G3), table rows of the
+// build's two rows (U0, U1) -- consumed in a fixed cycle; each is requested when the consumption of the group two places ahead of
+// it starts (three live groups beside the 128 accumulators).
+constexpr size_t kXchg = (size_t)8 * 16384;   // exchange buffer: 64 accumulator registers per wave
+__host__ __device__ inline size_t c8wk_smem_bytes(int KP) {
+  const size_t loop = c8w_smem_bytes(KP), x = kOffLoop + kXchg;
+  return loop > x ? loop : x;
+}
+__global__ __launch_bounds__(kT, 2) void edge_c8wk_kernel(const EdgeParams p) {
+  constexpr int CB = 2;
+  f16_saturate_mode();
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const Lds L(smem);
+  char* s_a1 = smem + kOffLoop;
+  char* s_c8 = s_a1 + 2 * kA1W;
+  float* s_wd = reinterpret_cast<float*>(s_c8 + 2 * kC8W);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int kh = wave >> 2, cb0 = 2 * (wave & 3);
+  const int KP = p.WmP;
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int e0 = tile * kR;
+  const int nvalid = min(kR, p.E - e0);
+  DIAG_STAMP_SETUP(p.stamps + ((size_t)8 + wave) * 32 * 4);
+  DIAG_STAMP(30, 0);
+
+  const int NC = KP / kKC, KS16 = KP / 16, KS32 = KP / 32;
+  const int brow = tid >> 3, kg = tid & 7;
+  const unsigned wbytes = diag::drop_weight_loads(p.dbg) ? 0u : (unsigned)((size_t)p.MP * KP * 2);
+  const rsrc_t rs_w = make_rsrc(p.w2m, wbytes);
+  const rsrc_t rs_w8 = make_rsrc(p.w2m_c8, wbytes);
+  const unsigned lane16 = lane * 16u;
+  const unsigned w0 = ((unsigned)cb0 * KS16 + 2u * kh) * 1024u;
+  const unsigned w80 = ((unsigned)cb0 * KS32 + (unsigned)kh) * 2048u;
+  auto ld16 = [&](const int c, const int ksl, const int cb) {   // fp16 fragment of (chunk c, this wave's k-step ksl, column block cb)
+    return ldbuf_v8<f16x8>(rs_w, lane16, w0 + ((unsigned)cb * KS16 + (unsigned)(4 * c + ksl)) * 1024u);
+  };
+  auto ld8 = [&](const int c, const int cb) {                   // e4m3 fragment of (chunk c, this wave's instruction, column block cb)
+    const unsigned o = w80 + ((unsigned)cb * KS32 + (unsigned)(2 * c)) * 2048u;
+    const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rs_w8, lane16, __builtin_amdgcn_readfirstlane(o), 0);
+    const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rs_w8, lane16, __builtin_amdgcn_readfirstlane(o + 1024u), 0);
+    return i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+  };
+  f16x8 bq[1][2][CB];
+  i32x8 b8[1][1][CB];
+
+  prologue_rows(p, L, e0, nvalid, p.wdm, KP, s_wd, tid);
+  DIAG_STAMP(30, 1);
+
+  const rsrc_t rs_tab = make_rsrc(p.table, diag::drop_table_loads(p.dbg) ? 0u : (unsigned)min((size_t)p.N * p.TC * 4, (size_t)0xFFFFFFFFu));
+  const unsigned vdst0 = (unsigned)L.dst[brow] * (unsigned)p.TC * 4u + (unsigned)kg * 32u;
+  const unsigned vsrc0 = (unsigned)L.src[brow] * (unsigned)p.TC * 4u + (unsigned)kg * 32u;
+  const unsigned vdst1 = (unsigned)L.dst[brow + 64] * (unsigned)p.TC * 4u + (unsigned)kg * 32u;
+  const unsigned vsrc1 = (unsigned)L.src[brow + 64] * (unsigned)p.TC * 4u + (unsigned)kg * 32u;
+  const unsigned offP = 2u * p.WxP * 4u, offQ = (2u * p.WxP + p.WmP) * 4u;   // fp32 table {Px|Qx|Pm|Qm}
+  char* slot0 = s_a1 + ((size_t)kg * kRPADW + brow) * 16;
+  const unsigned sw = ((unsigned)brow >> 4) & 1u;
+  char* slo0 = s_c8 + (size_t)(kg >> 2) * (c8w_block(2) - c8w_block(0)) + (size_t)brow * 32 + ((((unsigned)kg >> 1) & 1u) ^ sw) * 16u + (unsigned)(kg & 1) * 8u;
+  constexpr int shi_delta = (int)(c8w_block(1) - c8w_block(0));
+  // operand reads: this wave's half of the chunk rides in the base registers (k-groups 4 kh .., e4m3 blocks 2 kh ..)
+  const unsigned abase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(s_a1 + ((size_t)(4 * kh + hh) * kRPADW + r) * 16);
+  const unsigned lds8 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)s_c8;
+  const unsigned rsw = ((unsigned)r >> 4) & 1u;
+  const unsigned cbaseA = lds8 + (unsigned)c8w_block(2) * (unsigned)kh + (unsigned)hh * 4096u + (unsigned)r * 32u + rsw * 16u;
+  const unsigned cbaseB = cbaseA ^ 16u;
+  constexpr int kScaleA = 127 - 12;
+  const int scale_b = __builtin_amdgcn_readfirstlane(p.c8_exp[2]);
+
+  f32x16 acc[4][CB];
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[rb][cb][i] = 0.f;
+
+  Unit ua0, ua1;
+  auto vload0 = [&](const int cq) {
+    const int c = cq < NC ? cq : NC - 1;
+    unit_load(ua0, rs_tab, vdst0, vsrc0, offP + (unsigned)c * kKC * 4u, offQ + (unsigned)c * kKC * 4u);
+  };
+  auto vload1 = [&](const int cq) {
+    const int c = cq < NC ? cq : NC - 1;
+    unit_load(ua1, rs_tab, vdst1, vsrc1, offP + (unsigned)c * kKC * 4u, offQ + (unsigned)c * kKC * 4u);
+  };
+  auto vrow = [&](auto par_c, auto row_c, const int c) {
+    constexpr int PAR = decltype(par_c)::value, ROW = decltype(row_c)::value;
+    unit_finish_c8w(ROW ? ua1 : ua0, s_wd + c * kKC + kg * 8, L.d2[brow + 64 * ROW], slot0 + PAR * kA1W + ROW * 64 * 16,
+                    slo0 + PAR * kC8W + ROW * 64 * 32, slo0 + PAR * kC8W + ROW * 64 * 32 + shi_delta);
+  };
+  const std::integral_constant<int, 0> P0;
+  const std::integral_constant<int, 1> P1;
+  auto wload16 = [&](const int cq) {
+    const int c = cq < NC ? cq : NC - 1;
+#pragma unroll
+    for (int ksl = 0; ksl < 2; ++ksl)
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) bq[0][ksl][cb] = ld16(c, ksl, cb);
+  };
+  auto wload8 = [&](const int cq) {
+    const int c = cq < NC ? cq : NC - 1;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) b8[0][0][cb] = ld8(c, cb);
+  };
+  auto vfinish = [&](auto par_c, const int c, const int mchunk) {   // build of chunk c; requests the weights of matrix phase mchunk
+    __builtin_amdgcn_s_setprio(3);
+    wload16(mchunk);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(diag::kC8NoBuild && c > 1)) vrow(par_c, P0, c);
+    else asm volatile("" :: "v"(ua0.p0), "v"(ua0.p1), "v"(ua0.q0), "v"(ua0.q1));
+    __builtin_amdgcn_sched_barrier(0);
+    wload8(mchunk);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(diag::kC8NoBuild && c > 1)) vrow(par_c, P1, c);
+    else asm volatile("" :: "v"(ua1.p0), "v"(ua1.p1), "v"(ua1.q0), "v"(ua1.q1));
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  vload0(0);
+  vload1(0);
+  const int S = prologue_segments<false>(p, L, e0, nvalid, tid, lane, wave);
+  vfinish(P0, 0, 0);
+  if (wave >= 4) { vload0(1); vload1(1); }
+  __syncthreads();
+  DIAG_STAMP(30, 2);
+  DIAG_RSTAMP(31, 1);
+
+#define LDS_RD(dst, base, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(off))
+#define LDS_WAIT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
+#define MAIN_STEP(A, KSTEP, RB)                                                                                          \
+  do {                                                                                                                   \
+    asm volatile("" : "+v"(A));                                                                                          \
+    if constexpr (!diag::kC8NoMain) {                                                                                    \
+      _Pragma("unroll") for (int cb = 0; cb < CB; ++cb)                                                                  \
+          acc[RB][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, bq[0][KSTEP][cb], acc[RB][cb], 0, 0, 0);               \
+    } else {                                                                                                             \
+      asm volatile("" ::"v"(bq[0][KSTEP][0]), "v"(bq[0][KSTEP][CB - 1]));                                                \
+    }                                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  } while (0)
+#define CORR_STEP(C0, C1, T, RB)                                                                                         \
+  do {                                                                                                                   \
+    if constexpr (!diag::kC8NoCorr) {                                                                                    \
+      asm volatile("" : "+v"(C0), "+v"(C1));                                                                             \
+      const u32x4 x0_ = C0, x1_ = C1;                                                                                    \
+      const i32x8 a8_ = {(int)x0_.x, (int)x0_.y, (int)x0_.z, (int)x0_.w, (int)x1_.x, (int)x1_.y, (int)x1_.z, (int)x1_.w}; \
+      _Pragma("unroll") for (int cb = 0; cb < CB; ++cb)                                                                  \
+          acc[RB][cb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8_, b8[0][T][cb], acc[RB][cb], 0, 0, 0, kScaleA, 0, scale_b); \
+    } else {                                                                                                             \
+      asm volatile("" ::"v"(b8[0][T][0]), "v"(b8[0][T][CB - 1]));                                                        \
+    }                                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  } while (0)
+  auto mphase = [&](auto par_c, const int c, const int tab_chunk) {   // this wave's half of chunk c; requests the table rows of build tab_chunk
+    constexpr int PAR = decltype(par_c)::value;
+    constexpr int kO16 = PAR * (int)kA1W, kO8 = PAR * (int)kC8W;
+    f16x8 a[3];
+    u32x4 c0[2], c1[2];
+#define MPHASE_AFTER_FIRST_READS do { __builtin_amdgcn_sched_barrier(0); if (tab_chunk >= 0) vload0(tab_chunk); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define MPHASE_AFTER_KSTEP1 do { if (tab_chunk >= 0) vload1(tab_chunk); __builtin_amdgcn_sched_barrier(0); } while (0)
+#include "edge_f16c8w_mphasek.inc"
+#undef MPHASE_AFTER_KSTEP1
+#undef MPHASE_AFTER_FIRST_READS
+  };
+  if (wave < 4) {
+    const int my_mode = tid < S ? segment_mode(p, L, e0, tid) : 0;
+    DIAG_STAMP(0, 0);
+    mphase(P0, 0, 1);
+    DIAG_STAMP(0, 1);
+    if (tid < S) L.seg_mode[tid] = my_mode;
+    vfinish(P1, 1, 1);
+    DIAG_STAMP(0, 2);
+    __syncthreads();
+    DIAG_STAMP(0, 3);
+    for (int i = 1; i + 1 < NC - 1; i += 2) {
+      DIAG_STAMP(i, 0); mphase(P1, i, i + 1); DIAG_STAMP(i, 1); vfinish(P0, i + 1, i + 1); DIAG_STAMP(i, 2); __syncthreads(); DIAG_STAMP(i, 3);
+      DIAG_STAMP(i + 1, 0); mphase(P0, i + 1, i + 2); DIAG_STAMP(i + 1, 1); vfinish(P1, i + 2, i + 2); DIAG_STAMP(i + 1, 2); __syncthreads(); DIAG_STAMP(i + 1, 3);
+    }
+  } else {
+    DIAG_STAMP(0, 0);
+    vfinish(P1, 1, 0);
+    DIAG_STAMP(0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mphase(P0, 0, 2);
+    DIAG_STAMP(0, 2);
+    __syncthreads();
+    DIAG_STAMP(0, 3);
+    for (int i = 1; i + 1 < NC - 1; i += 2) {
+      DIAG_STAMP(i, 0); vfinish(P0, i + 1, i); DIAG_STAMP(i, 1); __builtin_amdgcn_sched_barrier(0); mphase(P1, i, i + 2); DIAG_STAMP(i, 2); __syncthreads(); DIAG_STAMP(i, 3);
+      DIAG_STAMP(i + 1, 0); vfinish(P1, i + 2, i + 1); DIAG_STAMP(i + 1, 1); __builtin_amdgcn_sched_barrier(0); mphase(P0, i + 1, i + 3); DIAG_STAMP(i + 1, 2); __syncthreads(); DIAG_STAMP(i + 1, 3);
+    }
+    wload16(NC - 1);
+    wload8(NC - 1);
+  }
+  DIAG_STAMP(NC - 1, 0);
+  mphase(P1, NC - 1, -1);
+  DIAG_STAMP(NC - 1, 1);
+#undef CORR_STEP
+#undef MAIN_STEP
+#undef LDS_WAIT
+#undef LDS_RD
+  __syncthreads();   // the loop buffers are dead
+  DIAG_STAMP(NC - 1, 3);
+  DIAG_STAMP(30, 3);
+  DIAG_RSTAMP(31, 2);
+
+  constexpr float kAcc = kNegLog2e / kF16WScale;
+  if constexpr (diag::kC8NoEpi) {
+    float v = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v += acc[rb][cb][i];
+    if (v == 123.456f) p.agg_m[0] = v;
+    return;
+  }
+  // the pair (w, w ^ 4) holds the two K halves of column blocks cb0, cb0 + 1: wave w keeps block cb0 + kh and hands the other to its
+  // partner; [receiving wave][16 pieces][64 lanes] x 16 bytes (a + b = b + a: both waves of a pair round alike)
+  f32x16 keep[4][1];
+  {
+    f32x4* xb = reinterpret_cast<f32x4*>(smem + kOffLoop);
+    f32x4* mine = xb + (size_t)wave * 1024 + lane;
+    f32x4* theirs = xb + (size_t)(wave ^ 4) * 1024 + lane;
+    auto give = [&](auto kc) {   // (compile-time register indices in both arms: kh is uniform over the wave)
+      constexpr int G = 1 - decltype(kc)::value;
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          theirs[(rb * 4 + q) * 64] = f32x4{acc[rb][G][4 * q], acc[rb][G][4 * q + 1], acc[rb][G][4 * q + 2], acc[rb][G][4 * q + 3]};
+    };
+    auto take = [&](auto kc) {
+      constexpr int K = decltype(kc)::value;
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 o = mine[(rb * 4 + q) * 64];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) keep[rb][0][4 * q + i] = acc[rb][K][4 * q + i] + o[i];
+        }
+    };
+    if (kh) give(P1); else give(P0);
+    __syncthreads();
+    if (kh) take(P1); else take(P0);
+  }
+  message_epilogue(p, L, keep, S, tile, tid, lane, wave, kAcc, cb0 + kh);
+  DIAG_STAMP(31, 0);
+}
+
 // e4m3 B fragments of the correction product for v_mfma_scale_f32_32x32x64_f8f6f4, one instruction per 32 hidden units:
 //   out[((nb * KS32 + t) * 2 + piece) * 1024 + lane * 16 + j],  lane l: column 32 nb + (l & 31), K block h = l >> 5
 //   block 0 holds e4m3(2^s_hi W_hi), block 1 e4m3(2^s_lo W_lo) of hidden units 32 t + [0, 32); register piece `piece` holds hidden
@@ -440,6 +703,7 @@ __global__ void pack_frags_c8w(const float* __restrict__ W, int Nout, int K, int
 int init_edge_f16c8w_attributes() {
   EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_c8w_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_c8w_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_c8wk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   return EGNN_OK;
 }
 
@@ -447,7 +711,7 @@ int init_edge_f16c8w_attributes() {
 // p.w2x_c8 / p.w2m_c8 = the e4m3 streams of pack_c8w_stream
 bool edge_f16c8w_supported(const EdgeParams& p) {
   return (p.WxP == 512 || p.WxP == 1024) && p.MP == 256 && p.WmP % 128 == 0 && p.WmP >= 128 && p.w2x && p.w2m && p.w2x_c8 && p.w2m_c8 && p.c8_exp &&
-         c8w_smem_bytes(p.WxP) <= 160 * 1024 && c8w_smem_bytes(p.WmP) <= 160 * 1024 && (size_t)p.N * p.TC * 4 < ((size_t)1 << 32);
+         c8w_smem_bytes(p.WxP) <= 160 * 1024 && c8wk_smem_bytes(p.WmP) <= 160 * 1024 && (size_t)p.N * p.TC * 4 < ((size_t)1 << 32);
 }
 
 int launch_edge_f16c8w_x(const EdgeParams& p, hipStream_t st) {
@@ -458,7 +722,9 @@ int launch_edge_f16c8w_x(const EdgeParams& p, hipStream_t st) {
 }
 int launch_edge_f16c8w_m(const EdgeParams& p, hipStream_t st) {
   const int tiles = (p.E + kR - 1) / kR;
-  hipLaunchKernelGGL((edge_c8w_kernel<true, 1>), dim3(tiles), dim3(kT), c8w_smem_bytes(p.WmP), st, p);
+  static const bool ksplit = !(getenv("EGNN_C8_KSPLIT") && atoi(getenv("EGNN_C8_KSPLIT")) == 0);   // A/B switch
+  if (ksplit) hipLaunchKernelGGL(edge_c8wk_kernel, dim3(tiles), dim3(kT), c8wk_smem_bytes(p.WmP), st, p);
+  else hipLaunchKernelGGL((edge_c8w_kernel<true, 1>), dim3(tiles), dim3(kT), c8w_smem_bytes(p.WmP), st, p);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }

@@ -213,9 +213,10 @@ __device__ __forceinline__ void x_head(const EdgeParams& p, const Lds& L, const 
 // acc_scale: t2 = acc_scale * acc + b2 (-log2(e); precision fp16 divides the weight fragments' 2^8 out here).
 template <bool PRE_SCALED = false>
 __device__ __forceinline__ void message_epilogue(const EdgeParams& p, const Lds& L, const f32x16 (&acc)[4][1], int S, int tile,
-                                                 int tid, int lane, int wave, const float acc_scale = kNegLog2e) {
+                                                 int tid, int lane, int wave, const float acc_scale = kNegLog2e,
+                                                 const int colblk = -1) {
   const int r = lane & 31, hh = lane >> 5;
-  const int ncol = 32 * wave + r;
+  const int ncol = 32 * (colblk < 0 ? wave : colblk) + r;   // colblk: the wave's column block when it is not its index
   float mval[64];
   {
     const float bb = p.b2m[ncol], wa = p.wa[ncol];

@@ -8,8 +8,9 @@ for t in 16 32; do
   echo "== EGNN_C8_TILE=$t: golden errors"
   EGNN_C8_TILE=$t timeout -k 10 300 python3 $R/tools/prec_errors.py --precisions f16c8 --skip-c2 2>&1 | tail -4 || exit 1
 done
-for t in 16 32; do
-  rm -rf /tmp/pp; EGNN_C8_TILE=$t rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pp -- python3 $R/bench.py --precision f16c8 --steps 5 --warmup 2 --reps 1 --no-cpu-baseline --no-train-leg --no-slab-leg --no-latency-leg --no-precision-legs > /dev/null 2>&1
+for t in 16 32 32n; do
+  if [ "$t" = "32n" ]; then export EGNN_C8_KSPLIT=0; else unset EGNN_C8_KSPLIT; fi
+  rm -rf /tmp/pp; EGNN_C8_TILE=${t%n} rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pp -- python3 $R/bench.py --precision f16c8 --steps 5 --warmup 2 --reps 1 --no-cpu-baseline --no-train-leg --no-slab-leg --no-latency-leg --no-precision-legs > /dev/null 2>&1
   python3 - "$t" <<'PY'
 import csv,glob,sys
 for f in glob.glob('/tmp/pp/**/*kernel_stats.csv', recursive=True):
@@ -20,6 +21,7 @@ for f in glob.glob('/tmp/pp/**/*kernel_stats.csv', recursive=True):
     print("tile %s: X %.3f ms  M %.3f ms" % (sys.argv[1], out.get('X',0), out.get('M',0)))
 PY
 done
+unset EGNN_C8_KSPLIT
 cd $R
 for r in $(seq 1 $1); do
   for t in 16 32; do

@@ -5,13 +5,17 @@ usage: python tools/gen/gen_c8_mphase.py {2|4}  -> C++ text for the body of `mph
        python tools/gen/gen_c8_mphase.py w {1|2} -> the same for the 32x32-tile kernels (edge_f16c8w.hip) at CB 32-column blocks per wave:
          16 fp16 pieces = 4 k-steps of 16 x 4 row blocks of 32 (padded image: k-group stride 129 rows), 8 e4m3 operands = 2
          instructions (32 hidden units each) x 4 row blocks, two 16-byte reads each from bases that differ in the swizzled half
+       python tools/gen/gen_c8_mphase.py w k -> 32x32 tiles, 2 column blocks per wave, HALF a chunk per wave (k-steps 0-1 and one
+         e4m3 instruction from the wave's own base: 8 pieces, 4 operands)
   CB = 2: an fp16 piece feeds 32 cycles of MFMAs, an e4m3 operand 64: rings of 8 pieces / 4 operands (256 cycles ahead)
   CB = 4: 64 / 128 cycles: rings of 3 pieces / 2 operands (as edge_x_m16.hip); the first e4m3 operands are requested under the
           last fp16 MFMAs in both"""
 import sys
 
 WIDE = sys.argv[1] == "w"
-CB = int(sys.argv[2]) * 2 if WIDE else int(sys.argv[1])     # in 16-column units: the same ring arithmetic
+KSPLIT = WIDE and sys.argv[2] == "k"     # message kernel, K split between the waves of a SIMD pair: half a chunk per wave
+CB = (4 if KSPLIT else int(sys.argv[2]) * 2) if WIDE else int(sys.argv[1])     # in 16-column units: the same ring arithmetic
+NPIECE, NCORR = (8, 4) if KSPLIT else (16, 8)
 import os
 RA, RC = (8, 4) if CB == 2 else (int(os.environ.get('C8_RA', 3)), int(os.environ.get('C8_RC', 2)))          # ring depths (C8_RA / C8_RC: experiments)
 out = []
@@ -30,15 +34,17 @@ if CB == 2:
     corr_slots = {8: 0, 10: 1, 12: 2, 14: 3}
 else:
     corr_slots = {13: 0, 15: 1} if RC == 2 else {11: 0, 13: 1, 15: 2}
-for u in range(16):
+if KSPLIT:
+    corr_slots = {5: 0, 7: 1}
+for u in range(NPIECE):
     seq.append(("useP", u))
-    if nextP < 16:
+    if nextP < NPIECE:
         seq.append(("P", nextP)); nextP += 1
     if u in corr_slots:
         seq.append(("C", corr_slots[u])); nextC = corr_slots[u] + 1
-for v in range(8):
+for v in range(NCORR):
     seq.append(("useC", v))
-    if nextC < 8:
+    if nextC < NCORR:
         seq.append(("C", nextC)); nextC += 1
 
 def younger(i, kind, idx):
@@ -59,15 +65,15 @@ for i, (kind, idx) in enumerate(seq):
         s, rb = (idx >> 2, idx & 3) if WIDE else (idx >> 3, idx & 7)
         out.append(f"    LDS_WAIT({younger(i, 'P', idx)});")
         out.append(f"    MAIN_STEP(a[{idx % RA}], {s}, {rb});")
-        if idx == 7:
+        if idx == 7 and not KSPLIT:
             out.append("    MPHASE_AFTER_KSTEP0;")
-        if idx == 15:
+        if idx == 15 or (KSPLIT and idx == 7):
             out.append("    MPHASE_AFTER_KSTEP1;")
     else:
         out.append(f"    LDS_WAIT({younger(i, 'C', idx)});")
         if WIDE:
             out.append(f"    CORR_STEP(c0[{idx % RC}], c1[{idx % RC}], {idx >> 2}, {idx & 3});")
-            if idx == 3:
+            if idx == 3 and not KSPLIT:
                 out.append("    MPHASE_AFTER_CORR0;")
         else:
             out.append(f"    CORR_STEP(c0[{idx % RC}], c1[{idx % RC}], {idx});")
