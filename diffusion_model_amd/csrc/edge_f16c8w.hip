@@ -41,20 +41,33 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(2))) short i16x2;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
-// SiLU + the three operand forms of one build unit (8 hidden units of one row), as unit_finish_c8 of edge_f16c8.hip
+// SiLU + the three operand forms of one build unit (8 hidden units of one row): the arithmetic of unit_finish_c8 (edge_f16c8.hip), bit
+// for bit.  The build's vector instructions are K-loop time (a SIMD's matrix and vector work overlap little in these kernels: chunk
+// time ~ matrix cycles + vector cycles of both waves, profiles/r05H_c8w_stamps.txt), so the remainder a - fp16(a) is ONE
+// v_fma_mix_f32 (fp16 operand x -1 + a, exact) instead of a conversion and a subtraction: message kernel -5 %.  (Packed fp32 adds /
+// fmas / multiplies -- half the instructions -- made both kernels 5 % SLOWER: profiles/r05J_c8w_ab.txt; MI355X_MICROARCH.md prices
+// v_pk_*_f32 beside MFMAs as an anti-lever.)
+template <int HALF>
+__device__ __forceinline__ float minus_f16(const float a, const unsigned hw) {   // a - float(half HALF of hw)
+  float r;
+  if constexpr (HALF == 0) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hw), "v"(a));
+  else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hw), "v"(a));
+  return r;
+}
 __device__ __forceinline__ void unit_finish_c8w(const Unit& u, const float* wd, float d2, char* slot16, char* slot_lo, char* slot_hi) {
   const f32x4 w0 = *reinterpret_cast<const f32x4*>(wd), w1 = *reinterpret_cast<const f32x4*>(wd + 4);
   float a[8];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    a[j] = silu_s(fmaf(w0[j], d2, u.p0[j] + u.q0[j]));
+    a[j] = silu_s(fmaf(w0[j], d2, u.p0[j] + u.q0[j]));   // table, wd pre-scaled by -log2(e)
     a[j + 4] = silu_s(fmaf(w1[j], d2, u.p1[j] + u.q1[j]));
   }
-  const f16x8 h = pack8<f16x8>(a);
+  const f16x8 h = pack8<f16x8>(a);   // RNE; MODE.FP16_OVFL: saturates instead of inf
   if constexpr (diag::kC8NoCvt8) { *reinterpret_cast<f16x8*>(slot16) = h; return; }
-  float lo[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) lo[j] = a[j] - (float)h[j];
+  const u32x4 hw = __builtin_bit_cast(u32x4, h);
+  const float lo[8] = {minus_f16<0>(a[0], hw.x), minus_f16<1>(a[1], hw.x), minus_f16<0>(a[2], hw.y), minus_f16<1>(a[3], hw.y),
+                       minus_f16<0>(a[4], hw.z), minus_f16<1>(a[5], hw.z), minus_f16<0>(a[6], hw.w), minus_f16<1>(a[7], hw.w)};
+  // v_cvt_scalef32_pk_fp8_f32: e4m3(src / scale), RNE, saturating at +-448 under MODE.FP16_OVFL
   i16x2 l0 = {0, 0}, l1 = {0, 0}, h0 = {0, 0}, h1 = {0, 0};
   l0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(l0, lo[0], lo[1], 0x1p-12f, false);
   l0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(l0, lo[2], lo[3], 0x1p-12f, true);
@@ -84,9 +97,19 @@ __global__ __launch_bounds__(kT, 2) void edge_c8w_kernel(const EdgeParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, hh = lane >> 5;
   const int KP = IS_M ? p.WmP : p.WxP;
-  const int nsplit = IS_M ? 1 : p.WxP / 512;
-  const int j = xcd_tile(blockIdx.x, gridDim.x);
-  const int tile = j / nsplit, half = j - tile * nsplit;
+  // workgroup -> (tile, column share).  1024-wide coordinate branch: an XCD works on ONE column share (XCD x: share x & 1, tiles of
+  // quarter x >> 1 of the edge list) -- its L2 (4 MB) then holds that share's fragments (fp16 + e4m3: 2 MB) instead of thrashing on
+  // both (4 MB + the table rows streaming through); the table rows of a graph are read by the two XCDs of its quarter.  -2.3 %.
+  int tile, half = 0;
+  if (!IS_M && p.WxP == 1024) {
+    const int ntiles = (p.E + kR - 1) / kR, per = (ntiles + 3) >> 2;
+    const int xcd = blockIdx.x & 7, g = xcd >> 1;
+    half = xcd & 1;
+    tile = g * per + (int)(blockIdx.x >> 3);
+    if (tile >= min((g + 1) * per, ntiles)) return;   // (grid: 8 x per workgroups)
+  } else {
+    tile = xcd_tile(blockIdx.x, gridDim.x);
+  }
   const int e0 = tile * kR;
   const int nvalid = min(kR, p.E - e0);
   DIAG_STAMP_SETUP(p.stamps + ((size_t)(IS_M ? 1 : 0) * 8 + wave) * 32 * 4);
@@ -716,7 +739,8 @@ bool edge_f16c8w_supported(const EdgeParams& p) {
 
 int launch_edge_f16c8w_x(const EdgeParams& p, hipStream_t st) {
   const int tiles = (p.E + kR - 1) / kR;
-  hipLaunchKernelGGL((edge_c8w_kernel<false, 2>), dim3(tiles * (p.WxP / 512)), dim3(kT), c8w_smem_bytes(p.WxP), st, p);
+  const int grid = p.WxP == 1024 ? 8 * ((tiles + 3) / 4) : tiles;   // (1024: see the kernel's workgroup map)
+  hipLaunchKernelGGL((edge_c8w_kernel<false, 2>), dim3(grid), dim3(kT), c8w_smem_bytes(p.WxP), st, p);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }

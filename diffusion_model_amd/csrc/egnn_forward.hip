@@ -1305,7 +1305,7 @@ int launch_layer_begin(egnn_ctx* c, hipStream_t st, int layer, int prec, int nor
       R = 128;
       p.w2x16 = lp.w2x_f16s16; p.w2m16 = lp.w2m_f16s16;
       // matrix tile shape: 32x32 (edge_f16c8w.hip) / 16x16 (edge_f16c8.hip); EGNN_C8_TILE = A/B switch
-      static const int c8_tile = getenv("EGNN_C8_TILE") ? atoi(getenv("EGNN_C8_TILE")) : 16;
+      static const int c8_tile = getenv("EGNN_C8_TILE") ? atoi(getenv("EGNN_C8_TILE")) : 32;
       bool wide = false;
       if (c8_tile == 32) {
         EdgeParams q = p;

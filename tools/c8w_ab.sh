@@ -8,16 +8,16 @@ for t in 16 32; do
   echo "== EGNN_C8_TILE=$t: golden errors"
   EGNN_C8_TILE=$t timeout -k 10 300 python3 $R/tools/prec_errors.py --precisions f16c8 --skip-c2 2>&1 | tail -4 || exit 1
 done
-for t in 16 32 32n; do
-  if [ "$t" = "32n" ]; then export EGNN_C8_KSPLIT=0; else unset EGNN_C8_KSPLIT; fi
-  rm -rf /tmp/pp; EGNN_C8_TILE=${t%n} rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pp -- python3 $R/bench.py --precision f16c8 --steps 5 --warmup 2 --reps 1 --no-cpu-baseline --no-train-leg --no-slab-leg --no-latency-leg --no-precision-legs > /dev/null 2>&1
+for t in 16 32 32k1 32k0; do   # 32k<n>: EGNN_C8_KSPLIT=<n> (message kernel variants)
+  case $t in *k*) export EGNN_C8_KSPLIT=${t#*k};; *) unset EGNN_C8_KSPLIT;; esac
+  rm -rf /tmp/pp; EGNN_C8_TILE=${t%k*} rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pp -- python3 $R/bench.py --precision f16c8 --steps 5 --warmup 2 --reps 1 --no-cpu-baseline --no-train-leg --no-slab-leg --no-latency-leg --no-precision-legs > /dev/null 2>&1
   python3 - "$t" <<'PY'
 import csv,glob,sys
 for f in glob.glob('/tmp/pp/**/*kernel_stats.csv', recursive=True):
     out={}
     for r in csv.DictReader(open(f)):
         n=r['Name']
-        if 'edge_c8' in n: out['X' if ('<false' in n or 'ILb0' in n) else 'M']=float(r['AverageNs'])/1e6
+        if 'edge_c8' in n: out['X' if (('<false' in n or 'ILb0' in n) and 'c8wk' not in n) else 'M']=float(r['AverageNs'])/1e6
     print("tile %s: X %.3f ms  M %.3f ms" % (sys.argv[1], out.get('X',0), out.get('M',0)))
 PY
 done
