@@ -50,7 +50,9 @@ def forward_sources_sha256() -> str:
     """Fingerprint of every source an inference forward of any precision runs through (edge kernels of all precisions, node
     kernels, packing): what a measured error table (tools/prec_errors.py) is valid for."""
     return _sources_sha256(("egnn_forward.hip", "edge_x_m16.hip", "edge_bf16_v4.hip", "edge_bf16_v3.hip", "edge_small.hip",
-                            "edge_bf16x3.hip", "edge_f16c8.hip", "node_bf16.hip", "edge_tile.h", "kernels.h", "common.h", "diag.h"))
+                            "edge_bf16x3.hip", "edge_f16c8.hip", "edge_f16c8w.hip", "edge_f16c8_mphase2.inc", "edge_f16c8_mphase4.inc",
+                            "edge_f16c8w_mphase1.inc", "edge_f16c8w_mphase2.inc", "edge_f16c8w_mphasek.inc", "node_bf16.hip", "edge_tile.h",
+                            "kernels.h", "common.h", "diag.h"))
 
 
 def training_sources_sha256() -> str:
@@ -60,7 +62,8 @@ def training_sources_sha256() -> str:
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(_HERE, "csrc")
-    names = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.cpp")))
+    names = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.cpp")) +
+                   glob.glob(os.path.join(csrc, "*.inc")))
     names += [os.path.join(_HERE, "autograd.py"), os.path.join(_HERE, "gemm.py")]
     for path in names:
         with open(path, "rb") as f:

@@ -252,18 +252,22 @@ def test_graph_plan_is_a_csr_view_of_any_edge_list(sizes, n_edges, seed):
 
 
 def test_generated_f16c8_matrix_phases_match_their_generator():
-    """csrc/edge_f16c8_mphase{2,4}.inc (fully unrolled operand pipelines: ring slots, LDS offsets and every s_waitcnt lgkmcnt
-    count) are generated by tools/gen/gen_c8_mphase.py: the committed files must be what the generator prints, and every wait
-    count must equal the number of LDS reads issued after the read it waits for (recounted here from the text)."""
+    """csrc/edge_f16c8_mphase{2,4}.inc and csrc/edge_f16c8w_mphase{1,2,k}.inc (fully unrolled operand pipelines: ring slots, LDS
+    offsets and every s_waitcnt lgkmcnt count) are generated by tools/gen/gen_c8_mphase.py: the committed files must be what the
+    generator prints, and every wait count must equal the number of LDS reads issued after the read it waits for (recounted here
+    from the text)."""
     import re
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for cb in (2, 4):
-        want = subprocess.run([sys.executable, os.path.join(root, "tools", "gen", "gen_c8_mphase.py"), str(cb)], capture_output=True,
+    # (generator arguments, file, LDS reads: fp16 pieces + two per e4m3 operand)
+    for args, name, reads in ((["2"], "edge_f16c8_mphase2.inc", 32), (["4"], "edge_f16c8_mphase4.inc", 32),
+                              (["w", "1"], "edge_f16c8w_mphase1.inc", 32), (["w", "2"], "edge_f16c8w_mphase2.inc", 32),
+                              (["w", "k"], "edge_f16c8w_mphasek.inc", 16)):
+        want = subprocess.run([sys.executable, os.path.join(root, "tools", "gen", "gen_c8_mphase.py")] + args, capture_output=True,
                               text=True, check=True, env={k: v for k, v in os.environ.items() if not k.startswith("C8_")}).stdout
-        have = open(os.path.join(root, "diffusion_model_amd", "csrc", f"edge_f16c8_mphase{cb}.inc")).read()
-        assert have == want, f"edge_f16c8_mphase{cb}.inc is stale: python tools/gen/gen_c8_mphase.py {cb} > ..."
+        have = open(os.path.join(root, "diffusion_model_amd", "csrc", name)).read()
+        assert have == want, f"{name} is stale: python tools/gen/gen_c8_mphase.py {' '.join(args)} > ..."
         # recount: walk the text, track the issue position of every register's latest read, check each wait
         pos, last_read, nreads = 0, {}, []
         pending_wait = None
@@ -282,4 +286,4 @@ def test_generated_f16c8_matrix_phases_match_their_generator():
             if m:
                 assert pending_wait == pos - last_read[m.group(2)], line      # both halves landed = the younger one landed
                 pending_wait = None
-        assert pos == 16 + 16     # 16 fp16 pieces + 8 e4m3 operands of two reads
+        assert pos == reads
