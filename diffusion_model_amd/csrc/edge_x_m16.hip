@@ -57,22 +57,9 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r15 = lane & 15, q4 = lane >> 4;
   const int KP = p.WxP;
-#ifdef XM16_SHARE_MAP   // experiment: one column share per XCD (as edge_f16c8w.hip); grid 8 x ceil(tiles / 4)
-  int tile, half = 0;
-  if (p.WxP == 1024) {
-    const int ntiles = (p.E + kR - 1) / kR, per = (ntiles + 3) >> 2;
-    const int xcd = blockIdx.x & 7, g = xcd >> 1;
-    half = xcd & 1;
-    tile = g * per + (int)(blockIdx.x >> 3);
-    if (tile >= min((g + 1) * per, ntiles)) return;
-  } else {
-    tile = xcd_tile(blockIdx.x, gridDim.x);
-  }
-#else
   const int nsplit = p.WxP / 512;
   const int j = xcd_tile(blockIdx.x, gridDim.x);
   const int tile = j / nsplit, half = j - tile * nsplit;
-#endif
   const int e0 = tile * kR;
   const int nvalid = min(kR, p.E - e0);
 
@@ -360,19 +347,11 @@ bool edge_x_m16_supported(const EdgeParams& p) {
 }
 
 // coordinate kernel only; p.w2x16 = mlp_x.2 packed by pack_frags_bf16_n16 (scaled by -1/log2(e))
-static inline int x16_grid(int tiles, int WxP) {
-#ifdef XM16_SHARE_MAP
-  return WxP == 1024 ? 8 * ((tiles + 3) / 4) : tiles;
-#else
-  return tiles * (WxP / 512);
-#endif
-}
-
 int launch_edge_x_m16(const EdgeParams& p, hipStream_t st) {
   const int tiles = (p.E + kR - 1) / kR;
   EdgeParams q = p;
   q.w2x = p.w2x16;
-  hipLaunchKernelGGL(edge_x_m16_kernel<false>, dim3(x16_grid(tiles, p.WxP)), dim3(kT), x16_smem_bytes(p.WxP), st, q);
+  hipLaunchKernelGGL(edge_x_m16_kernel<false>, dim3(tiles * (p.WxP / 512)), dim3(kT), x16_smem_bytes(p.WxP), st, q);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }
@@ -382,7 +361,7 @@ int launch_edge_x_m16_f16(const EdgeParams& p, hipStream_t st) {
   const int tiles = (p.E + kR - 1) / kR;
   EdgeParams q = p;
   q.w2x = p.w2x16;
-  hipLaunchKernelGGL((edge_x_m16_kernel<false, f16x8>), dim3(x16_grid(tiles, p.WxP)), dim3(kT), x16_smem_bytes(p.WxP), st, q);
+  hipLaunchKernelGGL((edge_x_m16_kernel<false, f16x8>), dim3(tiles * (p.WxP / 512)), dim3(kT), x16_smem_bytes(p.WxP), st, q);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }
@@ -392,7 +371,7 @@ int launch_edge_x_m16_save(const EdgeParams& p, hipStream_t st) {
   const int tiles = (p.E + kR - 1) / kR;
   EdgeParams q = p;
   q.w2x = p.w2x16;
-  hipLaunchKernelGGL(edge_x_m16_kernel<true>, dim3(x16_grid(tiles, p.WxP)), dim3(kT), x16_smem_bytes(p.WxP), st, q);
+  hipLaunchKernelGGL(edge_x_m16_kernel<true>, dim3(tiles * (p.WxP / 512)), dim3(kT), x16_smem_bytes(p.WxP), st, q);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }
