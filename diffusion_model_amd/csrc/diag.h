@@ -127,11 +127,14 @@ EGNN_DIAG_FLAG(kC8NoEpi, false);
 #endif
 #undef EGNN_DIAG_FLAG
 // EdgeParams::dbg (environment EGNN_DEBUG, read by a diagnostic build only): bit 0 = zero-size weight descriptor, bit 1 =
-// zero-size table descriptor (loads that never leave the CU).  The product build ignores the field at compile time.
+// zero-size table descriptor (loads that never leave the CU), bit 2 = every chunk reads chunk 0's weight fragments (edge_f16c8w.hip:
+// a weight stream that always hits the L2).  The product build ignores the field at compile time.
 #ifdef EGNN_DIAG
 __host__ __device__ inline bool drop_weight_loads(int dbg) { return (dbg & 1) != 0; }
 __host__ __device__ inline bool drop_table_loads(int dbg) { return (dbg & 2) != 0; }
+__host__ __device__ inline bool hot_weight_loads(int dbg) { return (dbg & 4) != 0; }
 #else
+__host__ __device__ constexpr bool hot_weight_loads(int) { return false; }
 __host__ __device__ constexpr bool drop_weight_loads(int) { return false; }
 __host__ __device__ constexpr bool drop_table_loads(int) { return false; }
 #endif

@@ -126,10 +126,13 @@ __global__ __launch_bounds__(kT, 2) void edge_c8w_kernel(const EdgeParams p) {
   const int cb0 = IS_M ? wave : half * 16 + wave * 2;            // first 32-column block of this wave
   const unsigned w0 = (unsigned)cb0 * KS16 * 1024u;              // fp16 stream: 1 KiB per (column block, k-step of 16)
   const unsigned w80 = (unsigned)cb0 * KS32 * 2048u;             // e4m3 stream: 2 KiB per (column block, 32 hidden units)
-  auto ld16 = [&](const int c, const int ks, const int cb) {     // fp16 fragment of (chunk c, k-step ks of 16, column block cb)
+  const bool hotw = diag::hot_weight_loads(p.dbg);
+  auto ld16 = [&](const int cq, const int ks, const int cb) {     // fp16 fragment of (chunk c, k-step ks of 16, column block cb)
+    const int c = hotw ? 0 : cq;
     return ldbuf_v8<f16x8>(rs_w, lane16, w0 + ((unsigned)cb * KS16 + (unsigned)(4 * c + ks)) * 1024u);
   };
-  auto ld8 = [&](const int c, const int t, const int cb) {       // e4m3 fragment (32 bytes per lane) of (chunk c, hidden half t, column block cb)
+  auto ld8 = [&](const int cq, const int t, const int cb) {       // e4m3 fragment (32 bytes per lane) of (chunk c, hidden half t, column block cb)
+    const int c = hotw ? 0 : cq;
     const unsigned o = w80 + ((unsigned)cb * KS32 + (unsigned)(2 * c + t)) * 2048u;
     const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rs_w8, lane16, __builtin_amdgcn_readfirstlane(o), 0);
     const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rs_w8, lane16, __builtin_amdgcn_readfirstlane(o + 1024u), 0);
