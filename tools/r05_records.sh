@@ -20,6 +20,6 @@ print("c2", d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["traffic"], d
 t=d["tolerance_grade"]; print("tg", t["precision"], t["ms_per_step"], t["golden_max_rel_err"], t["meets_tolerance"], t["candidates"])
 print("train", d["ddp_train"]["ms_per_step"], d["ddp_train"]["roofline"]["traffic"], "tg-train", d["ddp_train_tolerance_grade"]["ms_per_step"])
 print("c3", d["c3"]["ms_per_step"], d["c3"]["metric"])
-r=json.load(open(f"gpurun_out/{tag}/bench_2rank_gloo.json"))
+r=json.loads([l for l in open(f"gpurun_out/{tag}/bench_2rank_gloo.json") if l.startswith("{")][-1])
 print("2rank", r["ms_per_step"], r.get("ddp_efficiency"), r["ddp_train"].get("ranks_share_device"), r["ddp_train"].get("ddp_efficiency_basis"), r["ddp_train"].get("efficiency_vs_no_collective"))
 PY
