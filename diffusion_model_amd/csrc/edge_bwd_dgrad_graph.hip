@@ -198,6 +198,18 @@ __global__ __launch_bounds__(kTG, 2) void edge_dgrad_graph_kernel(const DgradGra
     LDS_RD(a[0], lds_a1_base, 0); LDS_RD(a[1], lds_a1_base, 512); LDS_RD(a[2], lds_a1_base, 1024); LDS_RD(a[3], lds_a1_base, 1536);
     auto chunk = [&](const int c, const bool copy, const bool last, bf16x8 (&xs)[PP]) {
       const unsigned abase = lds_a1_base + off_cur, nbase = lds_a1_base + off_nxt;
+#ifdef EGNN_EXP_DG_HALFLDS   // timing experiment (wrong results): every operand piece feeds two k-steps = half the LDS reads
+#define GROUP(S, RB)                                                                                          \
+      {                                                                                                       \
+        if (((S) & 1) == 0) {                                                                                 \
+          if ((RB) == 0) LDS_WAIT(3); else if ((RB) == 1) LDS_WAIT(2); else if ((RB) == 2) LDS_WAIT(1); else LDS_WAIT(0); \
+        }                                                                                                     \
+        asm volatile("" : "+v"(a[RB]));                                                                       \
+        acc[RB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[RB], bq[S], acc[RB], 0, 0, 0);                    \
+        if ((S) == 1) LDS_RD(a[RB], abase, 2 * 4128 + (RB) * 512);                                            \
+        else if ((S) == 3 && !last) LDS_RD(a[RB], nbase, (RB) * 512);                                         \
+      }
+#else
 #define GROUP(S, RB)                                                                                          \
       {                                                                                                       \
         if (!last || (S) < 3 || (RB) == 0) LDS_WAIT(3);                                                       \
@@ -209,6 +221,7 @@ __global__ __launch_bounds__(kTG, 2) void edge_dgrad_graph_kernel(const DgradGra
         if ((S) < 3) LDS_RD(a[RB], abase, ((S) + 1) * 4128 + (RB) * 512);                                     \
         else if (!last) LDS_RD(a[RB], nbase, (RB) * 512);                                                     \
       }
+#endif
 #define KSTEP(S)                                                                                              \
       GROUP(S, 0) GROUP(S, 1) GROUP(S, 2) GROUP(S, 3)                                                         \
       if (copy && ((S) % (4 / PP)) == 4 / PP - 1) {                                                           \
