@@ -14,6 +14,8 @@
 //   * weight fragments packed [16-column block][32-deep k-step][lane][8 bf16] (pack_frags_bf16_n16);
 //   * the row sums of the head s = w3 . SiLU(a2) + b3 run over the 16 lanes of a DPP row (tile128::butterfly16).
 // Prologue and segment sums are the shared ones of edge_tile.h.
+#include <cstdlib>
+
 #include "diag.h"
 #include "edge_tile.h"
 
@@ -44,9 +46,14 @@ typedef __attribute__((ext_vector_type(4))) float f32x4v;
 // leaves, so that egcl_backward_heads_saved / the wgrad GEMMs find the same buffers.
 // V8 = the MFMA operand type: bf16x8 (precision bf16) or f16x8 (precision fp16: v_mfma_f32_16x16x32_f16, same rate, 11
 // significant bits; weights packed x 2^8, kernels.h "MFMA operand type").
-template <bool SAVE, typename V8 = bf16x8>
+// PERSIST = true (inference): one workgroup per CU walks over its share of the (tile, column share) units, and the NEXT unit's edge
+// indices, coordinates, first table rows and first weight fragments are requested under the CURRENT unit's epilogue (4 us of vector
+// arithmetic, the matrix pipe idle): the three dependent memory round trips of the prologue (2.2 us of a 26 us workgroup,
+// profiles/r03t_fwd_wg_stamps.txt) and the dispatch gap between workgroups (0.3 us) leave the critical path.
+template <bool SAVE, typename V8 = bf16x8, bool PERSIST = false>
 __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
   static_assert(!(SAVE && OpTraits<V8>::f16), "the training forward keeps bf16 activations");
+  static_assert(!(SAVE && PERSIST), "the persistent form is the inference kernel");
   if constexpr (OpTraits<V8>::f16) f16_saturate_mode();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const Lds L(smem);
@@ -58,7 +65,57 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
   const int r15 = lane & 15, q4 = lane >> 4;
   const int KP = p.WxP;
   const int nsplit = p.WxP / 512;
-  const int j = xcd_tile(blockIdx.x, gridDim.x);
+  const int NC = KP / kKC, KS = KP / 32;
+  const int brow = tid >> 3, kg = tid & 7;   // this thread builds rows brow and brow + 64, columns 8 kg .. 8 kg + 7 of a chunk
+  const rsrc_t rs_tab = make_rsrc(p.table, diag::drop_table_loads(p.dbg) ? 0u : (unsigned)((size_t)p.N * p.TC * 2));
+  const rsrc_t rs_w = make_rsrc(p.w2x, diag::drop_weight_loads(p.dbg) ? 0u : (unsigned)((size_t)p.WxP * KP * 2));
+  const unsigned offP = 0u, offQ = (unsigned)p.WxP * 2u;   // fp16 table: {Px | Qx | Pm | Qm}
+  const unsigned lane16 = lane * 16u;
+  const int nunits = PERSIST ? ((p.E + kR - 1) / kR) * nsplit : (int)gridDim.x;
+  UnitH uc0, uc1;   // table pieces of chunk 0
+  V8 bq[2][4];      // weight fragments of the 2 k-steps of the current chunk
+  // PERSIST: what the prologue of the next unit needs, requested under the epilogue of the current one
+  int pf_d0, pf_s0, pf_d1, pf_s1, pf_d, pf_s, pf_r0, pf_r1;   // (pf_r0/1: row_ptr[dst], row_ptr[dst + 1] of row tid: the segment modes)
+  float pf_x[6];
+  auto unit_of = [&](const int bv, int& tile_o, int& half_o) {
+    const int jj = xcd_tile(bv, nunits);
+    tile_o = jj / nsplit;
+    half_o = jj - tile_o * nsplit;
+  };
+  // (tq: the caller's copy of the thread index -- an opaque one inside the unit loop, so that brow / kg are re-derived there instead of
+  // living across the K loop)
+  auto prefetch_indices = [&](const int bv, const int tq) {   // this thread's two build rows (all threads) and row tid (threads 0-127)
+    int t, h;
+    unit_of(bv, t, h);
+    const int ne0 = t * kR, nnv = min(kR, p.E - ne0), br = tq >> 3;
+    const bool r0 = br < nnv, r1 = br + 64 < nnv, rt = tq < nnv && tq < kR;
+    pf_d0 = r0 ? p.edge_dst[ne0 + br] : 0; pf_s0 = r0 ? p.edge_src[ne0 + br] : 0;
+    pf_d1 = r1 ? p.edge_dst[ne0 + br + 64] : 0; pf_s1 = r1 ? p.edge_src[ne0 + br + 64] : 0;
+    pf_d = rt ? p.edge_dst[ne0 + tq] : 0; pf_s = rt ? p.edge_src[ne0 + tq] : 0;
+  };
+  auto prefetch_data = [&](const int bv, const int tq) {      // coordinates of row tid, table pieces of chunk 0, first weight fragments
+    int t, h;
+    unit_of(bv, t, h);
+    const unsigned k16 = (unsigned)(tq & 7) * 16u, l16 = (unsigned)(tq & 63) * 16u;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { pf_x[k] = p.x[3 * pf_d + k]; pf_x[3 + k] = p.x[3 * pf_s + k]; }   // (threads >= 128: node 0, unused; written by every thread so that nothing is carried around the K loop)
+    pf_r0 = p.row_ptr[pf_d]; pf_r1 = p.row_ptr[pf_d + 1];
+    unith_load(uc0, rs_tab, (unsigned)pf_d0 * (unsigned)p.TC * 2u + k16, (unsigned)pf_s0 * (unsigned)p.TC * 2u + k16, offP, offQ);
+    unith_load(uc1, rs_tab, (unsigned)pf_d1 * (unsigned)p.TC * 2u + k16, (unsigned)pf_s1 * (unsigned)p.TC * 2u + k16, offP, offQ);
+    const unsigned nw0 = (unsigned)(h * 32 + wave * 4) * KS * 1024u;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) bq[s][cb] = ldbuf_v8<V8>(rs_w, l16, nw0 + ((unsigned)cb * KS + s) * 1024u);
+  };
+  if constexpr (PERSIST) {
+    for (int i = tid; i < KP; i += kT) s_wd[i] = p.wdx[i];   // (ordered by the first unit's row barrier)
+    prefetch_indices(blockIdx.x, tid);
+    prefetch_data(blockIdx.x, tid);
+  }
+  int bv = blockIdx.x;
+  do {
+  const int j = xcd_tile(bv, nunits);
   const int tile = j / nsplit, half = j - tile * nsplit;
   const int e0 = tile * kR;
   const int nvalid = min(kR, p.E - e0);
@@ -66,24 +123,39 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
   DIAG_STAMP_SETUP(p.stamps + (size_t)wave * 32 * 4);
   DIAG_STAMP(30, 0);   // kernel entry
   WG_STAMP(0);
-  prologue_rows(p, L, e0, nvalid, p.wdx, KP, s_wd, tid);
+  // PERSIST: the thread index as the prologue / the epilogue see it is re-derived per unit from an opaque copy -- otherwise hipcc hoists
+  // their unit-invariant address arithmetic out of the unit loop and keeps it in registers ACROSS the K loop, whose build then runs
+  // on four temporaries (serial exp -> add -> rcp -> mul chains: +4 % kernel time, profiles/r05U_xp_ab.txt)
+  int tid_p = tid;
+  if constexpr (PERSIST) asm volatile("" : "+v"(tid_p));
+  const int lane_p = tid_p & 63;
+  if constexpr (!PERSIST) {
+    prologue_rows(p, L, e0, nvalid, p.wdx, KP, s_wd, tid);
+  } else {   // prologue_rows of edge_tile.h from the prefetched registers
+    const int tid = tid_p;
+    if (tid < kR) {
+      const float dx = pf_x[0] - pf_x[3], dy = pf_x[1] - pf_x[4], dz = pf_x[2] - pf_x[5];   // (rows past the list: index 0 twice = 0)
+      L.dst[tid] = pf_d;
+      L.src[tid] = pf_s;
+      L.diff[tid] = dx; L.diff[kR + tid] = dy; L.diff[2 * kR + tid] = dz;
+      const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+      L.d2[tid] = nrm * nrm;
+      reinterpret_cast<int*>(L.gseg)[tid] = pf_r0;        // (the message kernels' gate scratch: free in this kernel)
+      reinterpret_cast<int*>(L.gseg)[kR + tid] = pf_r1;
+    }
+    __syncthreads();
+  }
   DIAG_STAMP(30, 1);   // edge rows and geometry ready
   WG_STAMP(1);
 
   // ---- K loop ----
-  const int NC = KP / kKC, KS = KP / 32;
-  const int brow = tid >> 3, kg = tid & 7;   // this thread builds rows brow and brow + 64, columns 8 kg .. 8 kg + 7 of a chunk
-  const rsrc_t rs_tab = make_rsrc(p.table, diag::drop_table_loads(p.dbg) ? 0u : (unsigned)((size_t)p.N * p.TC * 2));
-  const rsrc_t rs_w = make_rsrc(p.w2x, diag::drop_weight_loads(p.dbg) ? 0u : (unsigned)((size_t)p.WxP * KP * 2));
-  const unsigned vdst0 = (unsigned)L.dst[brow] * (unsigned)p.TC * 2u + (unsigned)kg * 16u;
-  const unsigned vsrc0 = (unsigned)L.src[brow] * (unsigned)p.TC * 2u + (unsigned)kg * 16u;
-  const unsigned vdst1 = (unsigned)L.dst[brow + 64] * (unsigned)p.TC * 2u + (unsigned)kg * 16u;
-  const unsigned vsrc1 = (unsigned)L.src[brow + 64] * (unsigned)p.TC * 2u + (unsigned)kg * 16u;
+  const unsigned vdst0 = (unsigned)(PERSIST ? pf_d0 : L.dst[brow]) * (unsigned)p.TC * 2u + (unsigned)kg * 16u;
+  const unsigned vsrc0 = (unsigned)(PERSIST ? pf_s0 : L.src[brow]) * (unsigned)p.TC * 2u + (unsigned)kg * 16u;
+  const unsigned vdst1 = (unsigned)(PERSIST ? pf_d1 : L.dst[brow + 64]) * (unsigned)p.TC * 2u + (unsigned)kg * 16u;
+  const unsigned vsrc1 = (unsigned)(PERSIST ? pf_s1 : L.src[brow + 64]) * (unsigned)p.TC * 2u + (unsigned)kg * 16u;
   const float d2r0 = L.d2[brow], d2r1 = L.d2[brow + 64];
-  const unsigned offP = 0u, offQ = (unsigned)p.WxP * 2u;   // fp16 table: {Px | Qx | Pm | Qm}
   char* slot0 = s_a1 + (size_t)kg * (kR * 16) + (size_t)(brow ^ kg) * 16;
   char* slot1 = slot0 + 64 * 16;
-  const unsigned lane16 = lane * 16u;
   // LDS byte address of this lane's operand piece in buffer 0 for the two k-steps of a chunk (k-groups q4 and 4 + q4)
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)s_a1;
   const unsigned abase0 = lds0 + (unsigned)q4 * (kR * 16) + (unsigned)(r15 ^ q4) * 16u;
@@ -116,15 +188,23 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
   // chunk 0: both rows' table pieces and the first weight fragments are requested, THEN the segment structure of the tile is
   // worked out (two barriers, waves 0 and 1 only) while they are in flight, then the activations are finished
   // (one row after the other and the segment structure in front of them: 2.3 us per 27 us workgroup, tools/fwd_stamps.py)
-  UnitH uc0, uc1;
-  unith_load(uc0, rs_tab, vdst0, vsrc0, offP, offQ);
-  unith_load(uc1, rs_tab, vdst1, vsrc1, offP, offQ);
-  V8 bq[2][4];   // weight fragments of the 2 k-steps of the current chunk
+  if constexpr (!PERSIST) {
+    unith_load(uc0, rs_tab, vdst0, vsrc0, offP, offQ);
+    unith_load(uc1, rs_tab, vdst1, vsrc1, offP, offQ);
 #pragma unroll
-  for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) bq[s][cb] = ldbuf_v8<V8>(rs_w, lane16, w0 + ((unsigned)cb * KS + s) * 1024u);
-  const int S = prologue_segments<false>(p, L, e0, nvalid, tid, lane, wave);   // seg_mode: under the first matrix phase, below
+      for (int cb = 0; cb < 4; ++cb) bq[s][cb] = ldbuf_v8<V8>(rs_w, lane16, w0 + ((unsigned)cb * KS + s) * 1024u);
+  }
+  const int S = prologue_segments<false>(p, L, e0, nvalid, tid_p, lane_p, wave);   // seg_mode: under the first matrix phase, below
+  if constexpr (PERSIST) {   // segment_mode of edge_tile.h from the prefetched row_ptr words of the segment's first row (read in the epilogue)
+    if (tid_p < S) {
+      const int* rp = reinterpret_cast<const int*>(L.gseg);
+      const int r0 = L.seg_rs[tid_p];
+      const bool first = (e0 + r0) == rp[r0], last = (e0 + L.seg_re[tid_p] + 1) == rp[kR + r0];
+      L.seg_mode[tid_p] = (first && last) ? 2 : (first ? 1 : 0);
+    }
+  }
   {
     const V8 o0 = unith_finish<V8>(uc0, s_wd + kg * 8, d2r0, slot0);
     const V8 o1 = unith_finish<V8>(uc1, s_wd + kg * 8, d2r1, slot1);
@@ -198,10 +278,10 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
   vload(1);
   if (wave < 4) {
     // row_ptr loads of the segment modes (needed by the epilogue only) ride under the first matrix phase of wave 0
-    const int my_mode = tid < S ? segment_mode(p, L, e0, tid) : 0;
+    const int my_mode = (!PERSIST && tid_p < S) ? segment_mode(p, L, e0, tid_p) : 0;
     for (int i = 0; i < NC - 1; ++i) {
       mphase(i, false);
-      if (i == 0 && tid < S) L.seg_mode[tid] = my_mode;
+      if (!PERSIST && i == 0 && tid_p < S) L.seg_mode[tid_p] = my_mode;
       vfinish(i + 1);
       vload(i + 2);
       __syncthreads();
@@ -222,7 +302,14 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
   DIAG_RSTAMP(31, 2);
 
   // ---- epilogue: s[row] = [b3] + sum_n w3[n] * SiLU(a2[row][n] + b2[n]) over this workgroup's 512 columns ----
-  // accumulator layout of the 16x16 tile: column = lane & 15, row = 4 (lane >> 4) + register
+  int tid_e = tid;
+  if constexpr (PERSIST) asm volatile("" : "+v"(tid_e));
+  const int lane_e = tid_e & 63, r15_e = lane_e & 15, q4_e = lane_e >> 4;
+  // accumulator layout of the 16x16 tile: column = lane_e & 15, row = 4 (lane_e >> 4) + register
+  const bool more = PERSIST && bv + (int)gridDim.x < nunits;   // (uniform)
+  // (the last unit requests itself again: unconditional writes, so that no old value of the prefetch registers is carried around the K loop)
+  const int bnext = more ? bv + (int)gridDim.x : bv;
+  if constexpr (PERSIST) prefetch_indices(bnext, tid_e);
   float part[32];
 #pragma unroll
   for (int v = 0; v < 32; ++v) part[v] = 0.f;
@@ -230,21 +317,21 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
                           // the accumulators then hold them for the SiLU below
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
-      const float bb = p.b2x[16 * (cb0 + cb) + r15];
+      const float bb = p.b2x[16 * (cb0 + cb) + r15_e];
 #pragma unroll
       for (int rb = 0; rb < 8; ++rb)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[rb][cb][i] = fmaf(acc[rb][cb][i], kNegLog2e, bb);
     }
-    // Row-major bf16 through a per-wave LDS tile kept TRANSPOSED, T[64 columns][16 rows] (32 bytes per column): a lane's four
-    // values of a column block are rows 4 q4 .. 4 q4 + 3 of ONE column = one 8-byte write (16-byte tile rows before: sixteen
-    // 2-byte writes per row block), and ds_read_b64_tr_b16 hands lane j of a 16-lane group row j of four neighbouring columns
+    // Row-major bf16 through a per-wave LDS tile kept TRANSPOSED, T[64 columns][16 rows] (32 bytes per column): a lane_e's four
+    // values of a column block are rows 4 q4_e .. 4 q4_e + 3 of ONE column = one 8-byte write (16-byte tile rows before: sixteen
+    // 2-byte writes per row block), and ds_read_b64_tr_b16 hands lane_e j of a 16-lane_e group row j of four neighbouring columns
     // (the group addresses 4 tile rows x 16 elements; gemm_tn.hip reads its operands the same way).  Two such reads = 8 columns =
     // one 16-byte store; a store instruction covers 64 contiguous bytes of each of 16 rows.
     typedef __attribute__((ext_vector_type(2))) unsigned u32x2s;
     char* tile = s_a1 + (size_t)wave * (64 * 32);
     const unsigned tile_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)tile;
-    const int g16 = lane >> 4, j16 = lane & 15;
+    const int g16 = lane_e >> 4, j16 = lane_e & 15;
     const unsigned rd_addr = tile_lds + (unsigned)((8 * g16 + (j16 >> 2)) * 32 + (j16 & 3) * 8);   // column 8 g16 + (j >> 2), rows 4 (j & 3) ..
     __bf16* tout = static_cast<__bf16*>(p.g_a2_out) + (size_t)e0 * p.WxP + 16 * cb0;
 #pragma unroll
@@ -254,7 +341,7 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
         u32x2s w;
         asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w.x) : "v"(acc[rb][cb][0]), "v"(acc[rb][cb][1]));
         asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w.y) : "v"(acc[rb][cb][2]), "v"(acc[rb][cb][3]));
-        *reinterpret_cast<u32x2s*>(tile + (16 * cb + r15) * 32 + q4 * 8) = w;
+        *reinterpret_cast<u32x2s*>(tile + (16 * cb + r15_e) * 32 + q4_e * 8) = w;
       }
       __builtin_amdgcn_wave_barrier();
       u32x2s t[2][2];   // [half of the 64 columns][4-column piece]
@@ -280,7 +367,7 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
   typedef __attribute__((ext_vector_type(2))) float f32x2;
 #pragma unroll
   for (int cb = 0; cb < 4; ++cb) {
-    const int n = 16 * (cb0 + cb) + r15;
+    const int n = 16 * (cb0 + cb) + r15_e;
     const float bb = p.b2x[n], w = p.w3x[n];
     constexpr float kAcc = kNegLog2e / OpTraits<V8>::wscale;   // fp16: the weight fragments carry 2^8
     const f32x2 bb2 = {bb, bb}, w2 = {w, w}, k2 = {kAcc, kAcc}, one2 = {1.0f, 1.0f};
@@ -301,32 +388,38 @@ __global__ __launch_bounds__(kT, 2) void edge_x_m16_kernel(const EdgeParams p) {
       }
   }
   WG_STAMP(6);   // second-layer SiLU + w3 products done
+  if constexpr (PERSIST) prefetch_data(bnext, tid_e);   // (the accumulators are dead: registers to spare)
   {
     float t0, t1;
-    butterfly16(part, lane, t0, t1);   // value indices 2 m, 2 m + 1 (m = lane & 15): row block m >> 1, register 2 (m & 1) + {0, 1}
-    const int row = 16 * (r15 >> 1) + 4 * q4 + 2 * (r15 & 1);
+    butterfly16(part, lane_e, t0, t1);   // value indices 2 m, 2 m + 1 (m = lane_e & 15): row block m >> 1, register 2 (m & 1) + {0, 1}
+    const int row = 16 * (r15_e >> 1) + 4 * q4_e + 2 * (r15_e & 1);
     L.part[wave * kR + row] = t0;
     L.part[wave * kR + row + 1] = t1;
   }
   __syncthreads();
   WG_STAMP(7);   // row partials of the 8 waves in LDS
-  if (tid < kR) {
+  if (tid_e < kR) {
     float v = half == 0 ? p.scal[0] : 0.f;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) v += L.part[w * kR + tid];
-    L.val[tid] = v;
+    for (int w = 0; w < 8; ++w) v += L.part[w * kR + tid_e];
+    L.val[tid_e] = v;
     // training forward: this column share of s_e for the backward's dL/d(x_i - x_j) = dL/d(sum_x[i]) * s_e.  (Rounds 3 / 4 up to
     // r04m never stored it -- the comment above promised it, the statement was missing: egcl_backward_heads_saved then read
     // whatever the buffer held, zeros in a fresh process, i.e. the term was silently dropped; found by running the graph-form
     // gradient test after another training test, fixed with tests/test_training.py::test_kept_buffers_are_fully_written.)
-    if constexpr (SAVE) { if (tid < nvalid && p.s_half_out) p.s_half_out[(size_t)half * p.E + e0 + tid] = v; }
+    if constexpr (SAVE) { if (tid_e < nvalid && p.s_half_out) p.s_half_out[(size_t)half * p.E + e0 + tid_e] = v; }
   }
   __syncthreads();
   WG_STAMP(8);   // s_e per row ready
-  coordinate_segment_sums(p, L, S, tile, half, tid, lane, wave);
+  coordinate_segment_sums(p, L, S, tile, half, tid_e, lane_e, wave);
   DIAG_STAMP(31, 0);   // epilogue done
   WG_STAMP(4);
   WG_STAMP_HW();
+  if constexpr (!PERSIST) break;
+  if (!more) break;
+  bv += (int)gridDim.x;
+  __syncthreads();   // the row / segment arrays of this unit have been read
+  } while (true);
 }
 
 }  // namespace
@@ -338,7 +431,25 @@ int init_edge_x_m16_attributes() {
                                160 * 1024));
   EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_x_m16_kernel<false, f16x8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                160 * 1024));
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_x_m16_kernel<false, bf16x8, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               160 * 1024));
+  EGNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_x_m16_kernel<false, f16x8, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               160 * 1024));
   return EGNN_OK;
+}
+
+// grid of the persistent form: one workgroup per CU when there are more than two units per CU, else 0 (EGNN_X_PERSIST=0: A/B switch,
+// read per launch so that a test can compare the two forms bit for bit in one process)
+static int persistent_grid(int units) {
+  const char* e = getenv("EGNN_X_PERSIST");
+  static int ncu = 0;
+  if (e && atoi(e) == 0) return 0;
+  if (ncu == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    ncu = n;
+  }
+  return units > 2 * ncu ? ncu : 0;
 }
 
 bool edge_x_m16_supported(const EdgeParams& p) {
@@ -351,7 +462,9 @@ int launch_edge_x_m16(const EdgeParams& p, hipStream_t st) {
   const int tiles = (p.E + kR - 1) / kR;
   EdgeParams q = p;
   q.w2x = p.w2x16;
-  hipLaunchKernelGGL(edge_x_m16_kernel<false>, dim3(tiles * (p.WxP / 512)), dim3(kT), x16_smem_bytes(p.WxP), st, q);
+  const int units = tiles * (p.WxP / 512), pg = persistent_grid(units);
+  if (pg > 0) hipLaunchKernelGGL((edge_x_m16_kernel<false, bf16x8, true>), dim3(pg), dim3(kT), x16_smem_bytes(p.WxP), st, q);
+  else hipLaunchKernelGGL(edge_x_m16_kernel<false>, dim3(units), dim3(kT), x16_smem_bytes(p.WxP), st, q);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }
@@ -361,7 +474,9 @@ int launch_edge_x_m16_f16(const EdgeParams& p, hipStream_t st) {
   const int tiles = (p.E + kR - 1) / kR;
   EdgeParams q = p;
   q.w2x = p.w2x16;
-  hipLaunchKernelGGL((edge_x_m16_kernel<false, f16x8>), dim3(tiles * (p.WxP / 512)), dim3(kT), x16_smem_bytes(p.WxP), st, q);
+  const int units = tiles * (p.WxP / 512), pg = persistent_grid(units);
+  if (pg > 0) hipLaunchKernelGGL((edge_x_m16_kernel<false, f16x8, true>), dim3(pg), dim3(kT), x16_smem_bytes(p.WxP), st, q);
+  else hipLaunchKernelGGL((edge_x_m16_kernel<false, f16x8>), dim3(units), dim3(kT), x16_smem_bytes(p.WxP), st, q);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }

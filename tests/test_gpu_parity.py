@@ -732,6 +732,39 @@ def test_width_sweep_all_edge_kernel_variants(H, m_size, wm, wx, wh):
             assert ex <= tol, (scope, precision, "eps_x")
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("wx", [1024, 512])
+def test_persistent_coordinate_kernel_is_bitwise_the_per_tile_kernel(precision, wx, monkeypatch):
+    """csrc/edge_x_m16.hip, PERSIST form (one workgroup per CU walking over its units with the next unit's prologue requested under
+    the current epilogue; chosen when there are more than two units per CU) against the one-workgroup-per-unit form (EGNN_X_PERSIST=0,
+    read per launch): the same arithmetic in the same order, so every output bit must agree -- on a ragged batch whose tile count is
+    no multiple of anything (a last tile of a few rows, graphs that straddle tiles, a single-atom graph), one layer and two."""
+    sizes = [61, 64, 1, 57, 64, 33, 64, 64, 50, 64, 64, 63, 64, 17, 64, 64, 64, 59, 64, 64, 64, 64, 2, 64, 64, 64, 64, 64, 64, 64] * (1 if wx == 1024 else 2)
+    E = sum(n * (n - 1) for n in sizes)
+    props = torch.cuda.get_device_properties(0)
+    assert (E + 127) // 128 * (wx // 512) > 2 * props.multi_processor_count, "the batch must be large enough for the persistent form"
+    H = 36
+    d = dims_for(H, 256, wx, wx, 128)
+    sd = egnn_ref.init_state_dict(2, **d, seed=5)
+    n = sum(sizes)
+    g = torch.Generator().manual_seed(4)
+    h, x = torch.randn(n, H, generator=g).to(DEV), torch.randn(n, 3, generator=g).to(DEV)
+    ei = dma.fully_connected_edge_index(sizes, device=DEV)
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes)).to(DEV)
+    net = build_net(sd, d, 2, precision=precision, norm_scope="graph")
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("EGNN_X_PERSIST", flag)
+        with torch.no_grad():
+            h1, x1 = net.egcl_list[0](ei, h, x, batch=batch)
+            h2, x2 = net(ei, h, x, batch=batch)
+        torch.cuda.synchronize()
+        out[flag] = [t.cpu() for t in (h1, x1, h2, x2)]
+    for a, b, name in zip(out["1"], out["0"], ("h layer 1", "x layer 1", "h", "x")):
+        assert torch.isfinite(a).all(), name
+        assert torch.equal(a, b), f"{name}: persistent and per-tile coordinate kernels differ (max {float((a - b).abs().max()):.3e})"
+
+
 _FALLBACK_SNIPPET = r"""
 import sys, torch, numpy as np
 sys.path.insert(0, {root!r})
