@@ -705,7 +705,8 @@ def test_generate_batches_across_data():
     (36, 256, 1024, 1024, 256),   # reference widths: v3 X (two column blocks) + M
     (36, 256, 128, 256, 64),      # v3 X with one column block, narrow message MLP
     (3, 256, 64, 512, 128),       # unconditional variant (H = 3) on the v3 path
-    (36, 250, 192, 512, 96),      # m_size padded to 256
+    (36, 250, 192, 512, 96),      # m_size padded to 256 (f16c8: the 16x16-tile kernels: 192 is no multiple of 128)
+    (36, 256, 256, 512, 128),     # f16c8 on 32x32 tiles with ONE 512-column share (4 chunks in the K-split message kernel)
     (36, 64, 128, 128, 64),       # m_size 64: fallback kernels
     (5, 10, 30, 22, 18),          # nothing aligned
 ])
