@@ -445,9 +445,12 @@ def sample_leg(args, rk, precision=None, batch=None, atoms=None, steps=None, war
                                         "(v_mfma_f32_16x16x32_f16) + message kernel edge_kernel_bf16_v4<1,true,..,f16x8>",
                                 "bf16x3": "fused edge pass of one EGCL layer: edge_x3_kernel<false> + edge_x3_kernel<true> "
                                           "(head/remainder operands, 3 bf16 MFMAs per product)",
-                                "f16c8": "fused edge pass of one EGCL layer: edge_c8_kernel<false> + edge_c8_kernel<true> (fp16 heads on "
-                                         "v_mfma_f32_16x16x32_f16 + both remainder products on one v_mfma_scale_f32_16x16x128_f8f6f4 "
-                                         "with e4m3 operands and fixed block scales)",
+                                "f16c8": ("fused edge pass of one EGCL layer: edge_c8_kernel<false> + edge_c8_kernel<true> (fp16 heads on "
+                                          "v_mfma_f32_16x16x32_f16 + both remainder products on one v_mfma_scale_f32_16x16x128_f8f6f4 "
+                                          "with e4m3 operands and fixed block scales)") if os.environ.get("EGNN_C8_TILE") == "16" else
+                                         ("fused edge pass of one EGCL layer: edge_c8w_kernel<false, 2> + edge_c8wk_kernel (fp16 heads on "
+                                          "v_mfma_f32_32x32x16_f16 + both remainder products on one v_mfma_scale_f32_32x32x64_f8f6f4 "
+                                          "with e4m3 operands and fixed block scales)"),
                                 "fp32": "fused edge pass of one EGCL layer: edge_kernel<F32> (v_mfma_f32_32x32x2_f32)"}[precision],
                      "avg_launch_ms": edge_ms.value, "launches": edge_n.value,
                      "algorithmic_flop_per_launch": flops_per_launch,
