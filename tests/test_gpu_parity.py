@@ -802,3 +802,17 @@ def test_non_default_bf16_edge_kernels(edge):
     out = subprocess.run([sys.executable, "-c", _FALLBACK_SNIPPET.format(root=root)], env=env, capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("switch", [{"EGNN_C8_TILE": "16"}, {"EGNN_C8_KSPLIT": "0"}])
+def test_f16c8_alternative_kernels_meet_the_tolerance(switch):
+    """The A/B switches of precision f16c8 keep working paths: EGNN_C8_TILE=16 = the 16x16-tile kernels of csrc/edge_f16c8.hip at the
+    reference widths (the default runs them only for message widths that are no multiple of 128), EGNN_C8_KSPLIT=0 = the 32x32-tile
+    message kernel with one column block per wave.  Same bar as the default path (1e-4 against the oracle); read once per process,
+    hence the child process."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    snippet = _FALLBACK_SNIPPET.replace('net.precision = "bf16"', 'net.precision = "f16c8"').replace("eh <= 1e-2 and ex <= 1e-2", "eh <= 1e-4 and ex <= 1e-4")
+    out = subprocess.run([sys.executable, "-c", snippet.format(root=root)], env=dict(os.environ, **switch), capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
