@@ -21,7 +21,7 @@
 namespace egnn {
 namespace {
 
-constexpr int kTD = 512, kRD = 128, kRBD = 4, kRPADD = kRD + 1, kKCD = 64;
+constexpr int kRD = 128, kRBD = 4, kRPADD = kRD + 1, kKCD = 64;
 constexpr size_t kA1D = (size_t)8 * kRPADD * 16;   // one A chunk [8 k-groups][129][8 bf16]
 constexpr int kRingD = 3;
 constexpr size_t kOffDstD = 0;                      // int[R]

@@ -28,8 +28,10 @@
 // matrix phase of chunk c (two register sets), the fp32 table rows of a build right after the previous build.  That fits beside
 // the accumulators at 2 column blocks per wave (256 columns per workgroup, 64 accumulator registers); at 4 column blocks (512
 // columns: the mlp_x activations built twice per tile instead of four times) the operands of the second matrix instruction do
-// not fit beside 128 accumulators -- hipcc spills inside the K loop in every schedule tried -- so the coordinate
-// branch runs as WxP / 256 column shares (kCBX).
+// not fit beside 128 accumulators with those distances -- hipcc spills inside the K loop -- so the coordinate branch (kCBX = 4)
+// runs the "tight" schedule of edge_c8_kernel: every operand group requested as late as its latency allows.
+// Since r05C the default f16c8 kernels are the 32x32-tile ones of edge_f16c8w.hip; these run with EGNN_C8_TILE=16 and for message
+// widths that are a multiple of 64 but not of 128.
 #include "diag.h"
 #include "edge_tile.h"
 #include <type_traits>

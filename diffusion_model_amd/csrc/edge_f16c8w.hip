@@ -7,11 +7,15 @@
 // Why: the 16x16 kernels are stall-bound, not power-bound (held clock 2.38 GHz, MFMA pipe ~50 % busy: DESIGN.md section 4), and an
 // MFMA holds its SIMD's vector issue for 8 cycles whatever its shape (MI355X_MICROARCH.md, cycle constants): 48 MFMAs per wave and
 // chunk take 384 issue cycles out of the partner wave's activation build, 24 of the 32x32 shapes take 192 -- and there are half as
-// many operand waits.  (edge_x_m16.hip chose 16x16 tiles because its loop runs against the power limit at 2.1 GHz, where the
-// 16x16 shape holds a higher clock; that does not apply here.)
-// Same workgroup tile (128 edges; coordinate branch 512 columns = 2 column blocks of 32 per wave, message branch 256 columns = 1
-// per wave), same two schedules (late requests beside 128 accumulator registers, whole-chunk request distances beside 64), same
-// generated matrix-phase bodies (tools/gen/gen_c8_mphase.py w); the epilogues are the shared 32x32-accumulator ones of edge_tile.h.
+// many operand waits.  Measured: coordinate kernel 4.13 -> 3.54 ms, its matrix pipe 50 % -> 71 % busy and the held clock 2.38 ->
+// 1.92-2.0 GHz: on these shapes the kernel reaches the power limit (where edge_x_m16.hip's bf16 loop already is), and is faster there.
+// Same workgroup tile as edge_f16c8.hip (128 edges), same generated matrix-phase bodies (tools/gen/gen_c8_mphase.py w {1|2|k}); the
+// epilogues are the shared 32x32-accumulator ones of edge_tile.h.  Three kernels:
+//   edge_c8w_kernel<false, 2>  coordinate branch: 512 columns per workgroup, 2 column blocks of 32 per wave (128 accumulator
+//                              registers), three-slot operand requests, one column share per XCD;
+//   edge_c8wk_kernel           message branch (the default): 256 columns, the K loop split inside SIMD pairs (below);
+//   edge_c8w_kernel<true, 1>   message branch with one column block per wave and whole-chunk request distances (EGNN_C8_KSPLIT=0: the
+//                              form the K-split kernel was measured against).
 //   fp16 image of a chunk: [8 k-groups][129 rows][16 B] (row padding instead of an XOR swizzle: a lane's pieces of all four k-steps
 //   and row blocks are ONE base + immediates; the 8 lanes that store a row's pieces hit 8 different slots);
 //   e4m3 image: four K blocks [128 rows][32 B] at q * 4096 + 64 (q >> 1) (a store instruction's two blocks on the two halves of
@@ -692,15 +696,13 @@ __global__ __launch_bounds__(kT, 2) void edge_c8wk_kernel(const EdgeParams p) {
 // e4m3 B fragments of the correction product for v_mfma_scale_f32_32x32x64_f8f6f4, one instruction per 32 hidden units:
 //   out[((nb * KS32 + t) * 2 + piece) * 1024 + lane * 16 + j],  lane l: column 32 nb + (l & 31), K block h = l >> 5
 //   block 0 holds e4m3(2^s_hi W_hi), block 1 e4m3(2^s_lo W_lo) of hidden units 32 t + [0, 32); register piece `piece` holds hidden
-//   units 16 piece .. + 15 of the block.  Scale exponents from *maxbits as pack_frags_c8 (c8_absmax_kernel ran before).
+//   units 16 piece .. + 15 of the block.  The scale exponent is the one pack_frags_c8 chose for this matrix (edge_f16c8.hip: it ran
+//   before on the same stream and left the e8m0 byte 127 - s_hi in exps[0], which the edge kernels of both tile shapes read).
 __global__ void pack_frags_c8w(const float* __restrict__ W, int Nout, int K, int ldw, int NP, int KP, unsigned char* __restrict__ out,
-                               float scale, const unsigned* __restrict__ maxbits) {
+                               float scale, const int* __restrict__ exps) {
   __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);   // MODE.FP16_OVFL: the conversions saturate
   const int KS32 = KP / 32;
-  const float mx = fminf(__builtin_bit_cast(float, *maxbits), 65504.f);
-  int s_hi = 0;
-  if (mx > 0.f) s_hi = (int)floorf(log2f(224.0f / mx));
-  s_hi = s_hi > 40 ? 40 : (s_hi < -40 ? -40 : s_hi);
+  const int s_hi = 127 - exps[0];
   const float inv_hi = __builtin_ldexpf(1.0f, -s_hi), inv_lo = __builtin_ldexpf(1.0f, -s_hi - 11);
   const size_t total = (size_t)(NP / 32) * KS32 * 2 * 64 * 8;   // byte PAIRS
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -756,11 +758,10 @@ int launch_edge_f16c8w_m(const EdgeParams& p, hipStream_t st) {
   return EGNN_OK;
 }
 
-// e4m3 stream for the 32x32x64 instruction; maxbits: the matrix's largest |w| as float bits (pack_c8_stream ran before: it also
-// wrote the scale exponents the edge kernels read)
-int pack_c8w_stream(const float* W, int Nout, int K, int ldw, int NP, int KP, void* out, float scale, const unsigned* maxbits,
-                    hipStream_t st) {
-  hipLaunchKernelGGL(pack_frags_c8w, dim3(256), dim3(256), 0, st, W, Nout, K, ldw, NP, KP, static_cast<unsigned char*>(out), scale, maxbits);
+// e4m3 stream for the 32x32x64 instruction; exps: the matrix's scale exponents as pack_c8_stream left them (it runs before, on the
+// same stream)
+int pack_c8w_stream(const float* W, int Nout, int K, int ldw, int NP, int KP, void* out, float scale, const int* exps, hipStream_t st) {
+  hipLaunchKernelGGL(pack_frags_c8w, dim3(256), dim3(256), 0, st, W, Nout, K, ldw, NP, KP, static_cast<unsigned char*>(out), scale, exps);
   EGNN_HIP(hipGetLastError());
   return EGNN_OK;
 }

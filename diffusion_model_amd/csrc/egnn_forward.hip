@@ -1696,8 +1696,8 @@ int egnn_pack_layer(egnn_ctx* c, void* stream, int l, const float* m0_w, const f
     if ((rc = pack_c8_stream(m2_w, M, Wm, Wm, MP, WmP, lp.w2m_c8, s2 * kF16WScale, lp.c8_exp + 2, reinterpret_cast<unsigned*>(lp.c8_exp + 5), st))) return rc;
     // ... and for the 32x32 tiles of edge_f16c8w.hip (same scale exponents)
     hipLaunchKernelGGL(pack_frags_bf16<_Float16>, g, b, 0, st, x2_w, Wx, Wx, Wx, WxP, WxP, reinterpret_cast<_Float16*>(lp.w2x_f16s), s2 * kF16WScale);
-    if ((rc = pack_c8w_stream(x2_w, Wx, Wx, Wx, WxP, WxP, lp.w2x_c8w, s2 * kF16WScale, reinterpret_cast<unsigned*>(lp.c8_exp + 4), st))) return rc;
-    if ((rc = pack_c8w_stream(m2_w, M, Wm, Wm, MP, WmP, lp.w2m_c8w, s2 * kF16WScale, reinterpret_cast<unsigned*>(lp.c8_exp + 5), st))) return rc;
+    if ((rc = pack_c8w_stream(x2_w, Wx, Wx, Wx, WxP, WxP, lp.w2x_c8w, s2 * kF16WScale, lp.c8_exp, st))) return rc;
+    if ((rc = pack_c8w_stream(m2_w, M, Wm, Wm, MP, WmP, lp.w2m_c8w, s2 * kF16WScale, lp.c8_exp + 2, st))) return rc;
     hipLaunchKernelGGL(pack_frags_bf16_lo, g, b, 0, st, x2_w, Wx, Wx, Wx, WxP, WxP, reinterpret_cast<__bf16*>(lp.w2x_bf16s_lo), s2);
     hipLaunchKernelGGL(pack_frags_bf16_lo, g, b, 0, st, m2_w, M, Wm, Wm, MP, WmP, reinterpret_cast<__bf16*>(lp.w2m_bf16s_lo), s2);
     hipLaunchKernelGGL(pack_frags_bf16<__bf16>, g, b, 0, st, h0_w, Wh, H + M, H + M, WhP, c->K1Q, reinterpret_cast<__bf16*>(lp.w1h_bf16), 1.0f);

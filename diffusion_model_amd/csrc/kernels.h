@@ -355,7 +355,7 @@ int launch_edge_f16c8w_x(const EdgeParams& p, hipStream_t st);
 int launch_edge_f16c8w_m(const EdgeParams& p, hipStream_t st);
 bool edge_f16c8w_supported(const EdgeParams& p);
 int init_edge_f16c8w_attributes();
-int pack_c8w_stream(const float* W, int Nout, int K, int ldw, int NP, int KP, void* out, float scale, const unsigned* maxbits, hipStream_t st);
+int pack_c8w_stream(const float* W, int Nout, int K, int ldw, int NP, int KP, void* out, float scale, const int* exps, hipStream_t st);
 int pack_c8_stream(const float* W, int Nout, int K, int ldw, int NP, int KP, void* out, float scale, int* exps, unsigned* maxbits,
                    hipStream_t st);
 
